@@ -1,0 +1,143 @@
+"""oracle_capi.py -- TEST INFRASTRUCTURE: ctypes loader for oracle/_build/libfbus_oracle*.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this.  The product package (fbus-ekf_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+FBO_MAX_MARKERS = 32
+MATLAB, CPP = 0, 1
+NEAREST, STACKED = 0, 1
+SIMPLE, JOSEPH = 0, 1
+
+
+class FboParams(C.Structure):
+    _fields_ = [
+        ("dialect", C.c_int), ("nstate", C.c_int),
+        ("q_diag", C.c_double * 4), ("r_pos", C.c_double), ("r_quat", C.c_double),
+        ("R_IL", C.c_double * 9), ("P_IL", C.c_double * 3), ("Q_IL", C.c_double * 4),
+        ("n_markers", C.c_int), ("marker_id", C.c_int * FBO_MAX_MARKERS),
+        ("marker_pos", (C.c_double * 3) * FBO_MAX_MARKERS),
+        ("marker_quat", (C.c_double * 4) * FBO_MAX_MARKERS),
+        ("switch_thres", C.c_double), ("cov_form", C.c_int),
+    ]
+
+
+class FbvParams(C.Structure):
+    _fields_ = [
+        ("R_IL", C.c_double * 9), ("P_LI", C.c_double * 3),
+        ("R_IR", C.c_double * 9), ("P_RI", C.c_double * 3),
+        ("n_air", C.c_double), ("n_glass", C.c_double), ("n_water", C.c_double),
+        ("d_air", C.c_double), ("d_glass", C.c_double), ("normal", C.c_double * 3),
+    ]
+
+
+def build(native=False):
+    """make the oracle library; returns its path."""
+    target = ["native"] if native else []
+    subprocess.run(["make", "-C", _HERE] + target, check=True, stdout=subprocess.DEVNULL)
+    name = "libfbus_oracle_native.so" if native else "libfbus_oracle.so"
+    return os.path.join(_HERE, "_build", name)
+
+
+_libs = {}
+
+
+def load(native=False):
+    key = bool(native)
+    if key in _libs:
+        return _libs[key]
+    name = "libfbus_oracle_native.so" if native else "libfbus_oracle.so"
+    path = os.path.join(_HERE, "_build", name)
+    if not os.path.exists(path):
+        path = build(native)
+    lib = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int)
+    lib.fbo_default_params.argtypes = [C.POINTER(FboParams), C.c_int, C.c_int]
+    lib.fbo_default_P0.argtypes = [C.POINTER(FboParams), dp]
+    lib.fbo_predict_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), dp, dp, dp, C.c_int, C.c_int]
+    lib.fbo_correct_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, ip, dp, dp,
+                                      C.c_int, ip, C.c_int]
+    lib.fbv_default_params.argtypes = [C.POINTER(FbvParams)]
+    lib.fbv_refraction_triangulate.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
+    lib.fbv_normal_triangulate.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
+    lib.fbv_marker_pose.argtypes = [dp, dp, dp, dp]
+    _libs[key] = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class Oracle:
+    """Batched fp64 oracle over flat numpy arrays (nominal Bx19, rot Bx9, P Bxnxn, prev B)."""
+
+    def __init__(self, dialect=MATLAB, nstate=18, cov_form=SIMPLE, native=False, nthreads=1):
+        self.lib = load(native)
+        self.prm = FboParams()
+        self.lib.fbo_default_params(C.byref(self.prm), dialect, nstate)
+        self.prm.cov_form = cov_form
+        self.n = nstate
+        self.nthreads = nthreads
+
+    def P0(self):
+        P = np.zeros((self.n, self.n))
+        self.lib.fbo_default_P0(C.byref(self.prm), _dp(P))
+        return P
+
+    def predict(self, nominal, rot, P, prev, accel, gyro, dt):
+        B = nominal.shape[0]
+        accel = np.ascontiguousarray(accel, np.float64)
+        gyro = np.ascontiguousarray(gyro, np.float64)
+        dt = np.ascontiguousarray(np.atleast_1d(dt), np.float64)
+        stride = 1 if dt.size == B and B > 1 else 0
+        for a in (nominal, rot, P):
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+        assert prev.dtype == np.int32
+        self.lib.fbo_predict_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm),
+                                   _dp(accel), _dp(gyro), _dp(dt), stride, self.nthreads)
+
+    def correct(self, nominal, rot, P, prev, ids, pos, quat, mode=NEAREST):
+        B = nominal.shape[0]
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        pos = np.ascontiguousarray(pos, np.float64).reshape(B, M, 3)
+        quat = np.ascontiguousarray(quat, np.float64).reshape(B, M, 4)
+        applied = np.zeros(B, np.int32)
+        self.lib.fbo_correct_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), M,
+                                   _ip(ids), _dp(pos), _dp(quat), mode, _ip(applied), self.nthreads)
+        return applied
+
+
+def vision_params():
+    lib = load()
+    p = FbvParams()
+    lib.fbv_default_params(C.byref(p))
+    return p
+
+
+def refraction_triangulate(p, left8, right8):
+    lib = load()
+    out = np.zeros(12)
+    lib.fbv_refraction_triangulate(C.byref(p), _dp(np.ascontiguousarray(left8, np.float64)),
+                                   _dp(np.ascontiguousarray(right8, np.float64)), _dp(out))
+    return out.reshape(4, 3)
+
+
+def marker_pose(corners12):
+    lib = load()
+    c = np.ascontiguousarray(corners12, np.float64).reshape(12)
+    pos, quat, rot = np.zeros(3), np.zeros(4), np.zeros(9)
+    lib.fbv_marker_pose(_dp(c), _dp(pos), _dp(quat), _dp(rot))
+    return pos, quat, rot.reshape(3, 3)

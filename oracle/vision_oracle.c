@@ -1,0 +1,285 @@
+/*
+ * vision_oracle.c -- TEST INFRASTRUCTURE (see vision_oracle.h).
+ * fp64 restatement of C++/src/vision.cpp:395-759 (triangulation + marker pose).
+ */
+#include "vision_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+#define FBV_REF_PI 3.1415926   /* C++/include/common.hpp:14 redefines M_PI to this value */
+
+static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double nrm3(const double* a) { return sqrt(dot3(a, a)); }
+static void cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void m3v(const double* R, const double* x, double* y)
+{
+    for (int i = 0; i < 3; ++i) y[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
+}
+static double det3cols(const double* c0, const double* c1, const double* c2)
+{
+    return c0[0] * (c1[1] * c2[2] - c1[2] * c2[1])
+         - c1[0] * (c0[1] * c2[2] - c0[2] * c2[1])
+         + c2[0] * (c0[1] * c1[2] - c0[2] * c1[1]);
+}
+
+/* cyclic Jacobi for a symmetric n x n matrix (n <= 4); V columns = eigenvectors */
+static void jacobi_sym(double* A, double* V, int n)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+static void rotmat_to_quat(const double R[9], double q[4])
+{   /* Eigen Quaterniond(Matrix3d), vision.cpp:758 */
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (R[7] - R[5]) * t;
+        q[2] = (R[2] - R[6]) * t;
+        q[3] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[1 + i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[3 * k + j] - R[3 * j + k]) * t;
+        q[1 + j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        q[1 + k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+}
+
+void fbv_default_params(fbv_params* p)
+{
+    /* C++/config/camerainfo1.yml (== matlab/config/camerainfo.yml) TSC blocks, raw */
+    static const double RL[9] = { -0.999862, 0.015685, -0.00548,
+                                  -0.015639, -0.999843, -0.00827,
+                                  -0.005609, -0.008183, 0.999951 };
+    static const double PL[3] = { 0.059967, 0.000127837, -0.002 };
+    static const double RR[9] = { -0.999826, 0.00929485, -0.0161445,
+                                  -0.00937869, -0.999942, 0.00514829,
+                                  -0.0160959, 0.00529897, 0.999857 };
+    static const double PR[3] = { -0.0601272, 0.000124714, -0.002 };
+    memcpy(p->R_IL, RL, sizeof(RL)); memcpy(p->P_LI, PL, sizeof(PL));
+    memcpy(p->R_IR, RR, sizeof(RR)); memcpy(p->P_RI, PR, sizeof(PR));
+    /* C++/config/paramconfig.yml:31-42 */
+    p->n_air = 1.00; p->n_glass = 1.49; p->n_water = 1.32;
+    p->d_air = 0.002; p->d_glass = 0.02;
+    p->normal[0] = 0; p->normal[1] = 0; p->normal[2] = 1;
+}
+
+/* one Snell refraction of unit ray r at an interface with normal nv; `first`
+ * selects which comparison the reference makes (vision.cpp:513-522 vs 532-541) */
+static void refract(const double* r, const double* nv, double alpha, int sqrt_minus, double* out, double* v_out)
+{
+    double v = dot3(r, nv);
+    double root = sqrt(1 - alpha * alpha * (1 - v * v));
+    double beta = sqrt_minus ? (root - alpha * v) : (alpha * v - root);
+    for (int i = 0; i < 3; ++i) out[i] = alpha * r[i] + beta * nv[i];
+    *v_out = v;
+}
+
+void fbv_refraction_triangulate(const fbv_params* p, const double left[8], const double right[8],
+                                double corners[12])
+{
+    /* vision.cpp:476-481 */
+    double R_RL[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += p->R_IL[3 * i + k] * p->R_IR[3 * j + k];
+            R_RL[3 * i + j] = acc;
+        }
+    double tmp[3], P_LR[3];
+    m3v(R_RL, p->P_RI, tmp);
+    for (int i = 0; i < 3; ++i) P_LR[i] = p->P_LI[i] - tmp[i];
+
+    for (int c = 0; c < 4; ++c) {
+        double pl[3] = { left[2 * c], left[2 * c + 1], 1.0 };
+        double pr[3] = { right[2 * c], right[2 * c + 1], 1.0 };
+        double nl = nrm3(pl), nr = nrm3(pr);
+        double r0L[3], r0R[3];
+        for (int i = 0; i < 3; ++i) { r0L[i] = pl[i] / nl; r0R[i] = pr[i] / nr; }
+
+        double alpha0 = p->n_air / p->n_glass;          /* :508-524 */
+        double r1L[3], r1R[3], v0L, v0R;
+        refract(r0L, p->normal, alpha0, p->n_air < p->n_glass, r1L, &v0L);
+        refract(r0R, p->normal, alpha0, p->n_air < p->n_glass, r1R, &v0R);
+        double alpha1 = p->n_glass / p->n_water;        /* :527-543 */
+        double r2L[3], r2R[3], v1L, v1R;
+        refract(r1L, p->normal, alpha1, p->n_glass > p->n_water, r2L, &v1L);
+        refract(r1R, p->normal, alpha1, p->n_glass > p->n_water, r2R, &v1R);
+
+        double P1L[3], P1R[3];                          /* :546-552 */
+        for (int i = 0; i < 3; ++i) {
+            P1L[i] = (p->d_air / v0L) * r0L[i] + (p->d_glass / v1L) * r1L[i];
+            P1R[i] = (p->d_air / v0R) * r0R[i] + (p->d_glass / v1R) * r1R[i];
+        }
+        double r2RL[3], P1RL[3];                        /* :555-556 */
+        m3v(R_RL, r2R, r2RL);
+        m3v(R_RL, P1R, P1RL);
+        for (int i = 0; i < 3; ++i) P1RL[i] += P_LR[i];
+
+        double cr[3], dP[3];                            /* :559-595 (Cramer) */
+        cross3(r2L, r2RL, cr);
+        for (int i = 0; i < 3; ++i) dP[i] = P1RL[i] - P1L[i];
+        double d1 = det3cols(cr, dP, r2RL);
+        double d2 = det3cols(cr, r2L, dP);
+        double d3 = det3cols(cr, r2L, r2RL);
+        double t1 = d1 / d3, t2 = -d2 / d3;
+        for (int i = 0; i < 3; ++i) {
+            double P = 0.5 * (P1L[i] + t1 * r2L[i] + P1RL[i] + t2 * r2RL[i]);
+            corners[3 * c + i] = (i < 2) ? -P : P;      /* :597-599 */
+        }
+    }
+}
+
+void fbv_normal_triangulate(const fbv_params* p, const double left[8], const double right[8],
+                            double corners[12])
+{
+    /* vision.cpp:399-409 */
+    double Rlr[9], t[3], tmp[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += p->R_IR[3 * i + k] * p->R_IL[3 * j + k];
+            Rlr[3 * i + j] = acc;
+        }
+    m3v(Rlr, p->P_RI, tmp);
+    for (int i = 0; i < 3; ++i) t[i] = p->P_LI[i] - tmp[i];
+    for (int c = 0; c < 4; ++c) {
+        double l[3] = { left[2 * c], left[2 * c + 1], 1.0 };
+        double r[3] = { right[2 * c], right[2 * c + 1], 1.0 };
+        double A[24];                                   /* 6 x 4, :424-426 */
+        double Sl[9] = { 0, -l[2], l[1],  l[2], 0, -l[0],  -l[1], l[0], 0 };
+        double Sr[9] = { 0, -r[2], r[1],  r[2], 0, -r[0],  -r[1], r[0], 0 };
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) A[i * 4 + j] = Sl[3 * i + j];
+            A[i * 4 + 3] = 0;
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += Sr[3 * i + k] * Rlr[3 * k + j];
+                A[(3 + i) * 4 + j] = acc;
+            }
+            A[(3 + i) * 4 + 3] = Sr[3 * i] * t[0] + Sr[3 * i + 1] * t[1] + Sr[3 * i + 2] * t[2];
+        }
+        /* right singular vector of the smallest singular value (:429-434)
+         * = eigenvector of A'A with the smallest eigenvalue */
+        double G[16], V[16];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double acc = 0;
+                for (int k = 0; k < 6; ++k) acc += A[k * 4 + i] * A[k * 4 + j];
+                G[i * 4 + j] = acc;
+            }
+        jacobi_sym(G, V, 4);
+        int kmin = 0;
+        for (int k = 1; k < 4; ++k) if (G[k * 4 + k] < G[kmin * 4 + kmin]) kmin = k;
+        double X[4] = { V[kmin], V[4 + kmin], V[8 + kmin], V[12 + kmin] };
+        double Pn[3] = { -X[0] / X[3], -X[1] / X[3], X[2] / X[3] };   /* :441-444 */
+        double sg = (Pn[2] < 0) ? -1.0 : 1.0;                         /* :445, Signum */
+        for (int i = 0; i < 3; ++i) corners[3 * c + i] = sg * Pn[i];
+    }
+}
+
+void fbv_marker_pose(const double corners[12], double pos[3], double quat[4], double rot[9])
+{
+    const double* C0 = corners;
+    const double* C1 = corners + 3;
+    const double* C2 = corners + 6;
+    const double* C3 = corners + 9;
+    /* vision.cpp:634-675 : scatter of the six corner differences */
+    const double* a[6] = { C1, C2, C3, C2, C3, C3 };
+    const double* b[6] = { C0, C0, C0, C1, C1, C2 };
+    double M[9] = { 0 };
+    for (int k = 0; k < 6; ++k) {
+        double v[3] = { a[k][0] - b[k][0], a[k][1] - b[k][1], a[k][2] - b[k][2] };
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M[3 * i + j] += v[i] * v[j];
+    }
+    /* :677-709 : eigenvector of the smallest eigenvalue = plane normal, sign rule */
+    double V[9];
+    jacobi_sym(M, V, 3);
+    int kmin = 0;
+    for (int k = 1; k < 3; ++k) if (M[4 * k] < M[4 * kmin]) kmin = k;
+    double Z[3] = { V[kmin], V[3 + kmin], V[6 + kmin] };
+    double zn = nrm3(Z);
+    for (int i = 0; i < 3; ++i) Z[i] /= zn;
+    if (Z[2] > 0.1) {
+        for (int i = 0; i < 3; ++i) Z[i] = -Z[i];
+    } else if (Z[2] < -0.1) {
+        /* keep */
+    } else {
+        double s = -((C0[0] < 0) ? -1.0 : 1.0) * ((Z[0] < 0) ? -1.0 : 1.0);
+        for (int i = 0; i < 3; ++i) Z[i] *= s;
+    }
+    /* :711-721 : plane offset and corner projections */
+    double sum[3] = { C0[0] + C1[0] + C2[0] + C3[0], C0[1] + C1[1] + C2[1] + C3[1], C0[2] + C1[2] + C2[2] + C3[2] };
+    double D = 0.25 * dot3(Z, sum);
+    double P1[3], P2[3], P4[3];
+    double t1 = dot3(Z, C0) - D, t2 = dot3(Z, C1) - D, t4 = dot3(Z, C3) - D;
+    for (int i = 0; i < 3; ++i) {
+        P1[i] = C0[i] - t1 * Z[i];
+        P2[i] = C1[i] - t2 * Z[i];
+        P4[i] = C3[i] - t4 * Z[i];
+    }
+    /* :736-751 : in-plane axes */
+    double V12[3], V14[3], m[3];
+    for (int i = 0; i < 3; ++i) { V12[i] = P2[i] - P1[i]; V14[i] = P4[i] - P1[i]; }
+    double n12 = nrm3(V12), n14 = nrm3(V14);
+    for (int i = 0; i < 3; ++i) m[i] = V12[i] / n12 + V14[i] / n14;
+    double ang = -FBV_REF_PI / 4, c = cos(ang), s = sin(ang);
+    double Rm[9];                       /* Eigen AngleAxisd(ang, Z).matrix() */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rm[3 * i + j] = (1 - c) * Z[i] * Z[j] + ((i == j) ? c : 0.0);
+    Rm[1] -= s * Z[2]; Rm[2] += s * Z[1];
+    Rm[3] += s * Z[2]; Rm[5] -= s * Z[0];
+    Rm[6] -= s * Z[1]; Rm[7] += s * Z[0];
+    double X[3], Y[3], mn = nrm3(m);
+    m3v(Rm, m, X);
+    for (int i = 0; i < 3; ++i) X[i] /= mn;
+    cross3(Z, X, Y);
+    /* :753-762 */
+    for (int i = 0; i < 3; ++i) { rot[3 * i] = X[i]; rot[3 * i + 1] = Y[i]; rot[3 * i + 2] = Z[i]; }
+    rotmat_to_quat(rot, quat);
+    memcpy(pos, P1, 3 * sizeof(double));
+}
