@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- EKF steps/s of the batched predict/correct hot path on N MI355X.
+
+Workload (BASELINE.json / BASELINE.md section 2.1): 200 Hz IMU + 30 Hz stereo, 4 markers
+per frame, batch 65 536 filters PER GPU (weak scaling), fp32, N = 18 parity layout,
+Matlab dialect.  One bench "step" = 0.1 s of simulated time for the whole batch
+= 20 predict launches + 3 correct launches in the 7/7/6 pattern = 23 EKF steps per
+filter, every launch through the per-call C ABI (the state makes a full HBM round
+trip per EKF step).  Inputs are generated on the host with the seeded synthetic
+generator and are resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract: see the task statement).  `roofline` is for the
+dominant kernel (predict): algorithmic bytes per launch (1620 B x B) / its average
+duration measured with HIP events on the launch stream inside the timed region.
+`cpu_baseline` is the fp64 dense oracle port (oracle/), timed on a bounded sample.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+PATTERN = (7, 7, 6)                 # predicts between corrects: 200 Hz IMU / 30 Hz stereo
+STEPS_PER_BENCH_STEP = sum(PATTERN) + len(PATTERN)      # 23 EKF steps per filter
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PREDICT_BYTES = 2 * 796 + 28        # packed record round trip + IMU sample
+CORRECT_BYTES_M4 = 2 * 796 + 32 * 4
+POOL = 4                            # distinct bench steps of input data resident in HBM, cycled
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536, help="filters per GPU")
+    ap.add_argument("--markers", type=int, default=4)
+    ap.add_argument("--mode", choices=["stacked", "nearest"], default="stacked")
+    ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, prm_dialect, seconds):
+    """fp64 dense oracle port on the host cores, on a bounded sample of the same workload."""
+    import oracle_capi as oc
+    from fbus_ekf import capi, synth
+    try:
+        oc.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    cores = os.cpu_count() or 1
+    prm = capi.default_params(prm_dialect)
+    mode = 1 if args.mode == "stacked" else 0
+
+    def run(Bs, threads, reps):
+        orc = oc.Oracle(prm_dialect, 18, native=native, nthreads=threads)
+        nom, rot, P, prev = synth.initial_state(0, Bs, list(prm.p0_diag), 18)
+        acc, gyr = synth.imu_samples(0, Bs, 0, sum(PATTERN), nom)
+        frames = [synth.marker_frame(0, Bs, f, args.markers, nom, prm) for f in range(len(PATTERN))]
+        dt = np.array([0.005])
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            k = 0
+            for f, K in enumerate(PATTERN):
+                for _k in range(K):
+                    orc.predict(nom, rot, P, prev, acc[k], gyr[k], dt)
+                    k += 1
+                orc.correct(nom, rot, P, prev, *frames[f], mode)
+        return Bs * STEPS_PER_BENCH_STEP * reps / (time.perf_counter() - t0)
+
+    probe = run(256, 1, 1)                                   # steps/s of one thread, short probe
+    Bs1 = int(min(8192, max(256, probe * min(seconds, 4.0) / STEPS_PER_BENCH_STEP)))
+    one = run(Bs1, 1, 1)
+    BsN = int(min(65536, max(1024, one * cores * 0.7 * seconds / STEPS_PER_BENCH_STEP)))
+    allc = run(BsN, cores, 1)
+    return {"value": allc, "unit": "EKF steps/s", "cores": cores, "kind": "port",
+            "sample": f"{BsN} filters x 1 bench step (20 predict + 3 correct, M={args.markers}, {args.mode}), "
+                      f"fp64 dense oracle port, {cores} threads, {'-march=native' if native else 'generic x86-64'}",
+            "value_1thread": one}
+
+
+def main():
+    args = parse()
+    import torch
+    from fbus_ekf import BatchedFilter, capi, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    dialect = capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP
+    mode = capi.MODE_STACKED if args.mode == "stacked" else capi.MODE_NEAREST
+    B, M = args.batch, args.markers
+    prm = capi.default_params(dialect)
+    lo, hi = shard.weak_range(B, rank)                       # this rank's filters in the global index space
+
+    # ---- synthetic inputs, uploaded before timing --------------------------------------
+    nom, rot, P, prev = synth.initial_state(lo, hi, list(prm.p0_diag), 18)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    pool = []
+    for s in range(POOL):
+        acc, gyr = synth.imu_samples(lo, hi, s * sum(PATTERN), sum(PATTERN), nom)
+        frames = []
+        for f in range(len(PATTERN)):
+            ids, pos, quat = synth.marker_frame(lo, hi, s * len(PATTERN) + f, M, nom, prm)
+            frames.append((torch.from_numpy(ids).to(dev), f32(pos), f32(quat)))
+        pool.append((f32(acc), f32(gyr), frames))
+    d_dt = f32(np.full(max(PATTERN), 0.005))
+
+    flt = BatchedFilter(B, prm, device=local_rank, dtype=32, nstate=18)
+    flt.set_stream(torch.cuda.current_stream())
+    flt.set_state(nom, rot, P, prev)
+    ptr, bpf, total = flt.records()
+    rec = torch.empty(total, dtype=torch.uint8, device=dev)  # records live in a torch tensor -> RCCL can ship them
+    flt.attach_records(rec)
+
+    def bench_step(i):
+        acc, gyr, frames = pool[i % POOL]
+        k = 0
+        for f, K in enumerate(PATTERN):
+            ids, pos, quat = frames[f]
+            flt.frame(acc[k:k + K], gyr[k:k + K], d_dt[:K], ids, pos, quat, mode)
+            k += K
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    flt.timing_enable(True)
+    for i in range(args.warmup):
+        bench_step(i)
+    torch.cuda.synchronize()
+    flt.timing_reset()
+    flt._keep.clear()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        bench_step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, dist, world, dev)
+
+    pred_ms, pred_n = flt.timing_read(capi.KERNEL_PREDICT)
+    corr_ms, corr_n = flt.timing_read(capi.KERNEL_CORRECT)
+    flt.timing_enable(False)
+
+    # ---- the single end-of-run collective: gather the packed records (timed separately) ----
+    torch.cuda.synchronize()
+    barrier()
+    tg = time.perf_counter()
+    gathered = shard.gather_records(rec, dist, world)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    nomf, _, Pf, _ = flt.get_state()
+    finite = bool(np.isfinite(nomf).all() and np.isfinite(Pf).all())
+
+    if rank == 0:
+        total_steps = world * B * STEPS_PER_BENCH_STEP * args.steps
+        value = total_steps / elapsed
+        pred_avg_ms = pred_ms / max(pred_n, 1)
+        achieved = PREDICT_BYTES * B / (pred_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "EKF steps/s (ImuUpdate+MeasureUpdate), batch=65536, 4 markers",
+            "value": value, "unit": "EKF steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch {B} filters/GPU, 200 Hz IMU + 30 Hz stereo (7/7/6 predicts per correct), "
+                                   f"{M} markers/frame, N=18, {args.dialect} dialect, correct mode {args.mode}, "
+                                   "per-call API (one launch per EKF step)",
+                       "batch_per_gpu": B, "markers": M, "ekf_steps_per_bench_step": STEPS_PER_BENCH_STEP,
+                       "parallelism": f"independent filter shards x{world}, one RCCL gather at the end"},
+            "roofline": {"bound": "hbm", "kernel": "predict_kernel<float,18>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_us": pred_avg_ms * 1e3, "launches": pred_n,
+                         "algorithmic_bytes_per_launch": PREDICT_BYTES * B},
+            "correct_kernel": {"avg_launch_us": corr_ms / max(corr_n, 1) * 1e3, "launches": corr_n,
+                               "achieved_GBs": CORRECT_BYTES_M4 * B / (corr_ms / max(corr_n, 1) * 1e-3) / 1e9},
+            "gather_ms": gather_ms, "gathered_bytes": int(sum(g.numel() for g in gathered)),
+            "state_finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, dialect, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    flt.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

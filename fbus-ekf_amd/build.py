@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Builds fbus-ekf_amd/lib/libfbus_ekf.so (HIP, gfx950) in-tree with hipcc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", "fbus_ekf.hip"), os.path.join(HERE, "csrc", "fbus_vision.hip")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "..", "include", "fbus_ekf.h")]
+OUT = os.path.join(HERE, "lib", "libfbus_ekf.so")
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    srcs = [s for s in SRC if os.path.exists(s)]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,468 @@
+// ekf_device.hpp -- device-side arithmetic of the batched error-state EKF (gfx950).
+//
+// Mapping: ONE FILTER PER LANE.  A lane keeps its filter's whole record --
+// nominal state (19), carried rotation (9), previous-marker id (1) and the
+// packed upper triangle of the N x N covariance (171 for N = 18) -- in VGPRs;
+// every loop below has compile-time bounds and is fully unrolled so that all
+// indexing is static (no scratch).  The structure of the reference's matrices
+// is exploited instead of forming dense N x N products:
+//
+//   predict   F = E_th * E_v * E_p  (three elementary block-row operations), so
+//             F P F' is applied as three in-place symmetric congruences
+//             (~800 FMA instead of ~23 k for the dense product);
+//   correct   the 7 rows of one marker (R is diagonal) are applied as 7
+//             sequential scalar updates at one linearisation point, which is
+//             algebraically the reference's K = P H' (H P H' + R)^-1 block
+//             update; H has non-zeros only in the p and theta columns.
+//
+// What the arithmetic reproduces (paths relative to the upstream repository):
+//   predict : matlab/ImuUpdate.m:36-82 ; C++/src/filter.cpp:533-616
+//   correct : matlab/MeasureUpdate.m:37-103 ; C++/src/filter.cpp:622-741
+//   helpers : matlab/quaternion_*.m, vector_to_crossmat.m ; C++/include/matrix_math.hpp:26-99
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fbus {
+
+enum { DIALECT_MATLAB = 0, DIALECT_CPP = 1 };
+enum { MODE_NEAREST = 0, MODE_STACKED = 1 };
+enum { COV_SIMPLE = 0, COV_JOSEPH = 1 };
+
+constexpr int MK_STRIDE = 24;   // per marker-map slot: pos3 quat4 C16 pad1
+
+// ---- record layout (elements of T inside one filter's record) ----------------
+template <int N>
+struct Lay {
+    static constexpr int NP = N * (N + 1) / 2;
+    static constexpr int OFF_P3 = 0, OFF_V = 3, OFF_Q = 6, OFF_BA = 10, OFF_BG = 13, OFF_G = 16;
+    static constexpr int OFF_R = 19, OFF_PREV = 28, OFF_COV = 29;
+    static constexpr int NREC = OFF_COV + NP;
+};
+
+template <typename T, int N>
+struct Rec {
+    static constexpr int EPC = 16 / (int)sizeof(T);                       // elements per 16-byte chunk
+    static constexpr int NRECP = (Lay<N>::NREC + EPC - 1) / EPC * EPC;    // padded record length
+    static constexpr int NCH = NRECP / EPC;                               // chunks per record
+};
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float>  { using type = float4;  };
+template <> struct Vec16<double> { using type = double2; };
+
+template <int N>
+__host__ __device__ constexpr int pidx(int i, int j)
+{
+    return (i <= j) ? (i * N - (i * (i - 1)) / 2 + (j - i)) : (j * N - (j * (j - 1)) / 2 + (i - j));
+}
+
+// ---- scalar helpers -------------------------------------------------------------
+__device__ __forceinline__ void fb_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ __forceinline__ void fb_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
+__device__ __forceinline__ float fb_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double fb_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fb_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double fb_abs(double x) { return fabs(x); }
+
+template <typename T>
+__device__ __forceinline__ void quat_mul(const T* p, const T* q, T* o)
+{   // quaternion_add.m:22-28
+    o[0] = p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3];
+    o[1] = p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2];
+    o[2] = p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+    o[3] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+}
+
+template <typename T>
+__device__ __forceinline__ void quat_to_rotmat_m(const T* q, T* R)
+{   // quaternion_to_rotmat.m:22-33
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z);           R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);           R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);           R[7] = 2 * (y * z + w * x);           R[8] = w * w - x * x - y * y + z * z;
+}
+
+template <typename T>
+__device__ __forceinline__ void quat_to_rotmat_e(const T* q, T* R)
+{   // Eigen Quaternion::toRotationMatrix (filter.cpp:542,562,564)
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    const T tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const T twx = tx * w, twy = ty * w, twz = tz * w;
+    const T txx = tx * x, txy = ty * x, txz = tz * x;
+    const T tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+template <typename T>
+__device__ __forceinline__ void quat_normalize(T* q)
+{
+    const T inv = T(1) / fb_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+
+// ---- constants handed to the kernels by value (wave-uniform -> SGPRs) -------------
+template <typename T>
+struct DevConst {
+    T qd[4];                // process noise on v, theta, ba, bg diagonals
+    T r_pos, r_quat;
+    T R_IL[9], P_IL[3], Q_IL[4];
+    T switch_thres;
+    int cov_form;
+    const T* mk;            // [n_slots][MK_STRIDE]: pos3 quat4 C16, C = Rq(Qm) Lq(Q_IL) L2
+    const short* id2slot;   // [FBUS_MAX_MARKER_ID + 1], -1 = not in the map
+};
+
+// ================================================================================
+// predict
+// ================================================================================
+// Covariance propagation P <- F P F' + Fi Q Fi', packed symmetric, in place.
+// R = carried rotation, a = accel - ba, Th = F(theta,theta) block.
+template <typename T, int N>
+__device__ __forceinline__ void cov_propagate(T* P, const T* R, const T* a, const T (&Th)[9], T dt, const T* qd)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+    constexpr bool G = (N == 18);
+    // A = -R [a]x dt (v,theta) ; Bm = -R dt (v,ba)      ImuUpdate.m:65-66 ; filter.cpp:600-601
+    T A[9], Bm[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T r0 = R[3 * i], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
+        A[3 * i + 0] = -dt * (r1 * a[2] - r2 * a[1]);
+        A[3 * i + 1] = -dt * (r2 * a[0] - r0 * a[2]);
+        A[3 * i + 2] = -dt * (r0 * a[1] - r1 * a[0]);
+        Bm[3 * i + 0] = -dt * r0; Bm[3 * i + 1] = -dt * r1; Bm[3 * i + 2] = -dt * r2;
+    }
+
+    // ---- E_p : rows p += dt * rows v ---------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j)
+            PS(i, j) += dt * (PS(j, 3 + i) + PS(i, 3 + j)) + dt * dt * PS(3 + i, 3 + j);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 3; c < N; ++c) PS(i, c) += dt * PS(3 + i, c);
+
+    // ---- E_v : rows v += A * rows theta + Bm * rows ba + dt * rows g ----------------
+#define INC(i, c) (A[3 * (i)] * PS(6, (c)) + A[3 * (i) + 1] * PS(7, (c)) + A[3 * (i) + 2] * PS(8, (c)) \
+                 + Bm[3 * (i)] * PS(9, (c)) + Bm[3 * (i) + 1] * PS(10, (c)) + Bm[3 * (i) + 2] * PS(11, (c)) \
+                 + (G ? dt * PS(15 + (i), (c)) : T(0)))
+    T Ut[9], Ua[9], Ug[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Ut[3 * i + j] = INC(i, 6 + j);
+            Ua[3 * i + j] = INC(i, 9 + j);
+            Ug[3 * i + j] = G ? INC(i, 15 + j) : T(0);
+        }
+    T D[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                acc += (PS(3 + i, 6 + k) + T(0.5) * Ut[3 * i + k]) * A[3 * j + k];
+                acc += (PS(3 + i, 9 + k) + T(0.5) * Ua[3 * i + k]) * Bm[3 * j + k];
+            }
+            if (G) acc += dt * (PS(3 + i, 15 + j) + T(0.5) * Ug[3 * i + j]);
+            D[3 * i + j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) PS(3 + i, 3 + j) += D[3 * i + j] + D[3 * j + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int c = 12; c < 15; ++c) PS(3 + i, c) += INC(i, c);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) PS(c, 3 + i) += INC(i, c);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            PS(3 + i, 6 + j) += Ut[3 * i + j];
+            PS(3 + i, 9 + j) += Ua[3 * i + j];
+            if (G) PS(3 + i, 15 + j) += Ug[3 * i + j];
+        }
+#undef INC
+
+    // ---- E_th : rows theta = Th * rows theta - dt * rows bg --------------------------
+    T Xn[9], Gm[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Xn[3 * i + j] = Th[3 * i] * PS(6, 12 + j) + Th[3 * i + 1] * PS(7, 12 + j) + Th[3 * i + 2] * PS(8, 12 + j)
+                          - dt * PS(12 + i, 12 + j);
+            Gm[3 * i + j] = Th[3 * i] * PS(6, 6 + j) + Th[3 * i + 1] * PS(7, 6 + j) + Th[3 * i + 2] * PS(8, 6 + j);
+        }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        if ((c >= 6 && c < 9) || (c >= 12 && c < 15)) continue;
+        const T o0 = PS(6, c), o1 = PS(7, c), o2 = PS(8, c);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            PS(6 + i, c) = Th[3 * i] * o0 + Th[3 * i + 1] * o1 + Th[3 * i + 2] * o2 - dt * PS(12 + i, c);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+            const T t1 = Gm[3 * i] * Th[3 * j] + Gm[3 * i + 1] * Th[3 * j + 1] + Gm[3 * i + 2] * Th[3 * j + 2];
+            PS(6 + i, 6 + j) = t1 - dt * (Xn[3 * i + j] + Xn[3 * j + i]) - dt * dt * PS(12 + i, 12 + j);
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) PS(6 + i, 12 + j) = Xn[3 * i + j];
+
+    // ---- + Fi Q Fi' (not scaled by dt)              ImuUpdate.m:70-73 ; filter.cpp:609-610
+#pragma unroll
+    for (int i = 3; i < 15; ++i) PS(i, i) += qd[(i - 3) / 3];
+#undef PS
+}
+
+// One ImuUpdate on the record held in registers.
+template <typename T, int N, int DIALECT>
+__device__ __forceinline__ void predict_step(T* rec, const T* accel, const T* gyro, T dt, const T* qd)
+{
+    using L = Lay<N>;
+    T* p = rec + L::OFF_P3; T* v = rec + L::OFF_V; T* q = rec + L::OFF_Q;
+    const T* ba = rec + L::OFF_BA; const T* bg = rec + L::OFF_BG; const T* g = rec + L::OFF_G;
+    T* R = rec + L::OFF_R; T* P = rec + L::OFF_COV;
+
+    const T a[3] = { accel[0] - ba[0], accel[1] - ba[1], accel[2] - ba[2] };   // ImuUpdate.m:37-38
+    const T w[3] = { gyro[0] - bg[0], gyro[1] - bg[1], gyro[2] - bg[2] };
+    const T wn = fb_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+
+    T Th[9], qT[4], qH[4], R0[9], RH[9], RT[9];
+    if (DIALECT == DIALECT_MATLAB) {
+        // ImuUpdate.m:41-48,68.  axis/|axis| is NaN at w == 0 in the reference; guarded here
+        // (identity rotation), bit-identical away from zero.
+        const T inv = (wn > T(0)) ? T(1) / wn : T(0);
+        const T n[3] = { w[0] * inv, w[1] * inv, w[2] * inv };
+        const T dth = wn * fb_abs(dt);
+        T s2, c2, s4, c4;
+        fb_sincos(dth * T(0.5), s2, c2);
+        fb_sincos(dth * T(0.25), s4, c4);
+        const T dqT[4] = { c2, n[0] * s2, n[1] * s2, n[2] * s2 };
+        const T dqH[4] = { c4, n[0] * s4, n[1] * s4, n[2] * s4 };
+        quat_mul(q, dqT, qT);
+        quat_mul(q, dqH, qH);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R0[i] = R[i];                 // carried, possibly stale (:46)
+        quat_to_rotmat_m(qH, RH);
+        quat_to_rotmat_m(qT, RT);
+        // expm(-[w]x dt) in closed form: I - sin(phi)[n]x + (1-cos(phi))[n]x^2 with
+        // sin(phi) = 2 s2 c2 and 1-cos(phi) = 2 s2^2 (no cancellation in fp32).
+        const T sa = (dt < T(0) ? -T(2) : T(2)) * s2 * c2, sb = T(2) * s2 * s2;
+        Th[0] = T(1) - sb + sb * n[0] * n[0]; Th[1] = sb * n[0] * n[1] + sa * n[2]; Th[2] = sb * n[0] * n[2] - sa * n[1];
+        Th[3] = sb * n[1] * n[0] - sa * n[2]; Th[4] = T(1) - sb + sb * n[1] * n[1]; Th[5] = sb * n[1] * n[2] + sa * n[0];
+        Th[6] = sb * n[2] * n[0] + sa * n[1]; Th[7] = sb * n[2] * n[1] - sa * n[0]; Th[8] = T(1) - sb + sb * n[2] * n[2];
+    } else {
+        // filter.cpp:539-564,603
+        quat_to_rotmat_e(q, R0);                                   // fresh (:542)
+        if (wn > T(10e-5)) {
+            const T inv = T(1) / wn;
+            const T n[3] = { w[0] * inv, w[1] * inv, w[2] * inv };
+            T s2, c2, s4, c4;
+            fb_sincos(wn * dt * T(0.5), s2, c2);
+            fb_sincos(wn * dt * T(0.25), s4, c4);
+            const T dqT[4] = { c2, n[0] * s2, n[1] * s2, n[2] * s2 };
+            const T dqH[4] = { c4, n[0] * s4, n[1] * s4, n[2] * s4 };
+            quat_mul(q, dqT, qT);
+            quat_mul(q, dqH, qH);
+        } else {
+            const T dqT[4] = { T(1), T(0.5) * dt * w[0], T(0.5) * dt * w[1], T(0.5) * dt * w[2] };
+            const T dqH[4] = { T(1), T(0.25) * dt * w[0], T(0.25) * dt * w[1], T(0.25) * dt * w[2] };
+            quat_mul(q, dqT, qT);
+            quat_mul(q, dqH, qH);
+        }
+        quat_normalize(qH);
+        quat_normalize(qT);
+        quat_to_rotmat_e(qH, RH);
+        quat_to_rotmat_e(qT, RT);
+        Th[0] = T(1);        Th[1] = w[2] * dt;   Th[2] = -w[1] * dt;
+        Th[3] = -w[2] * dt;  Th[4] = T(1);        Th[5] = w[0] * dt;
+        Th[6] = w[1] * dt;   Th[7] = -w[0] * dt;  Th[8] = T(1);
+    }
+
+    // covariance first: it reads the pre-step (carried) rotation (filter.cpp:510)
+    cov_propagate<T, N>(P, R, a, Th, dt, qd);
+
+    // velocity / position, RK4-style   ImuUpdate.m:49-60 ; filter.cpp:567-581
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T kv1 = R0[3 * i] * a[0] + R0[3 * i + 1] * a[1] + R0[3 * i + 2] * a[2] + g[i];
+        const T kv2 = RH[3 * i] * a[0] + RH[3 * i + 1] * a[1] + RH[3 * i + 2] * a[2] + g[i];
+        const T kv4 = RT[3 * i] * a[0] + RT[3 * i + 1] * a[1] + RT[3 * i + 2] * a[2] + g[i];
+        const T kv3 = kv2;
+        const T v0 = v[i];
+        v[i] = v0 + dt / 6 * (kv1 + 2 * kv2 + 2 * kv3 + kv4);
+        const T kp2 = v0 + kv1 * dt / 2, kp3 = v0 + kv2 * dt / 2, kp4 = v0 + kv3 * dt / 2;   // dt/2 sic
+        p[i] = p[i] + dt / 6 * (v0 + 2 * kp2 + 2 * kp3 + kp4);
+    }
+    if (DIALECT == DIALECT_MATLAB) quat_normalize(qT);               // ImuUpdate.m:76
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = qT[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = RT[i];                        // ImuUpdate.m:77 ; filter.cpp:564
+}
+
+// ================================================================================
+// correct
+// ================================================================================
+// One scalar measurement row h (non-zeros hA in columns 0..2, hB in columns 6..8),
+// residual rk, noise Rk, applied to P and accumulated into dx.
+template <typename T, int N, bool HAS_A>
+__device__ __forceinline__ void scalar_update(T* P, T* dx, const T* hA, const T* hB, T rk, T Rk, int cov_form)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+    T Ph[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T acc = hB[0] * PS(i, 6) + hB[1] * PS(i, 7) + hB[2] * PS(i, 8);
+        if (HAS_A) acc += hA[0] * PS(i, 0) + hA[1] * PS(i, 1) + hA[2] * PS(i, 2);
+        Ph[i] = acc;
+    }
+    T s = Rk + hB[0] * Ph[6] + hB[1] * Ph[7] + hB[2] * Ph[8];
+    T inn = rk - (hB[0] * dx[6] + hB[1] * dx[7] + hB[2] * dx[8]);
+    if (HAS_A) {
+        s += hA[0] * Ph[0] + hA[1] * Ph[1] + hA[2] * Ph[2];
+        inn -= hA[0] * dx[0] + hA[1] * dx[1] + hA[2] * dx[2];
+    }
+    const T is = T(1) / s;
+    T K[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        K[i] = Ph[i] * is;
+        dx[i] += K[i] * inn;
+    }
+    if (cov_form == COV_JOSEPH) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = i; j < N; ++j) PS(i, j) += s * K[i] * K[j] - K[i] * Ph[j] - Ph[i] * K[j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = i; j < N; ++j) PS(i, j) -= K[i] * Ph[j];
+    }
+#undef PS
+}
+
+// The 7 rows of one marker (map slot constants mk), linearised at the record's
+// nominal state (which is not modified until inject()).
+template <typename T, int N, int DIALECT>
+__device__ __forceinline__ void marker_update(T* rec, T* dx, const DevConst<T>& dc, const T* __restrict__ mk,
+                                              const T* yp, const T* yq)
+{
+    using L = Lay<N>;
+    const T* p = rec + L::OFF_P3; const T* q = rec + L::OFF_Q; const T* R = rec + L::OFF_R;
+    T* P = rec + L::OFF_COV;
+    T Pm[3], Qm[4], Cm[16];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Pm[i] = mk[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Qm[i] = mk[3 + i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Cm[i] = mk[7 + i];
+
+    // hp = R_IL R' (Pm - p - R P_IL)          MeasureUpdate.m:67 ; filter.cpp:684-685
+    T d[3], u[3], t[3], hp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        u[i] = Pm[i] - p[i];
+        d[i] = u[i] - (R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2]);
+    }
+    T ru[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        t[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
+        ru[i] = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2];      // R'(Pm - p)
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hp[i] = dc.R_IL[3 * i] * t[0] + dc.R_IL[3 * i + 1] * t[1] + dc.R_IL[3 * i + 2] * t[2];
+    // hq = Q_IL (x) q* (x) Qm                  MeasureUpdate.m:68 ; filter.cpp:686
+    const T qc[4] = { q[0], -q[1], -q[2], -q[3] };
+    T tmp[4], hq[4];
+    quat_mul(dc.Q_IL, qc, tmp);
+    quat_mul(tmp, Qm, hq);
+
+    // H(1:3,1:3) = -R_IL R' ; H(1:3,7:9) = R_IL [R'(Pm-p)]x      MeasureUpdate.m:72-73 ; filter.cpp:691-692
+    T Hpp[9], Hpt[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Hpp[3 * i + j] = -(l0 * R[3 * j] + l1 * R[3 * j + 1] + l2 * R[3 * j + 2]);
+        Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
+        Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
+        Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
+    }
+    // H(4:7,7:9) = Rq(Qm) Lq(Q_IL) L2 Lq(q) L1 = C * (Lq(q) L1)   MeasureUpdate.m:74-75 ; filter.cpp:693-694
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    const T LL[12] = { -x, -y, -z,   w, -z, y,   z, w, -x,   -y, x, w };   // Lq(q)(:,2:4)
+    // sign unification                          MeasureUpdate.m:77-81 ; filter.cpp:698-706
+    T k1 = T(0), k2 = T(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k1 += (yq[i] - hq[i]) * (yq[i] - hq[i]);
+        k2 += (yq[i] + hq[i]) * (yq[i] + hq[i]);
+    }
+    const T sg = (k1 > k2) ? T(-0.5) : T(0.5);                    // 0.5 = L1
+    T Hq[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Hq[3 * i + j] = sg * (Cm[4 * i] * LL[j] + Cm[4 * i + 1] * LL[3 + j] + Cm[4 * i + 2] * LL[6 + j] + Cm[4 * i + 3] * LL[9 + j]);
+    const T sq = (k1 > k2) ? T(-1) : T(1);
+
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        scalar_update<T, N, true>(P, dx, Hpp + 3 * k, Hpt + 3 * k, yp[k] - hp[k], dc.r_pos, dc.cov_form);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // Matlab zeroes the quaternion residual (MeasureUpdate.m:88); C++ uses it (filter.cpp:718-721)
+        const T rk = (DIALECT == DIALECT_CPP) ? (yq[k] - sq * hq[k]) : T(0);
+        scalar_update<T, N, false>(P, dx, Hq + 3 * k, Hq + 3 * k, rk, dc.r_quat, dc.cov_form);
+    }
+}
+
+// State injection   MeasureUpdate.m:92-98 ; filter.cpp:726-733.  R is NOT refreshed.
+template <typename T, int N>
+__device__ __forceinline__ void inject(T* rec, const T* dx)
+{
+    using L = Lay<N>;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        rec[L::OFF_P3 + i] += dx[i];
+        rec[L::OFF_V + i] += dx[3 + i];
+        rec[L::OFF_BA + i] += dx[9 + i];
+        rec[L::OFF_BG + i] += dx[12 + i];
+        if (N == 18) rec[L::OFF_G + i] += dx[15 + i];
+    }
+    const T n2 = dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8];
+    const T nn = fb_sqrt(n2);
+    T s, c;
+    fb_sincos(nn * T(0.5), s, c);
+    const T k = (nn > T(0)) ? s / nn : T(0);                      // guard for the reference's 0/0
+    const T dq[4] = { c, dx[6] * k, dx[7] * k, dx[8] * k };
+    T qn[4];
+    quat_mul(rec + L::OFF_Q, dq, qn);
+    quat_normalize(qn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rec[L::OFF_Q + i] = qn[i];
+}
+
+}  // namespace fbus

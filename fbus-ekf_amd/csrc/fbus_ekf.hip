@@ -1,0 +1,883 @@
+// fbus_ekf.hip -- kernels, launchers and the C ABI (include/fbus_ekf.h) of the
+// MI355X-native batched error-state EKF.  gfx950 only; no CPU fallback.
+//
+// HBM layout of the filter records ("64-filter tiles of 16-byte chunks"): a record is
+// NRECP elements of T = NCH chunks of 16 bytes.  Filters are grouped in tiles of 64
+// (one wave); a tile is NCH consecutive 1 KiB pieces and piece c holds chunk c of the
+// tile's 64 filters, lane-major.  Chunk c of filter b is therefore at byte offset
+// ((b / 64) * NCH + c) * 1024 + (b % 64) * 16: a wave moves its tile with NCH fully
+// coalesced 1 KiB buffer_load_dwordx4 / buffer_store_dwordx4 over one contiguous
+// NCH KiB region, and a rank's records are one contiguous block for the RCCL gather.
+#include "../../include/fbus_ekf.h"
+#include "ekf_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace fbus;
+
+namespace {
+
+constexpr int BLOCK = 64;               // one wave per workgroup: B/64 workgroups spread over 256 CUs x 4 SIMDs
+
+// ---------------------------------------------------------------------------------
+// record <-> registers
+// ---------------------------------------------------------------------------------
+// A tile = the records of 64 consecutive filters = NCH pieces of 1 KiB; piece c holds
+// chunk c (16 bytes) of each of the 64 filters, so one wave moves a piece with one
+// buffer_load_dwordx4 / buffer_store_dwordx4.  The descriptor covers exactly one tile
+// (wave-uniform base), the lane contributes a 32-bit offset, the piece index goes
+// into soffset/imm -- no per-piece 64-bit address lives in VGPRs.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <typename T, int N>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const T* recs, unsigned tile)
+{
+    constexpr unsigned TILE_BYTES = Rec<T, N>::NCH * 1024u;
+    char* tb = const_cast<char*>(reinterpret_cast<const char*>(recs)) + (size_t)tile * TILE_BYTES;
+    return __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)TILE_BYTES, 0x00020000);
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void load_record(__amdgpu_buffer_rsrc_t rs, unsigned lane, T* rec)
+{
+    constexpr int EPC = Rec<T, N>::EPC;
+    const unsigned off = lane * 16u;
+#pragma unroll
+    for (int c = 0; c < Rec<T, N>::NCH; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (c & 3) * 1024u, (c >> 2) * 4096, 0);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) rec[c * EPC + k] = e[k];
+    }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void store_record(__amdgpu_buffer_rsrc_t rs, unsigned lane, const T* rec)
+{
+    constexpr int EPC = Rec<T, N>::EPC;
+    const unsigned off = lane * 16u;
+#pragma unroll
+    for (int c = 0; c < Rec<T, N>::NCH; ++c) {
+        u32x4 v;
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) e[k] = rec[c * EPC + k];
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c & 3) * 1024u, (c >> 2) * 4096, 0);
+    }
+}
+
+// element e of filter b inside the tiled record storage (pack/unpack helpers)
+template <typename T, int N>
+__device__ __forceinline__ size_t elem_index(size_t b, int e)
+{
+    constexpr int EPC = Rec<T, N>::EPC;
+    return ((b >> 6) * Rec<T, N>::NCH + (size_t)(e / EPC)) * (64 * EPC) + (b & 63) * EPC + (e % EPC);
+}
+
+// ---------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------
+// K consecutive ImuUpdates per launch (K = 1 is the per-call API).
+// accel/gyro: [K][B][3]; dt: [K] (dt_stride 0) or [K][B] (dt_stride 1).
+template <typename T, int N, int DIALECT, bool MULTI>
+__global__ void __launch_bounds__(BLOCK)
+predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
+               const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
+{
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
+    T rec[Rec<T, N>::NRECP];
+    load_record<T, N>(rs, threadIdx.x, rec);
+    if (MULTI) {
+        for (int k = 0; k < K; ++k) {
+            const size_t o = ((size_t)k * B + b) * 3;
+            const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
+            const T w[3] = { gyro[o], gyro[o + 1], gyro[o + 2] };
+            const T h = dt_stride ? dt[(size_t)k * B + b] : dt[k];
+            predict_step<T, N, DIALECT>(rec, a, w, h, dc.qd);
+        }
+    } else {
+        const size_t o = (size_t)b * 3;
+        const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
+        const T w[3] = { gyro[o], gyro[o + 1], gyro[o + 2] };
+        const T h = dt_stride ? dt[b] : dt[0];
+        predict_step<T, N, DIALECT>(rec, a, w, h, dc.qd);
+    }
+    store_record<T, N>(rs, threadIdx.x, rec);
+}
+
+template <typename T, int N, int DIALECT>
+__global__ void __launch_bounds__(BLOCK)
+correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+               const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
+               unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    if (skip && skip[b]) { applied[b] = 0; return; }
+
+    const int* my_ids = ids + (size_t)b * M;
+    const T* my_pos = pos + (size_t)b * M * 3;
+    const T* my_quat = quat + (size_t)b * M * 4;
+
+    int first = 0, last = M;            // marker slots [first, last) to apply
+    int new_prev = -1;
+    if (mode == MODE_NEAREST) {
+        // recs is re-read below; only the previous-marker id is needed for the selection
+        int prev_id = 0;
+        if (DIALECT == DIALECT_CPP) {
+            prev_id = (int)recs[elem_index<T, N>(b, L::OFF_PREV)];
+        }
+        // nearest visible marker, start threshold 10   MeasureUpdate.m:51-60 ; filter.cpp:639-664
+        int min_i = -1, prev_i = -1;
+        T min_d = T(10), prev_d = T(0);
+        for (int i = 0; i < M; ++i) {
+            const int id = my_ids[i];
+            if (id < 0) continue;
+            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
+            const T dist = fb_sqrt(x * x + y * y + z * z);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i < 0) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
+        const int id = my_ids[min_i];
+        const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+        if (slot < 0) { applied[b] = 0; return; }              // filter.cpp:671-673
+        if (DIALECT == DIALECT_CPP) new_prev = id;              // filter.cpp:675
+        first = min_i; last = min_i + 1;
+    }
+
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
+    T rec[Rec<T, N>::NRECP];
+    load_record<T, N>(rs, threadIdx.x, rec);
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    int used = 0;
+    for (int i = first; i < last; ++i) {
+        const int id = my_ids[i];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+        const int slot = dc.id2slot[id];
+        if (slot < 0) continue;
+        const T yp[3] = { my_pos[3 * i], my_pos[3 * i + 1], my_pos[3 * i + 2] };
+        const T yq[4] = { my_quat[4 * i], my_quat[4 * i + 1], my_quat[4 * i + 2], my_quat[4 * i + 3] };
+        marker_update<T, N, DIALECT>(rec, dx, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
+        ++used;
+    }
+    if (used == 0) { applied[b] = 0; return; }
+    inject<T, N>(rec, dx);
+    if (new_prev >= 0) rec[L::OFF_PREV] = (T)new_prev;
+    store_record<T, N>(rs, threadIdx.x, rec);
+    applied[b] = 1;
+}
+
+// AoS (API arrays) <-> records.  Not on the hot path.
+template <typename T, int N>
+__global__ void pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ nominal,
+                            const T* __restrict__ rot, const T* __restrict__ P, const int* __restrict__ prev)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    auto put = [&](int e, T v) { recs[elem_index<T, N>(b, e)] = v; };
+    if (nominal) for (int i = 0; i < 19; ++i) put(i, nominal[(size_t)b * 19 + i]);
+    if (rot) for (int i = 0; i < 9; ++i) put(L::OFF_R + i, rot[(size_t)b * 9 + i]);
+    if (prev) put(L::OFF_PREV, (T)prev[b]);
+    if (P)
+        for (int i = 0; i < N; ++i)
+            for (int j = i; j < N; ++j) {   // the reference symmetrises every step; store the mean of the two halves
+                const T u = P[((size_t)b * N + i) * N + j], l = P[((size_t)b * N + j) * N + i];
+                put(L::OFF_COV + pidx<N>(i, j), (u + l) / 2);
+            }
+}
+
+template <typename T, int N>
+__global__ void unpack_kernel(const T* __restrict__ recs, int B, T* __restrict__ nominal,
+                              T* __restrict__ rot, T* __restrict__ P, int* __restrict__ prev)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    auto get = [&](int e) { return recs[elem_index<T, N>(b, e)]; };
+    if (nominal) for (int i = 0; i < 19; ++i) nominal[(size_t)b * 19 + i] = get(i);
+    if (rot) for (int i = 0; i < 9; ++i) rot[(size_t)b * 9 + i] = get(L::OFF_R + i);
+    if (prev) prev[b] = (int)get(L::OFF_PREV);
+    if (P)
+        for (int i = 0; i < N; ++i)
+            for (int j = i; j < N; ++j) {
+                const T v = get(L::OFF_COV + pidx<N>(i, j));
+                P[((size_t)b * N + i) * N + j] = v;
+                P[((size_t)b * N + j) * N + i] = v;
+            }
+}
+
+template <typename T, int N>
+__global__ void reset_cov_kernel(T* __restrict__ recs, int B, T d0, T d1, T d2, T d3, T d4, T d5)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const T d[6] = { d0, d1, d2, d3, d4, d5 };
+    for (int i = 0; i < N; ++i)
+        for (int j = i; j < N; ++j) {
+            const int e = L::OFF_COV + pidx<N>(i, j);
+            recs[elem_index<T, N>(b, e)] = (i == j) ? d[i / 3] : T(0);
+        }
+}
+
+// ---------------------------------------------------------------------------------
+// host-side constants
+// ---------------------------------------------------------------------------------
+void rotmat_to_quat(const double R[9], double q[4])
+{   // trace based, as Eigen's Quaterniond(Matrix3d) (filter.cpp:630, main.cpp marker load)
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[1 + i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[3 * k + j] - R[3 * j + k]) * t;
+        q[1 + j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        q[1 + k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+}
+
+struct HostConst {
+    double R_IL[9], P_IL[3], Q_IL[4];
+    std::vector<double> mk;             // n_markers x MK_STRIDE
+    std::vector<short> id2slot;
+};
+
+bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
+{
+    // T_IL = diag(-1,-1,1,1) * T_SC_left    FBUS_EKF.m:68 ; filter.hpp:67-70
+    double T[16];
+    std::memcpy(T, prm.T_SC_left, sizeof(T));
+    for (int j = 0; j < 4; ++j) { T[j] = -T[j]; T[4 + j] = -T[4 + j]; }
+    double t[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) hc.R_IL[3 * i + j] = T[4 * i + j];
+        t[i] = T[4 * i + 3];
+    }
+    for (int i = 0; i < 3; ++i)         // P_IL = -R_IL' t   MeasureUpdate.m:47 ; filter.cpp:631-632
+        hc.P_IL[i] = -(hc.R_IL[i] * t[0] + hc.R_IL[3 + i] * t[1] + hc.R_IL[6 + i] * t[2]);
+    rotmat_to_quat(hc.R_IL, hc.Q_IL);
+    if (prm.n_markers < 0 || prm.n_markers > FBUS_MAX_MARKERS) { err = "n_markers out of range"; return false; }
+    hc.id2slot.assign(FBUS_MAX_MARKER_ID + 1, (short)-1);
+    hc.mk.assign((size_t)std::max(prm.n_markers, 1) * MK_STRIDE, 0.0);
+    const double w = hc.Q_IL[0], x = hc.Q_IL[1], y = hc.Q_IL[2], z = hc.Q_IL[3];
+    // Lq(Q_IL) * L2, L2 = diag(1,-1,-1,-1)   MeasureUpdate.m:39-44
+    const double LL2[16] = { w,  x,  y,  z,
+                             x, -w,  z, -y,
+                             y, -z, -w,  x,
+                             z,  y, -x, -w };
+    for (int k = 0; k < prm.n_markers; ++k) {
+        const int id = prm.marker_id[k];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) { err = "marker id out of range"; return false; }
+        hc.id2slot[id] = (short)k;
+        double* m = &hc.mk[(size_t)k * MK_STRIDE];
+        for (int i = 0; i < 3; ++i) m[i] = prm.marker_pos[k][i];
+        double q[4];
+        rotmat_to_quat(prm.marker_rot[k], q);
+        for (int i = 0; i < 4; ++i) m[3 + i] = q[i];
+        // C = Rq(Qm) * Lq(Q_IL) * L2   (MeasureUpdate.m:74)
+        const double Rq[16] = { q[0], -q[1], -q[2], -q[3],
+                                q[1],  q[0],  q[3], -q[2],
+                                q[2], -q[3],  q[0],  q[1],
+                                q[3],  q[2], -q[1],  q[0] };
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double acc = 0;
+                for (int l = 0; l < 4; ++l) acc += Rq[4 * i + l] * LL2[4 * l + j];
+                m[7 + 4 * i + j] = acc;
+            }
+    }
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------
+struct fbus_ekf {
+    int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
+    fbus_params prm{};
+    HostConst hc;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    void* recs = nullptr;
+    bool own_recs = false;
+    size_t rec_bytes = 0, bytes_per_filter = 0;
+    void* d_mk = nullptr;
+    short* d_id2slot = nullptr;
+    unsigned char* d_applied = nullptr;
+    // staging for the host-pointer entry points (grown on demand)
+    void* stage[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t stage_cap[6] = { 0, 0, 0, 0, 0, 0 };
+    std::string err;
+    // timing
+    bool timing = false;
+    struct EvPair { hipEvent_t a, b; int kind; };
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0 };
+    int64_t t_n[FBUS_KERNEL_COUNT] = { 0, 0, 0 };
+};
+
+namespace {
+
+int fail(fbus_ekf_t h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((h), FBUS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+size_t esize(const fbus_ekf* h) { return h->dtype == 32 ? 4 : 8; }
+
+template <typename T>
+DevConst<T> make_dc(const fbus_ekf* h)
+{
+    DevConst<T> dc;
+    for (int i = 0; i < 4; ++i) dc.qd[i] = (T)h->prm.q_diag[i];
+    dc.r_pos = (T)h->prm.r_pos;
+    dc.r_quat = (T)h->prm.r_quat;
+    for (int i = 0; i < 9; ++i) dc.R_IL[i] = (T)h->hc.R_IL[i];
+    for (int i = 0; i < 3; ++i) dc.P_IL[i] = (T)h->hc.P_IL[i];
+    for (int i = 0; i < 4; ++i) dc.Q_IL[i] = (T)h->hc.Q_IL[i];
+    dc.switch_thres = (T)h->prm.switch_thres;
+    dc.cov_form = h->prm.cov_form;
+    dc.mk = (const T*)h->d_mk;
+    dc.id2slot = h->d_id2slot;
+    return dc;
+}
+
+int flush_events(fbus_ekf_t h)
+{
+    if (h->ev_used == 0) return FBUS_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
+        h->t_ms[h->ev_pool[i].kind] += ms;
+        h->t_n[h->ev_pool[i].kind] += 1;
+    }
+    h->ev_used = 0;
+    return FBUS_OK;
+}
+
+// returns the index of the event pair to close after the launch, or -1
+int timing_begin(fbus_ekf_t h, int kind)
+{
+    if (!h->timing) return -1;
+    if (h->ev_used == h->ev_pool.size()) {
+        if (h->ev_pool.size() >= 8192) {
+            if (flush_events(h) != FBUS_OK) return -1;
+        } else {
+            fbus_ekf::EvPair p;
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+            h->ev_pool.push_back(p);
+        }
+    }
+    const int i = (int)h->ev_used++;
+    h->ev_pool[i].kind = kind;
+    (void)hipEventRecord(h->ev_pool[i].a, h->stream);
+    return i;
+}
+
+void timing_end(fbus_ekf_t h, int i)
+{
+    if (i >= 0) (void)hipEventRecord(h->ev_pool[i].b, h->stream);
+}
+
+template <typename T, int N, int D>
+int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
+{
+    const int grid = (h->B + BLOCK - 1) / BLOCK;
+    const int ev = timing_begin(h, K == 1 ? FBUS_KERNEL_PREDICT : FBUS_KERNEL_PREDICT_N);
+    if (K == 1)
+        hipLaunchKernelGGL((predict_kernel<T, N, D, false>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, K,
+                           (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h));
+    else
+        hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, K,
+                           (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h));
+    timing_end(h, ev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+template <typename T, int N, int D>
+int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,
+                     const uint8_t* skip)
+{
+    const int grid = (h->B + BLOCK - 1) / BLOCK;
+    const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
+    hipLaunchKernelGGL((correct_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, M,
+                       (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied,
+                       make_dc<T>(h));
+    timing_end(h, ev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+#define DISPATCH(h, FN, ...)                                                                     \
+    do {                                                                                         \
+        const int key_ = ((h)->dtype == 64 ? 4 : 0) | ((h)->N == 15 ? 2 : 0) | ((h)->prm.dialect == FBUS_DIALECT_CPP ? 1 : 0); \
+        switch (key_) {                                                                          \
+            case 0: return FN<float, 18, DIALECT_MATLAB>(__VA_ARGS__);                           \
+            case 1: return FN<float, 18, DIALECT_CPP>(__VA_ARGS__);                              \
+            case 2: return FN<float, 15, DIALECT_MATLAB>(__VA_ARGS__);                           \
+            case 3: return FN<float, 15, DIALECT_CPP>(__VA_ARGS__);                              \
+            case 4: return FN<double, 18, DIALECT_MATLAB>(__VA_ARGS__);                          \
+            case 5: return FN<double, 18, DIALECT_CPP>(__VA_ARGS__);                             \
+            case 6: return FN<double, 15, DIALECT_MATLAB>(__VA_ARGS__);                          \
+            default: return FN<double, 15, DIALECT_CPP>(__VA_ARGS__);                            \
+        }                                                                                        \
+    } while (0)
+
+int launch_predict(fbus_ekf_t h, int K, const void* a, const void* g, const void* dt, int per)
+{
+    DISPATCH(h, launch_predict_t, h, K, a, g, dt, per);
+}
+
+int launch_correct(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,
+                   const uint8_t* skip)
+{
+    DISPATCH(h, launch_correct_t, h, M, ids, pos, quat, mode, skip);
+}
+
+template <typename T, int N>
+int pack_t(fbus_ekf_t h, const void* nom, const void* rot, const void* P, const int32_t* prev)
+{
+    const int grid = (h->B + 255) / 256;
+    hipLaunchKernelGGL((pack_kernel<T, N>), dim3(grid), dim3(256), 0, h->stream, (T*)h->recs, h->B,
+                       (const T*)nom, (const T*)rot, (const T*)P, (const int*)prev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+template <typename T, int N>
+int unpack_t(fbus_ekf_t h, void* nom, void* rot, void* P, int32_t* prev)
+{
+    const int grid = (h->B + 255) / 256;
+    hipLaunchKernelGGL((unpack_kernel<T, N>), dim3(grid), dim3(256), 0, h->stream, (const T*)h->recs, h->B,
+                       (T*)nom, (T*)rot, (T*)P, (int*)prev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+template <typename T, int N>
+int reset_cov_t(fbus_ekf_t h)
+{
+    const int grid = (h->B + 255) / 256;
+    const double* d = h->prm.p0_diag;
+    hipLaunchKernelGGL((reset_cov_kernel<T, N>), dim3(grid), dim3(256), 0, h->stream, (T*)h->recs, h->B,
+                       (T)d[0], (T)d[1], (T)d[2], (T)d[3], (T)d[4], (T)d[5]);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+#define DISPATCH2(h, FN, ...)                                                        \
+    do {                                                                             \
+        if ((h)->dtype == 32) {                                                      \
+            if ((h)->N == 18) return FN<float, 18>(__VA_ARGS__);                     \
+            return FN<float, 15>(__VA_ARGS__);                                       \
+        }                                                                            \
+        if ((h)->N == 18) return FN<double, 18>(__VA_ARGS__);                        \
+        return FN<double, 15>(__VA_ARGS__);                                          \
+    } while (0)
+
+int do_pack(fbus_ekf_t h, const void* n, const void* r, const void* P, const int32_t* pv) { DISPATCH2(h, pack_t, h, n, r, P, pv); }
+int do_unpack(fbus_ekf_t h, void* n, void* r, void* P, int32_t* pv) { DISPATCH2(h, unpack_t, h, n, r, P, pv); }
+int do_reset_cov(fbus_ekf_t h) { DISPATCH2(h, reset_cov_t, h); }
+
+int ensure_stage(fbus_ekf_t h, int slot, size_t bytes)
+{
+    if (bytes <= h->stage_cap[slot]) return FBUS_OK;
+    if (h->stage[slot]) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipFree(h->stage[slot]));
+        h->stage[slot] = nullptr;
+        h->stage_cap[slot] = 0;
+    }
+    HIP_TRY(h, hipMalloc(&h->stage[slot], bytes));
+    h->stage_cap[slot] = bytes;
+    return FBUS_OK;
+}
+
+// copies a host array into staging slot `slot`; returns the device pointer through out
+int stage_in(fbus_ekf_t h, int slot, const void* host, size_t bytes, const void** out)
+{
+    *out = nullptr;
+    if (!host || bytes == 0) return FBUS_OK;
+    int rc = ensure_stage(h, slot, bytes);
+    if (rc != FBUS_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->stage[slot], host, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = h->stage[slot];
+    return FBUS_OK;
+}
+
+size_t record_elems(int dtype, int N)
+{
+    if (dtype == 32) return N == 18 ? Rec<float, 18>::NRECP : Rec<float, 15>::NRECP;
+    return N == 18 ? Rec<double, 18>::NRECP : Rec<double, 15>::NRECP;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+const char* fbus_status_string(int s)
+{
+    switch (s) {
+        case FBUS_OK: return "ok";
+        case FBUS_ERR_INVALID: return "invalid argument";
+        case FBUS_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case FBUS_ERR_HIP: return "HIP runtime error";
+        case FBUS_ERR_UNSUPPORTED: return "unsupported dtype/nstate/mode";
+        case FBUS_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+int fbus_params_default(fbus_params* prm, int dialect)
+{
+    if (!prm || (dialect != FBUS_DIALECT_MATLAB && dialect != FBUS_DIALECT_CPP)) return FBUS_ERR_INVALID;
+    std::memset(prm, 0, sizeof(*prm));
+    prm->dialect = dialect;
+    prm->cov_form = FBUS_COV_SIMPLE;
+    // FBUS_EKF.m:36-39,103-106 ; paramconfig.yml:46-49 via filter.hpp:108-115
+    prm->q_diag[0] = 1e-3; prm->q_diag[1] = 1e-4; prm->q_diag[2] = 1e-3; prm->q_diag[3] = 1e-4;
+    if (dialect == FBUS_DIALECT_MATLAB) {
+        prm->r_pos = 0.01; prm->r_quat = 0.01;                       // FBUS_EKF.m:32-33
+        const double d[6] = { 1e-4, 0.1, 1e-4, 1e-3, 1e-3, 100.0 };  // FBUS_EKF.m:88-99
+        std::memcpy(prm->p0_diag, d, sizeof(d));
+    } else {
+        prm->r_pos = 0.001; prm->r_quat = 0.001;                     // paramconfig.yml:53-54
+        const double d[6] = { 1e-4, 1e-2, 1e-4, 1e-2, 1e-2, 100.0 }; // filter.hpp:29-34
+        std::memcpy(prm->p0_diag, d, sizeof(d));
+    }
+    // camerainfo1.yml == matlab/config/camerainfo.yml, raw T_SC
+    const double TL[16] = { -0.999862, 0.015685, -0.00548, 0.059967,
+                            -0.015639, -0.999843, -0.00827, 0.000127837,
+                            -0.005609, -0.008183, 0.999951, -0.002,
+                            0, 0, 0, 1 };
+    const double TR[16] = { -0.999826, 0.00929485, -0.0161445, -0.0601272,
+                            -0.00937869, -0.999942, 0.00514829, 0.000124714,
+                            -0.0160959, 0.00529897, 0.999857, -0.002,
+                            0, 0, 0, 1 };
+    std::memcpy(prm->T_SC_left, TL, sizeof(TL));
+    std::memcpy(prm->T_SC_right, TR, sizeof(TR));
+    // GetMarkerMap.m:1-63 == markersetup.yml
+    const double I3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    const double RA[9] = { 1, 0, 0, 0, 0, -1, 0, 1, 0 };
+    const double RB[9] = { 1, 0, 0, 0, -1, 0, 0, 0, -1 };
+    const struct { int id; double pos[3]; const double* rot; } map[12] = {
+        { 0, { 0, 0, 0 }, I3 },         { 1, { 0, 0.61, 0.285 }, RA },  { 2, { 0, 0.61, 1.185 }, RA },
+        { 3, { 0, 0.61, 2.085 }, RA },  { 4, { 0, 0.61, 2.985 }, RA },  { 5, { 0, 0.265, 4.12 }, RB },
+        { 6, { 0, -0.635, 4.12 }, RB }, { 7, { 0, -1.535, 4.12 }, RB }, { 8, { 0, -2.435, 4.12 }, RB },
+        { 16, { 0, -2.7, 0 }, I3 },     { 17, { 0, -1.8, 0 }, I3 },     { 18, { 0, -0.9, 0 }, I3 } };
+    prm->n_markers = 12;
+    for (int k = 0; k < 12; ++k) {
+        prm->marker_id[k] = map[k].id;
+        std::memcpy(prm->marker_pos[k], map[k].pos, sizeof(double) * 3);
+        std::memcpy(prm->marker_rot[k], map[k].rot, sizeof(double) * 9);
+    }
+    prm->switch_thres = 0.5;    // paramconfig.yml:57
+    prm->max_dist = 2.0;        // paramconfig.yml:56
+    prm->n_air = 1.00; prm->n_glass = 1.49; prm->n_water = 1.32;    // paramconfig.yml:31-42
+    prm->d_air = 0.002; prm->d_glass = 0.02;
+    prm->port_normal[0] = 0; prm->port_normal[1] = 0; prm->port_normal[2] = 1;
+    return FBUS_OK;
+}
+
+int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int device, int dtype, int nstate)
+{
+    if (!out) return FBUS_ERR_INVALID;
+    *out = nullptr;
+    if (!prm || batch <= 0) return FBUS_ERR_INVALID;
+    if ((dtype != 32 && dtype != 64) || (nstate != 15 && nstate != 18)) return FBUS_ERR_UNSUPPORTED;
+    if (prm->dialect != FBUS_DIALECT_MATLAB && prm->dialect != FBUS_DIALECT_CPP) return FBUS_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FBUS_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FBUS_ERR_NO_DEVICE;
+
+    fbus_ekf* h = new (std::nothrow) fbus_ekf();
+    if (!h) return FBUS_ERR_NOMEM;
+    h->B = batch;
+    h->Bs = (batch + 63) / 64 * 64;
+    h->device = device;
+    h->dtype = dtype;
+    h->N = nstate;
+    h->prm = *prm;
+    std::string err;
+    if (!build_host_const(h->prm, h->hc, err)) { delete h; return FBUS_ERR_INVALID; }
+
+    auto bail = [&](int code) { fbus_ekf_destroy(h); return code; };
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(FBUS_ERR_HIP);
+    h->stream = h->own_stream;
+    h->bytes_per_filter = record_elems(dtype, nstate) * esize(h);
+    h->rec_bytes = h->bytes_per_filter * (size_t)h->Bs;
+    if (hipMalloc(&h->recs, h->rec_bytes) != hipSuccess) return bail(FBUS_ERR_NOMEM);
+    h->own_recs = true;
+    if (hipMemsetAsync(h->recs, 0, h->rec_bytes, h->stream) != hipSuccess) return bail(FBUS_ERR_HIP);
+    if (hipMalloc((void**)&h->d_applied, (size_t)h->Bs) != hipSuccess) return bail(FBUS_ERR_NOMEM);
+    if (hipMemsetAsync(h->d_applied, 0, (size_t)h->Bs, h->stream) != hipSuccess) return bail(FBUS_ERR_HIP);
+    // marker table + id lookup
+    const size_t nmk = h->hc.mk.size();
+    if (hipMalloc(&h->d_mk, nmk * esize(h)) != hipSuccess) return bail(FBUS_ERR_NOMEM);
+    if (dtype == 32) {
+        std::vector<float> f(h->hc.mk.begin(), h->hc.mk.end());
+        if (hipMemcpy(h->d_mk, f.data(), nmk * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(FBUS_ERR_HIP);
+    } else {
+        if (hipMemcpy(h->d_mk, h->hc.mk.data(), nmk * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(FBUS_ERR_HIP);
+    }
+    const size_t lut = h->hc.id2slot.size() * sizeof(short);
+    if (hipMalloc((void**)&h->d_id2slot, lut) != hipSuccess) return bail(FBUS_ERR_NOMEM);
+    if (hipMemcpy(h->d_id2slot, h->hc.id2slot.data(), lut, hipMemcpyHostToDevice) != hipSuccess) return bail(FBUS_ERR_HIP);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(FBUS_ERR_HIP);
+    *out = h;
+    return FBUS_OK;
+}
+
+int fbus_ekf_destroy(fbus_ekf_t h)
+{
+    if (!h) return FBUS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& p : h->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (int i = 0; i < 6; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
+    if (h->own_recs && h->recs) (void)hipFree(h->recs);
+    if (h->d_applied) (void)hipFree(h->d_applied);
+    if (h->d_mk) (void)hipFree(h->d_mk);
+    if (h->d_id2slot) (void)hipFree(h->d_id2slot);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return FBUS_OK;
+}
+
+int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return FBUS_OK;
+}
+
+int fbus_ekf_sync(fbus_ekf_t h)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+const char* fbus_ekf_last_error(fbus_ekf_t h) { return h ? h->err.c_str() : "null handle"; }
+
+int fbus_ekf_set_state_dev(fbus_ekf_t h, const void* nominal, const void* rot, const void* P, const int32_t* prev_id)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    return do_pack(h, nominal, rot, P, prev_id);
+}
+
+int fbus_ekf_get_state_dev(fbus_ekf_t h, void* nominal, void* rot, void* P, int32_t* prev_id)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    return do_unpack(h, nominal, rot, P, prev_id);
+}
+
+int fbus_ekf_set_state(fbus_ekf_t h, const void* nominal, const void* rot, const void* P, const int32_t* prev_id)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), B = (size_t)h->B, N = (size_t)h->N;
+    const void *dn, *dr, *dP, *dp;
+    int rc;
+    if ((rc = stage_in(h, 0, nominal, B * 19 * es, &dn)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, rot, B * 9 * es, &dr)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 2, P, B * N * N * es, &dP)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 3, prev_id, B * 4, &dp)) != FBUS_OK) return rc;
+    if ((rc = do_pack(h, dn, dr, dP, (const int32_t*)dp)) != FBUS_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));    // host buffers may be reused by the caller
+    return FBUS_OK;
+}
+
+int fbus_ekf_get_state(fbus_ekf_t h, void* nominal, void* rot, void* P, int32_t* prev_id)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), B = (size_t)h->B, N = (size_t)h->N;
+    int rc;
+    if (nominal && (rc = ensure_stage(h, 0, B * 19 * es)) != FBUS_OK) return rc;
+    if (rot && (rc = ensure_stage(h, 1, B * 9 * es)) != FBUS_OK) return rc;
+    if (P && (rc = ensure_stage(h, 2, B * N * N * es)) != FBUS_OK) return rc;
+    if (prev_id && (rc = ensure_stage(h, 3, B * 4)) != FBUS_OK) return rc;
+    if ((rc = do_unpack(h, nominal ? h->stage[0] : nullptr, rot ? h->stage[1] : nullptr, P ? h->stage[2] : nullptr,
+                        prev_id ? (int32_t*)h->stage[3] : nullptr)) != FBUS_OK) return rc;
+    if (nominal) HIP_TRY(h, hipMemcpyAsync(nominal, h->stage[0], B * 19 * es, hipMemcpyDeviceToHost, h->stream));
+    if (rot) HIP_TRY(h, hipMemcpyAsync(rot, h->stage[1], B * 9 * es, hipMemcpyDeviceToHost, h->stream));
+    if (P) HIP_TRY(h, hipMemcpyAsync(P, h->stage[2], B * N * N * es, hipMemcpyDeviceToHost, h->stream));
+    if (prev_id) HIP_TRY(h, hipMemcpyAsync(prev_id, h->stage[3], B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_reset_cov(fbus_ekf_t h)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    return do_reset_cov(h);
+}
+
+int fbus_ekf_records(fbus_ekf_t h, void** dev_ptr, size_t* bytes_per_filter, size_t* total_bytes)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    if (dev_ptr) *dev_ptr = h->recs;
+    if (bytes_per_filter) *bytes_per_filter = h->bytes_per_filter;
+    if (total_bytes) *total_bytes = h->rec_bytes;
+    return FBUS_OK;
+}
+
+int fbus_ekf_attach_records(fbus_ekf_t h, void* dev_ptr, size_t total_bytes)
+{
+    if (!h || !dev_ptr) return FBUS_ERR_INVALID;
+    if (total_bytes != h->rec_bytes) return fail(h, FBUS_ERR_INVALID, "attach_records: size mismatch");
+    if (((uintptr_t)dev_ptr & 15) != 0) return fail(h, FBUS_ERR_INVALID, "attach_records: pointer not 16-byte aligned");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(dev_ptr, h->recs, h->rec_bytes, hipMemcpyDeviceToDevice));
+    if (h->own_recs) HIP_TRY(h, hipFree(h->recs));
+    h->recs = dev_ptr;
+    h->own_recs = false;
+    return FBUS_OK;
+}
+
+int fbus_ekf_predict_n_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
+{
+    if (!h || !accel || !gyro || !dt || K < 1) return FBUS_ERR_INVALID;
+    return launch_predict(h, K, accel, gyro, dt, dt_per_filter);
+}
+
+int fbus_ekf_predict_dev(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
+{
+    return fbus_ekf_predict_n_dev(h, 1, accel, gyro, dt, dt_per_filter);
+}
+
+int fbus_ekf_predict_n(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
+{
+    if (!h || !accel || !gyro || !dt || K < 1) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), B = (size_t)h->B;
+    const void *da, *dg, *dd;
+    int rc;
+    if ((rc = stage_in(h, 0, accel, (size_t)K * B * 3 * es, &da)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, gyro, (size_t)K * B * 3 * es, &dg)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 2, dt, (size_t)K * (dt_per_filter ? B : 1) * es, &dd)) != FBUS_OK) return rc;
+    if ((rc = launch_predict(h, K, da, dg, dd, dt_per_filter)) != FBUS_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));    // staging buffers are reused by the next host call
+    return FBUS_OK;
+}
+
+int fbus_ekf_predict(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
+{
+    return fbus_ekf_predict_n(h, 1, accel, gyro, dt, dt_per_filter);
+}
+
+int fbus_ekf_correct_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,
+                         const uint8_t* skip)
+{
+    if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    return launch_correct(h, M, ids, pos, quat, mode, skip);
+}
+
+int fbus_ekf_correct(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,
+                     const uint8_t* skip)
+{
+    if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    const size_t es = esize(h), B = (size_t)h->B;
+    const void *di, *dp, *dq, *ds;
+    int rc;
+    if ((rc = stage_in(h, 0, ids, B * M * 4, &di)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, pos, B * M * 3 * es, &dp)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 2, quat, B * M * 4 * es, &dq)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 3, skip, B, &ds)) != FBUS_OK) return rc;
+    if ((rc = launch_correct(h, M, (const int32_t*)di, dp, dq, mode, (const uint8_t*)ds)) != FBUS_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host)
+{
+    if (!h || !applied_host) return FBUS_ERR_INVALID;
+    HIP_TRY(h, hipMemcpyAsync(applied_host, h->d_applied, (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
+                       int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
+{
+    if (!h || K < 0) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), B = (size_t)h->B;
+    for (int k = 0; k < K; ++k) {
+        const char* a = (const char*)accel + (size_t)k * B * 3 * es;
+        const char* g = (const char*)gyro + (size_t)k * B * 3 * es;
+        const char* d = (const char*)dt + (size_t)k * (dt_per_filter ? B : 1) * es;
+        const int rc = launch_predict(h, 1, a, g, d, dt_per_filter);
+        if (rc != FBUS_OK) return rc;
+    }
+    if (M > 0) return fbus_ekf_correct_dev(h, M, ids, pos, quat, mode, skip);
+    return FBUS_OK;
+}
+
+int fbus_ekf_timing_enable(fbus_ekf_t h, int on)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    if (!on) { const int rc = flush_events(h); if (rc != FBUS_OK) return rc; }
+    h->timing = on != 0;
+    return FBUS_OK;
+}
+
+int fbus_ekf_timing_reset(fbus_ekf_t h)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    const int rc = flush_events(h);
+    if (rc != FBUS_OK) return rc;
+    for (int i = 0; i < FBUS_KERNEL_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    return FBUS_OK;
+}
+
+int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* launches)
+{
+    if (!h || kernel < 0 || kernel >= FBUS_KERNEL_COUNT) return FBUS_ERR_INVALID;
+    const int rc = flush_events(h);
+    if (rc != FBUS_OK) return rc;
+    if (total_ms) *total_ms = h->t_ms[kernel];
+    if (launches) *launches = h->t_n[kernel];
+    return FBUS_OK;
+}
+
+}  // extern "C"

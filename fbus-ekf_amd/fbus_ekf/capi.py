@@ -1,0 +1,105 @@
+"""ctypes binding of include/fbus_ekf.h (no torch, no numpy-side arithmetic)."""
+import ctypes as C
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)                       # fbus-ekf_amd/
+_HEADER = os.path.join(os.path.dirname(_ROOT), "include", "fbus_ekf.h")
+
+DIALECT_MATLAB, DIALECT_CPP = 0, 1
+MODE_NEAREST, MODE_STACKED = 0, 1
+COV_SIMPLE, COV_JOSEPH = 0, 1
+KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N = 0, 1, 2
+MAX_MARKERS, MAX_VISIBLE = 32, 16
+
+
+class FbusError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: status {code}" + (f" ({detail})" if detail else ""))
+
+
+class FbusParams(C.Structure):
+    _fields_ = [
+        ("dialect", C.c_int32), ("cov_form", C.c_int32),
+        ("q_diag", C.c_double * 4), ("r_pos", C.c_double), ("r_quat", C.c_double),
+        ("p0_diag", C.c_double * 6),
+        ("T_SC_left", C.c_double * 16), ("T_SC_right", C.c_double * 16),
+        ("n_markers", C.c_int32), ("marker_id", C.c_int32 * MAX_MARKERS),
+        ("marker_pos", (C.c_double * 3) * MAX_MARKERS), ("marker_rot", (C.c_double * 9) * MAX_MARKERS),
+        ("switch_thres", C.c_double), ("max_dist", C.c_double),
+        ("n_air", C.c_double), ("n_glass", C.c_double), ("n_water", C.c_double),
+        ("d_air", C.c_double), ("d_glass", C.c_double), ("port_normal", C.c_double * 3),
+    ]
+
+
+def library_path():
+    return os.path.join(_ROOT, "lib", "libfbus_ekf.so")
+
+
+def declared_symbols():
+    """Every function the public header declares (used by the export test)."""
+    text = open(_HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fbus_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FbusError(-1, "load_library",
+                        f"{path} is missing -- build it with `python fbus-ekf_amd/build.py` "
+                        "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p
+    H = C.c_void_p
+    sig = {
+        "fbus_params_default": ([C.POINTER(FbusParams), C.c_int], C.c_int),
+        "fbus_ekf_create": ([C.POINTER(H), C.POINTER(FbusParams), C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+        "fbus_ekf_destroy": ([H], C.c_int),
+        "fbus_ekf_set_stream": ([H, vp], C.c_int),
+        "fbus_ekf_sync": ([H], C.c_int),
+        "fbus_ekf_last_error": ([H], C.c_char_p),
+        "fbus_status_string": ([C.c_int], C.c_char_p),
+        "fbus_ekf_set_state": ([H, vp, vp, vp, ip], C.c_int),
+        "fbus_ekf_get_state": ([H, vp, vp, vp, ip], C.c_int),
+        "fbus_ekf_set_state_dev": ([H, vp, vp, vp, ip], C.c_int),
+        "fbus_ekf_get_state_dev": ([H, vp, vp, vp, ip], C.c_int),
+        "fbus_ekf_reset_cov": ([H], C.c_int),
+        "fbus_ekf_records": ([H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], C.c_int),
+        "fbus_ekf_attach_records": ([H, vp, C.c_size_t], C.c_int),
+        "fbus_ekf_predict": ([H, vp, vp, vp, C.c_int], C.c_int),
+        "fbus_ekf_predict_dev": ([H, vp, vp, vp, C.c_int], C.c_int),
+        "fbus_ekf_predict_n": ([H, C.c_int, vp, vp, vp, C.c_int], C.c_int),
+        "fbus_ekf_predict_n_dev": ([H, C.c_int, vp, vp, vp, C.c_int], C.c_int),
+        "fbus_ekf_correct": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_correct_dev": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_get_applied": ([H, u8p], C.c_int),
+        "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_timing_enable": ([H, C.c_int], C.c_int),
+        "fbus_ekf_timing_reset": ([H], C.c_int),
+        "fbus_ekf_timing_read": ([H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def default_params(dialect=DIALECT_MATLAB):
+    lib = load_library()
+    p = FbusParams()
+    rc = lib.fbus_params_default(C.byref(p), dialect)
+    if rc != 0:
+        raise FbusError(rc, "fbus_params_default")
+    return p

@@ -1,0 +1,206 @@
+"""BatchedFilter: the reference filter's predict()/correct() contract for B filters on one GPU.
+
+Mirrors `State = ImuUpdate(State, accel, gyro, dt)` (matlab/ImuUpdate.m:36) and
+`State = MeasureUpdate(State, visionMeas, markerMap, cameraInfo)`
+(matlab/MeasureUpdate.m:37) / FILTER::UpdateCovariance+UpdateNominalState and
+FILTER::ObservationUpdate (C++/src/filter.cpp:588-616,533-582,622-754), with the
+state owned by the object as in the C++ FILTER class.  All arithmetic happens in
+libfbus_ekf.so; this class only converts arguments.
+
+Host (numpy) arrays go through the staging entry points; device arrays (anything
+with `.data_ptr()`, e.g. torch tensors on the handle's GPU) go to the `_dev` entry
+points without copies.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _is_dev(x):
+    return hasattr(x, "data_ptr")
+
+
+class BatchedFilter:
+    def __init__(self, batch, params=None, dialect=capi.DIALECT_MATLAB, device=0, dtype=32, nstate=18,
+                 stream=None):
+        self._lib = capi.load_library()
+        self._h = C.c_void_p()
+        self.params = params if params is not None else capi.default_params(dialect)
+        self.B, self.device, self.dtype, self.N = int(batch), int(device), int(dtype), int(nstate)
+        self.np_dtype = np.float32 if dtype == 32 else np.float64
+        rc = self._lib.fbus_ekf_create(C.byref(self._h), C.byref(self.params), self.B, self.device, self.dtype, self.N)
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise capi.FbusError(rc, "fbus_ekf_create", self._lib.fbus_status_string(rc).decode())
+        self._keep = []          # device arrays that must outlive asynchronous launches
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ---- plumbing -------------------------------------------------------------
+    def _check(self, rc, where):
+        if rc != 0:
+            detail = self._lib.fbus_ekf_last_error(self._h).decode() or self._lib.fbus_status_string(rc).decode()
+            raise capi.FbusError(rc, where, detail)
+
+    def close(self):
+        if self._h:
+            self._lib.fbus_ekf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream):
+        """stream: an int/hipStream_t handle or an object with `.cuda_stream` (torch.cuda.Stream)."""
+        handle = getattr(stream, "cuda_stream", stream)
+        self._check(self._lib.fbus_ekf_set_stream(self._h, C.c_void_p(handle or None)), "set_stream")
+
+    def sync(self):
+        self._check(self._lib.fbus_ekf_sync(self._h), "sync")
+        self._keep.clear()
+
+    def _host(self, a, shape, dtype=None):
+        a = np.ascontiguousarray(a, dtype or self.np_dtype)
+        if a.size != int(np.prod(shape)):
+            raise ValueError(f"expected {shape}, got {a.shape}")
+        return a
+
+    @staticmethod
+    def _p(a):
+        if a is None:
+            return None
+        if _is_dev(a):
+            return C.c_void_p(a.data_ptr())
+        return a.ctypes.data_as(C.c_void_p)
+
+    def _dev_checked(self, a, numel, what):
+        if a.numel() != numel:
+            raise ValueError(f"{what}: expected {numel} elements, got {a.numel()}")
+        if hasattr(a, "is_contiguous") and not a.is_contiguous():
+            raise ValueError(f"{what}: device array must be contiguous")
+        self._keep.append(a)
+        return a
+
+    # ---- state ----------------------------------------------------------------
+    def set_state(self, nominal=None, rot=None, P=None, prev_id=None):
+        B, N = self.B, self.N
+        if any(_is_dev(x) for x in (nominal, rot, P, prev_id) if x is not None):
+            rc = self._lib.fbus_ekf_set_state_dev(self._h, self._p(nominal), self._p(rot), self._p(P), self._p(prev_id))
+            return self._check(rc, "set_state_dev")
+        nominal = None if nominal is None else self._host(nominal, (B, 19))
+        rot = None if rot is None else self._host(rot, (B, 9))
+        P = None if P is None else self._host(P, (B, N, N))
+        prev_id = None if prev_id is None else self._host(prev_id, (B,), np.int32)
+        rc = self._lib.fbus_ekf_set_state(self._h, self._p(nominal), self._p(rot), self._p(P), self._p(prev_id))
+        self._check(rc, "set_state")
+
+    def get_state(self):
+        B, N = self.B, self.N
+        nominal = np.empty((B, 19), self.np_dtype)
+        rot = np.empty((B, 9), self.np_dtype)
+        P = np.empty((B, N, N), self.np_dtype)
+        prev = np.empty(B, np.int32)
+        rc = self._lib.fbus_ekf_get_state(self._h, self._p(nominal), self._p(rot), self._p(P), self._p(prev))
+        self._check(rc, "get_state")
+        return nominal, rot, P, prev
+
+    def reset_cov(self):
+        self._check(self._lib.fbus_ekf_reset_cov(self._h), "reset_cov")
+
+    def records(self):
+        """(device pointer, bytes per filter, total bytes) of the packed records."""
+        ptr, bpf, tot = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._check(self._lib.fbus_ekf_records(self._h, C.byref(ptr), C.byref(bpf), C.byref(tot)), "records")
+        return ptr.value, bpf.value, tot.value
+
+    def attach_records(self, dev_array):
+        """Make the handle keep its records inside a caller-owned device array (e.g. a torch uint8 tensor)."""
+        nbytes = dev_array.numel() * dev_array.element_size()
+        self._check(self._lib.fbus_ekf_attach_records(self._h, self._p(dev_array), nbytes), "attach_records")
+        self._records_owner = dev_array
+
+    # ---- predict == ImuUpdate -----------------------------------------------------
+    def predict(self, accel, gyro, dt):
+        return self.predict_n(accel, gyro, dt, K=1)
+
+    def predict_n(self, accel, gyro, dt, K=None):
+        B = self.B
+        if _is_dev(accel):
+            K = K if K is not None else accel.numel() // (3 * B)
+            per = 1 if dt.numel() == K * B and not (B == 1 and dt.numel() == K) else 0
+            if not per and dt.numel() != K:
+                raise ValueError("dt must have K or K*B elements")
+            self._dev_checked(accel, K * B * 3, "accel"); self._dev_checked(gyro, K * B * 3, "gyro")
+            self._dev_checked(dt, dt.numel(), "dt")
+            rc = self._lib.fbus_ekf_predict_n_dev(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per)
+            return self._check(rc, "predict_n_dev")
+        accel = np.ascontiguousarray(accel, self.np_dtype)
+        K = K if K is not None else accel.size // (3 * B)
+        accel = self._host(accel, (K, B, 3))
+        gyro = self._host(gyro, (K, B, 3))
+        dt = np.ascontiguousarray(np.atleast_1d(dt), self.np_dtype)
+        per = 1 if (dt.size == K * B and B > 1) else 0
+        if not per and dt.size != K:
+            raise ValueError("dt must have K or K*B elements")
+        rc = self._lib.fbus_ekf_predict_n(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per)
+        self._check(rc, "predict_n")
+
+    # ---- correct == MeasureUpdate -----------------------------------------------------
+    def correct(self, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
+        B = self.B
+        if _is_dev(ids):
+            M = ids.numel() // B
+            self._dev_checked(ids, B * M, "ids"); self._dev_checked(pos, B * M * 3, "pos")
+            self._dev_checked(quat, B * M * 4, "quat")
+            if skip is not None:
+                self._dev_checked(skip, B, "skip")
+            rc = self._lib.fbus_ekf_correct_dev(self._h, M, self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
+            return self._check(rc, "correct_dev")
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        pos = self._host(pos, (B, M, 3))
+        quat = self._host(quat, (B, M, 4))
+        skip = None if skip is None else self._host(skip, (B,), np.uint8)
+        rc = self._lib.fbus_ekf_correct(self._h, M, self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
+        self._check(rc, "correct")
+
+    def applied(self):
+        out = np.empty(self.B, np.uint8)
+        self._check(self._lib.fbus_ekf_get_applied(self._h, self._p(out)), "get_applied")
+        return out
+
+    def frame(self, accel, gyro, dt, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
+        """K per-sample predict launches followed by one correct launch (device arrays only)."""
+        B = self.B
+        K = accel.numel() // (3 * B)
+        per = 1 if (dt.numel() == K * B and B > 1) else 0
+        M = ids.numel() // B if ids is not None else 0
+        for a in (accel, gyro, dt, ids, pos, quat, skip):
+            if a is not None:
+                self._keep.append(a)
+        rc = self._lib.fbus_ekf_frame_dev(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per, M,
+                                          self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
+        self._check(rc, "frame_dev")
+
+    # ---- timing -------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self._lib.fbus_ekf_timing_enable(self._h, 1 if on else 0), "timing_enable")
+
+    def timing_reset(self):
+        self._check(self._lib.fbus_ekf_timing_reset(self._h), "timing_reset")
+
+    def timing_read(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.fbus_ekf_timing_read(self._h, kernel, C.byref(ms), C.byref(n)), "timing_read")
+        return ms.value, n.value

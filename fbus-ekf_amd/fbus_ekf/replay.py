@@ -1,0 +1,100 @@
+"""Dataset replay driver: the frame loop of matlab/FBUS_EKF.m:118-210 around predict/correct.
+
+Host-side sequencing only (which IMU rows belong to which camera frame, when to
+reset); the filter arithmetic is delegated to an `engine` exposing the
+BatchedFilter interface (set_state / get_state / predict / correct) with B = 1.
+File formats: SURVEY.md App. C (imu.txt `t ax ay az gx gy gz`, image.txt
+`t id px py pz qw qx qy qz`).
+
+The one-off initialisation (InitGravityAndGyrobias.m:36-40,
+InitPositionAndQuaternion.m:38-80, ResetState.m:37-80) is a handful of 3-vector
+operations per run and is done here on the host, as in the reference.
+"""
+import numpy as np
+
+from . import synth
+
+
+def init_gravity_gyrobias(imu_rows):
+    """InitGravityAndGyrobias.m:36-40 : mean of the first IMU rows."""
+    mean = np.asarray(imu_rows, float).mean(axis=0)
+    return -np.array([0.0, 0.0, np.linalg.norm(mean[1:4])]), mean[4:7].copy()
+
+
+def nearest(meas):
+    """index of the nearest marker, start threshold 10 (MeasureUpdate.m:51-60)."""
+    best, bi = 10.0, -1
+    for i, row in enumerate(meas):
+        d = np.linalg.norm(row[1:4])
+        if d < best:
+            best, bi = d, i
+    return bi
+
+
+def pose_from_marker(meas_row, params):
+    """InitPositionAndQuaternion.m:52-72 / ResetState.m:52-72 : IMU pose from one marker."""
+    R_IL, P_IL, Q_IL = synth.camera_constants(params)
+    ids, mpos, mquat = synth.marker_table(params)
+    k = int(np.nonzero(ids == int(meas_row[0]))[0][0])
+    yp, yq = meas_row[1:4], meas_row[4:8]
+    q = synth.qmul(synth.qmul(mquat[k], yq * np.array([1.0, -1, -1, -1])), Q_IL)
+    R = synth.q2R(q)
+    p = -R @ R_IL.T @ yp + mpos[k] - R @ P_IL
+    return p, q, R
+
+
+def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
+    """Runs the recording through `engine` (B = 1).  Returns (states, npredict):
+    states[k] = [t, nominal(19), rot(9), P(N*N)] after frame k."""
+    imu = np.asarray(imu, float)
+    image = np.asarray(image, float)
+    N = engine.N
+    g0, bg0 = init_gravity_gyrobias(imu[:500])                      # FBUS_EKF.m:118
+    meas0 = image[0:1, 1:9]
+    p, q, R = pose_from_marker(meas0[nearest(meas0)], params)       # FBUS_EKF.m:124-132
+    nominal = np.zeros((1, 19))
+    nominal[0, 0:3], nominal[0, 6:10], nominal[0, 13:16] = p, q, bg0
+    nominal[0, 16:19] = [9.8, 0.0, 0.0]                             # InitPositionAndQuaternion.m:79
+    P0 = np.diag(np.repeat(np.array(list(params.p0_diag)), 3)[:N])[None]
+    engine.set_state(nominal, R.reshape(1, 9), P0, np.zeros(1, np.int32))
+    idx = int(np.argmax(imu[:, 0] > image[0, 0]))
+    pre_img, n_img = 0.0, 0
+    out, npred = [], []
+    while n_img < len(image) - 1 and (max_frames is None or len(out) < max_frames):
+        j = n_img + 1                                               # FBUS_EKF.m:155-164
+        while j < len(image) and image[j, 0] == image[n_img, 0]:
+            j += 1
+        cur = image[n_img, 0]
+        meas = image[n_img:j, 1:9]
+        n_img = j
+        cnt = 0
+        if cur - pre_img > 0.1 and pre_img != 0 and matlab_reset:   # FBUS_EKF.m:168-171, ResetState.m:75-79
+            nominal, rot, P, prev = engine.get_state()
+            p, q, R = pose_from_marker(meas[nearest(meas)], params)
+            nominal[0, 0:3], nominal[0, 6:10] = p, q
+            nominal[0, 3:6] = 0
+            nominal[0, 10:13] = 0
+            engine.set_state(nominal, R.reshape(1, 9), None, None)
+            pre_img = cur
+        else:
+            pre_imu = imu[idx - 1, 0]                               # FBUS_EKF.m:175-191
+            k = idx
+            while k < len(imu):
+                if imu[k, 0] > cur:
+                    break
+                if imu[k, 0] < pre_img:
+                    pre_imu = imu[k, 0]
+                    k += 1
+                    continue
+                dt = imu[k, 0] - pre_imu
+                pre_imu = imu[k, 0]
+                engine.predict(imu[k:k + 1, 1:4], imu[k:k + 1, 4:7], np.array([dt]))
+                cnt += 1
+                k += 1
+            idx = k
+            pre_img = cur
+            engine.correct(meas[:, 0].astype(np.int32)[None], meas[None, :, 1:4], meas[None, :, 4:8], 0)
+        nominal, rot, P, _ = engine.get_state()
+        out.append(np.concatenate([[cur], nominal.ravel(), rot.ravel(), P.ravel()]).astype(np.float64))
+        npred.append(cnt)
+    return np.array(out), np.array(npred)

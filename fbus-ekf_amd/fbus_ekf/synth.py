@@ -1,0 +1,162 @@
+"""Seeded synthetic IMU + marker streams (host logic; numpy only).
+
+Counter-based: every array is generated per block of 1024 filters from
+Philox(key = [seed + stream id + step, block index]), so any shard [lo, hi) of the
+batch reproduces exactly the values of the unsharded run.
+Distributions follow the land recording of the reference
+(matlab/dataset/landdata/dataset-02): accel noise std (0.66, 0.18, 0.53) m/s^2, gyro
+std (0.022, 0.014, 0.008) rad/s, gravity [9.8, 0, 0] (InitPositionAndQuaternion.m:79).
+"""
+import numpy as np
+
+BASE_SEED = 0xFB05EC0F
+RNG_BLOCK = 1024
+_S_STATE, _S_IMU, _S_MARK = 1 << 40, 2 << 40, 3 << 40
+
+ACC_STD = np.array([0.66, 0.18, 0.53])
+GYR_STD = np.array([0.022, 0.014, 0.008])
+GRAVITY = np.array([9.8, 0.0, 0.0])
+
+
+def _blocks(lo, hi):
+    b0, b1 = lo // RNG_BLOCK, (hi - 1) // RNG_BLOCK
+    for blk in range(b0, b1 + 1):
+        s = max(lo, blk * RNG_BLOCK) - blk * RNG_BLOCK
+        e = min(hi, (blk + 1) * RNG_BLOCK) - blk * RNG_BLOCK
+        yield blk, s, e
+
+
+def _rng(stream, step, blk, seed):
+    return np.random.Generator(np.random.Philox(key=[(seed + stream + step) & (2**64 - 1), blk]))
+
+
+def _draw(lo, hi, stream, step, seed, fn):
+    parts = [fn(_rng(stream, step, blk, seed))[s:e] for blk, s, e in _blocks(lo, hi)]
+    return np.concatenate(parts, axis=0)
+
+
+# ---- small quaternion helpers for building consistent measurements (wxyz) -----------
+def qmul(p, q):
+    pw, px, py, pz = np.moveaxis(p, -1, 0)
+    qw, qx, qy, qz = np.moveaxis(q, -1, 0)
+    return np.stack([pw * qw - px * qx - py * qy - pz * qz,
+                     pw * qx + px * qw + py * qz - pz * qy,
+                     pw * qy - px * qz + py * qw + pz * qx,
+                     pw * qz + px * qy - py * qx + pz * qw], axis=-1)
+
+
+def q2R(q):
+    w, x, y, z = np.moveaxis(q, -1, 0)
+    R = np.stack([w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+                  2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z], axis=-1)
+    return R.reshape(q.shape[:-1] + (3, 3))
+
+
+def R2q(R):
+    """trace-based conversion of one 3x3 rotation matrix."""
+    R = np.asarray(R, float)
+    t = np.trace(R)
+    q = np.zeros(4)
+    if t > 0:
+        t = np.sqrt(t + 1)
+        q[0] = 0.5 * t
+        t = 0.5 / t
+        q[1:] = [(R[2, 1] - R[1, 2]) * t, (R[0, 2] - R[2, 0]) * t, (R[1, 0] - R[0, 1]) * t]
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1)
+        q[1 + i] = 0.5 * t
+        t = 0.5 / t
+        q[0] = (R[k, j] - R[j, k]) * t
+        q[1 + j] = (R[j, i] + R[i, j]) * t
+        q[1 + k] = (R[k, i] + R[i, k]) * t
+    return q
+
+
+def camera_constants(params):
+    """R_IL, P_IL, Q_IL from the raw left T_SC of an FbusParams (flip as FBUS_EKF.m:68)."""
+    T = np.array(list(params.T_SC_left), float).reshape(4, 4)
+    T = np.diag([-1.0, -1, 1, 1]) @ T
+    R_IL = T[:3, :3]
+    return R_IL, -R_IL.T @ T[:3, 3], R2q(R_IL)
+
+
+def marker_table(params):
+    n = params.n_markers
+    ids = np.array(list(params.marker_id)[:n], np.int32)
+    pos = np.array([list(params.marker_pos[k]) for k in range(n)], float)
+    quat = np.array([R2q(np.array(list(params.marker_rot[k])).reshape(3, 3)) for k in range(n)], float)
+    return ids, pos, quat
+
+
+# ---- streams ----------------------------------------------------------------------------
+def initial_state(lo, hi, p0_diag, nstate=18, seed=BASE_SEED, mixed_cov=False):
+    """nominal (n,19), rot (n,9), P (n,N,N), prev_id (n,) for filters [lo, hi)."""
+    N = nstate
+
+    def gen(r):
+        p = r.uniform(-1, 1, (RNG_BLOCK, 3))
+        v = r.normal(0, 0.1, (RNG_BLOCK, 3))
+        q = r.normal(size=(RNG_BLOCK, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        ba = r.normal(0, 0.05, (RNG_BLOCK, 3))
+        bg = r.normal(0, 0.002, (RNG_BLOCK, 3))
+        g = np.broadcast_to(GRAVITY, (RNG_BLOCK, 3))
+        A = r.normal(0, 0.05, (RNG_BLOCK, 18, 18))
+        return np.concatenate([p, v, q, ba, bg, g, A.reshape(RNG_BLOCK, -1)], axis=1)
+
+    raw = _draw(lo, hi, _S_STATE, 0, seed, gen)
+    nominal = np.ascontiguousarray(raw[:, :19])
+    rot = q2R(nominal[:, 6:10]).reshape(-1, 9)
+    P0 = np.diag(np.repeat(np.asarray(p0_diag, float), 3)[:N])
+    n = hi - lo
+    if mixed_cov:   # A P0 A' with A = I + small random: dense, symmetric positive definite
+        A = np.eye(N) + raw[:, 19:].reshape(n, 18, 18)[:, :N, :N]
+        P = A @ P0 @ np.swapaxes(A, 1, 2)
+        P = (P + np.swapaxes(P, 1, 2)) / 2
+    else:
+        P = np.broadcast_to(P0, (n, N, N)).copy()
+    return nominal, rot, P, np.zeros(n, np.int32)
+
+
+def imu_samples(lo, hi, step, K, nominal0, seed=BASE_SEED):
+    """accel, gyro (K, n, 3) for IMU steps [step, step+K) of filters [lo, hi):
+    specific force of a body at rest in the initial attitude plus recorded noise levels."""
+    R0 = q2R(nominal0[:, 6:10])
+    f0 = np.einsum("nji,j->ni", R0, -GRAVITY)           # R' (-g)
+    acc, gyr = [], []
+    for k in range(K):
+        z = _draw(lo, hi, _S_IMU, step + k, seed, lambda r: r.normal(size=(RNG_BLOCK, 6)))
+        acc.append(f0 + z[:, :3] * ACC_STD)
+        gyr.append(z[:, 3:] * GYR_STD)
+    return np.stack(acc), np.stack(gyr)
+
+
+def marker_frame(lo, hi, frame, M, nominal0, params, seed=BASE_SEED, noise=1e-3):
+    """ids (n,M) int32, pos (n,M,3), quat (n,M,4): M distinct map markers per filter,
+    measurement = h(x0) + N(0, noise) with x0 the initial nominal state."""
+    R_IL, P_IL, Q_IL = camera_constants(params)
+    mids, mpos, mquat = marker_table(params)
+    nm = len(mids)
+
+    def gen(r):
+        order = np.argsort(r.random((RNG_BLOCK, nm)), axis=1)[:, :M]
+        z = r.normal(size=(RNG_BLOCK, M, 7))
+        return np.concatenate([order[..., None].astype(float), z], axis=2)
+
+    raw = _draw(lo, hi, _S_MARK, frame, seed, gen)
+    slot = raw[..., 0].astype(np.int64)
+    z = raw[..., 1:]
+    p0, q0 = nominal0[:, 0:3], nominal0[:, 6:10]
+    R0 = q2R(q0)
+    Pm, Qm = mpos[slot], mquat[slot]                               # (n,M,3), (n,M,4)
+    d = Pm - p0[:, None, :] - np.einsum("nij,j->ni", R0, P_IL)[:, None, :]
+    hp = np.einsum("ij,nmj->nmi", R_IL, np.einsum("nji,nmj->nmi", R0, d))
+    qc = q0 * np.array([1.0, -1, -1, -1])
+    hq = qmul(qmul(np.broadcast_to(Q_IL, q0.shape), qc)[:, None, :], Qm)
+    pos = hp + noise * z[..., :3]
+    quat = hq + noise * z[..., 3:]
+    quat /= np.linalg.norm(quat, axis=-1, keepdims=True)
+    return mids[slot].astype(np.int32), pos, quat

@@ -1,0 +1,166 @@
+/*
+ * fbus_ekf.h -- C ABI of the MI355X-native batched error-state EKF.
+ *
+ * Drop-in boundary for ONE path of CASIA-RoboticFish/FBUS-EKF: the filter's
+ * predict (ImuUpdate) and correct (MeasureUpdate) steps, batched over B
+ * independent filters that live in device memory.  The reference exposes no
+ * FFI of its own (predict/correct are private members / Matlab functions), so
+ * each entry point cites the reference call contract it replaces.  Paths are
+ * relative to the upstream repository.
+ *
+ * Conventions
+ *   - one handle = one device, B filters, one dtype (32|64) and one error-state
+ *     size (18 = reference, 15 = gravity block removed);
+ *   - calls are stream-ordered and asynchronous until fbus_ekf_sync();
+ *     a handle is not thread-safe;
+ *   - every function returns FBUS_OK (0) or a negative/positive fbus_status;
+ *     fbus_ekf_last_error() gives the text of the last failure on a handle;
+ *   - "host" entry points take host pointers in the handle's dtype (float for
+ *     32, double for 64) and stage them through library-owned device buffers;
+ *     "_dev" entry points take device pointers and add no copies -- these are
+ *     the hot path;
+ *   - arrays are dense row-major: nominal B x 19 (p3 v3 q4[wxyz] ba3 bg3 g3),
+ *     rot B x 9 (carried rotation matrix, see below), P B x N x N,
+ *     accel/gyro B x 3, marker ids B x M (int32, -1 = absent),
+ *     marker pos B x M x 3, marker quat B x M x 4 (wxyz);
+ *   - there is NO CPU fallback: without a HIP device create() fails with
+ *     FBUS_ERR_NO_DEVICE.
+ */
+#ifndef FBUS_EKF_H
+#define FBUS_EKF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBUS_MAX_MARKERS 32     /* marker-map entries                     */
+#define FBUS_MAX_VISIBLE 16     /* markers per frame and filter (M)       */
+#define FBUS_MAX_MARKER_ID 1023 /* ArUco ids handled by the id->slot table */
+
+typedef struct fbus_ekf* fbus_ekf_t;
+
+typedef enum fbus_status {
+    FBUS_OK = 0,
+    FBUS_ERR_INVALID = 1,       /* bad argument                          */
+    FBUS_ERR_NO_DEVICE = 2,     /* no usable HIP device                  */
+    FBUS_ERR_HIP = 3,           /* a HIP runtime call failed             */
+    FBUS_ERR_UNSUPPORTED = 4,   /* dtype / nstate / mode not built       */
+    FBUS_ERR_NOMEM = 5
+} fbus_status;
+
+/* Which of the reference's two implementations is reproduced. */
+enum { FBUS_DIALECT_MATLAB = 0,   /* matlab/ImuUpdate.m, MeasureUpdate.m             */
+       FBUS_DIALECT_CPP = 1 };    /* C++/src/filter.cpp                              */
+/* Measurement handling in correct(). */
+enum { FBUS_MODE_NEAREST = 0,     /* reference: nearest marker (C++: + hysteresis), 7 rows */
+       FBUS_MODE_STACKED = 1 };   /* extension: all visible markers, 7M rows, one linearisation point */
+/* Covariance correction form. */
+enum { FBUS_COV_SIMPLE = 0,       /* (I-KH)P then symmetrise (MeasureUpdate.m:101-102)  */
+       FBUS_COV_JOSEPH = 1 };     /* (I-KH)P(I-KH)' + K R K'                            */
+
+/* Replaces: EkfParam (C++/include/common.hpp:32-54), the constants built in the
+ * FILTER ctor (C++/include/filter.hpp:63-125), matlab/FBUS_EKF.m:32-39,83-112,
+ * MarkerPoseServer (common.hpp:19-29 / matlab/GetMarkerMap.m), CameraInfo::T_SC
+ * and RefractInfo (common.hpp:58-103). */
+typedef struct fbus_params {
+    int32_t dialect;            /* FBUS_DIALECT_*                                       */
+    int32_t cov_form;           /* FBUS_COV_*                                           */
+    double  q_diag[4];          /* process noise added to the v, theta, ba, bg diagonals (not scaled by dt) */
+    double  r_pos, r_quat;      /* measurement noise: position rows, quaternion rows    */
+    double  p0_diag[6];         /* initial covariance per block p v theta ba bg g (used by fbus_ekf_reset_cov) */
+    double  T_SC_left[16];      /* left camera T_SC, row-major 4x4, RAW (the diag(-1,-1,1,1) flip is applied inside) */
+    double  T_SC_right[16];     /* right camera T_SC, RAW (triangulation only)          */
+    int32_t n_markers;
+    int32_t marker_id[FBUS_MAX_MARKERS];
+    double  marker_pos[FBUS_MAX_MARKERS][3];
+    double  marker_rot[FBUS_MAX_MARKERS][9];    /* row-major rotation marker->world     */
+    double  switch_thres;       /* C++ dialect marker hysteresis (paramconfig.yml:57)   */
+    double  max_dist;           /* marker_max_dist (paramconfig.yml:56), init/reset only */
+    double  n_air, n_glass, n_water;            /* flat-port refraction (paramconfig.yml:31-42) */
+    double  d_air, d_glass;
+    double  port_normal[3];
+} fbus_params;
+
+/* Fills prm with the reference's constants for the given dialect
+ * (FBUS_EKF.m / paramconfig.yml / camerainfo1.yml / GetMarkerMap.m). */
+int fbus_params_default(fbus_params* prm, int dialect);
+
+/* ---- lifetime ------------------------------------------------------------- */
+/* Replaces: FILTER::FILTER (filter.hpp:63-137) for a batch of filters.
+ * dtype 32|64, nstate 15|18.  device = HIP ordinal. */
+int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int device, int dtype, int nstate);
+int fbus_ekf_destroy(fbus_ekf_t h);
+/* Run all work of this handle on an existing hipStream_t (e.g. the caller's
+ * framework stream).  NULL restores the handle's own stream. */
+int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream);
+int fbus_ekf_sync(fbus_ekf_t h);
+const char* fbus_ekf_last_error(fbus_ekf_t h);
+const char* fbus_status_string(int status);
+
+/* ---- state I/O (also serves as checkpoint / resume) ------------------------ */
+/* Replaces: direct member access to NominalState/ErrorState (common.hpp:205-247)
+ * and the Matlab State struct (FBUS_EKF.m:74-85).  Any pointer may be NULL to
+ * skip that part.  prev_id is the C++ dialect's preUsedMarkerID_ (filter.hpp). */
+int fbus_ekf_set_state(fbus_ekf_t h, const void* nominal, const void* rot, const void* P, const int32_t* prev_id);
+int fbus_ekf_get_state(fbus_ekf_t h, void* nominal, void* rot, void* P, int32_t* prev_id);
+int fbus_ekf_set_state_dev(fbus_ekf_t h, const void* nominal, const void* rot, const void* P, const int32_t* prev_id);
+int fbus_ekf_get_state_dev(fbus_ekf_t h, void* nominal, void* rot, void* P, int32_t* prev_id);
+/* P <- diag(p0_diag) for every filter. */
+int fbus_ekf_reset_cov(fbus_ekf_t h);
+/* The packed device-resident records (what a multi-GPU gather ships): base
+ * pointer, bytes per filter and total bytes.  Layout: DESIGN.md section 3. */
+int fbus_ekf_records(fbus_ekf_t h, void** dev_ptr, size_t* bytes_per_filter, size_t* total_bytes);
+/* Point the handle at caller-owned device storage of total_bytes (as reported
+ * by fbus_ekf_records) so that a framework tensor can alias the records. */
+int fbus_ekf_attach_records(fbus_ekf_t h, void* dev_ptr, size_t total_bytes);
+
+/* ---- predict == ImuUpdate -------------------------------------------------- */
+/* Replaces: State = ImuUpdate(State, accel, gyro, dt) (matlab/ImuUpdate.m:36) and
+ * FILTER::UpdateCovariance + UpdateNominalState (filter.cpp:588-616,533-582) as
+ * called per IMU sample from BatchImuProcessing (filter.cpp:505-516).
+ * dt_per_filter = 0: dt points to ONE value; 1: B values. */
+int fbus_ekf_predict(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
+int fbus_ekf_predict_dev(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
+/* K consecutive IMU samples in one launch (state stays in registers between
+ * samples).  accel/gyro are K x B x 3, dt is K (dt_per_filter=0) or K x B.
+ * Same arithmetic, same results as K fbus_ekf_predict calls. */
+int fbus_ekf_predict_n(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
+int fbus_ekf_predict_n_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
+
+/* ---- correct == MeasureUpdate ---------------------------------------------- */
+/* Replaces: State = MeasureUpdate(State, visionMeas[8xM], markerMap, cameraInfo)
+ * (matlab/MeasureUpdate.m:37) and FILTER::ObservationUpdate (filter.cpp:622-754)
+ * fed by SetDetectionResult (filter.cpp:61-65).  ids B x M (-1 = slot unused),
+ * pos B x M x 3, quat B x M x 4.  skip (B bytes, may be NULL): non-zero = leave
+ * that filter untouched.  Filters with no usable marker are left untouched
+ * (the reference's silent early return, filter.cpp:671-673). */
+int fbus_ekf_correct(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat,
+                     int mode, const uint8_t* skip);
+int fbus_ekf_correct_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat,
+                         int mode, const uint8_t* skip);
+/* 1 where the last correct() applied an update, 0 where it returned early. */
+int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host);
+
+/* ---- one camera frame: K predicts then one correct -------------------------- */
+/* Replaces one iteration of the frame loop (matlab/FBUS_EKF.m:175-196;
+ * filter.cpp:232-235): enqueues K per-sample predict launches followed by one
+ * correct launch without returning to the caller in between.  Device pointers. */
+int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
+                       int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
+
+/* ---- measurement support (bench / profiling) -------------------------------- */
+enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N = 2, FBUS_KERNEL_COUNT = 3 };
+/* When enabled, every launch of the listed kernels is bracketed by HIP events
+ * on the handle's stream; read() synchronises and returns the summed device
+ * time and launch count since the last reset. */
+int fbus_ekf_timing_enable(fbus_ekf_t h, int on);
+int fbus_ekf_timing_reset(fbus_ekf_t h);
+int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBUS_EKF_H */

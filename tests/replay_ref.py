@@ -1,0 +1,40 @@
+"""Test helper: drives fbus_ekf.replay with the fp64 oracle as the engine."""
+import numpy as np
+
+import oracle_capi as oc
+from fbus_ekf import capi, replay
+
+
+class OracleEngine:
+    """BatchedFilter-shaped adapter around oracle_capi.Oracle (tests only)."""
+
+    def __init__(self, batch, dialect=0, nstate=18, cov_form=0):
+        self.B, self.N = batch, nstate
+        self.orc = oc.Oracle(dialect, nstate, cov_form)
+        self.nominal = np.zeros((batch, 19))
+        self.rot = np.zeros((batch, 9))
+        self.P = np.zeros((batch, nstate, nstate))
+        self.prev = np.zeros(batch, np.int32)
+
+    def set_state(self, nominal=None, rot=None, P=None, prev_id=None):
+        if nominal is not None: self.nominal[...] = np.asarray(nominal, float).reshape(self.B, 19)
+        if rot is not None: self.rot[...] = np.asarray(rot, float).reshape(self.B, 9)
+        if P is not None: self.P[...] = np.asarray(P, float).reshape(self.B, self.N, self.N)
+        if prev_id is not None: self.prev[...] = prev_id
+
+    def get_state(self):
+        return self.nominal.copy(), self.rot.copy(), self.P.copy(), self.prev.copy()
+
+    def predict(self, accel, gyro, dt):
+        self.orc.predict(self.nominal, self.rot, self.P, self.prev,
+                         np.asarray(accel, float).reshape(self.B, 3), np.asarray(gyro, float).reshape(self.B, 3),
+                         np.asarray(dt, float))
+
+    def correct(self, ids, pos, quat, mode=0, skip=None):
+        return self.orc.correct(self.nominal, self.rot, self.P, self.prev, ids, pos, quat, mode)
+
+
+def replay_with_oracle(imu, image, dialect, nframes):
+    eng = OracleEngine(1, dialect, 18)
+    prm = capi.default_params(dialect)
+    return replay.replay(eng, imu, image, prm, max_frames=nframes)

@@ -1,0 +1,202 @@
+"""CPU suite, part 1: the oracle itself.
+
+ * the vision oracle against the reference's own recorded corners.txt -> image.txt
+   data (the only sharp golden vectors the reference holds);
+ * the C oracle against the independently written numpy twin and against the
+   committed golden vectors;
+ * algebraic invariants of the filter (symmetry, PSD, N=15 inside N=18,
+   Joseph == simple, one stacked marker == nearest marker).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ekf_oracle_np as onp
+import oracle_capi as oc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---------------------------------------------------------------- vision (pinned)
+def test_vision_water_matches_reference_recording():
+    d = np.load(os.path.join(GOLD, "vision_water.npz"))
+    p = oc.vision_params()
+    for c, im in zip(d["corners"], d["image"]):
+        corners = oc.refraction_triangulate(p, c[2:10], c[10:18])
+        pos, quat, _ = oc.marker_pose(corners)
+        assert np.abs(pos - im[2:5]).max() < 1.5e-5          # files carry 6 significant digits
+        assert min(np.abs(quat - im[5:9]).max(), np.abs(quat + im[5:9]).max()) < 5e-5
+
+
+def test_vision_water_is_sharp_in_refraction_index():
+    """n_water = 1.33 instead of 1.32 must visibly break the match (the fixture is sharp)."""
+    d = np.load(os.path.join(GOLD, "vision_water.npz"))
+    p = oc.vision_params()
+    p.n_water = 1.33
+    c, im = d["corners"][0], d["image"][0]
+    pos, _, _ = oc.marker_pose(oc.refraction_triangulate(p, c[2:10], c[10:18]))
+    assert np.abs(pos - im[2:5]).max() > 1e-3
+
+
+def test_vision_land_pose_fit_matches_reference_recording():
+    d = np.load(os.path.join(GOLD, "vision_land.npz"))
+    for c, im in zip(d["corners"], d["image"]):
+        pos, quat, rot = oc.marker_pose(c[2:14])
+        assert np.abs(pos - im[2:5]).max() < 1.5e-5
+        assert np.abs(quat - im[5:9]).max() < 5e-5
+        assert np.abs(rot @ rot.T - np.eye(3)).max() < 1e-12
+
+
+# ---------------------------------------------------------------- EKF oracle
+def _np_states(nom, rot, P, prev, n):
+    out = []
+    for b in range(nom.shape[0]):
+        s = onp.State(n)
+        s.p, s.v, s.q = nom[b, 0:3].copy(), nom[b, 3:6].copy(), nom[b, 6:10].copy()
+        s.ba, s.bg, s.g = nom[b, 10:13].copy(), nom[b, 13:16].copy(), nom[b, 16:19].copy()
+        s.R, s.P, s.prev_id = rot[b].reshape(3, 3).copy(), P[b].copy(), int(prev[b])
+        out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+@pytest.mark.parametrize("n", [18, 15])
+def test_c_oracle_matches_golden(dialect, n):
+    g = np.load(os.path.join(GOLD, "ekf_random.npz"))
+    t = f"d{dialect}_n{n}"
+    orc = oc.Oracle(dialect, n)
+    # predict (filters 0/1 hit the w == 0 / small-rate cases; matlab dialect NaNs at w == 0 like the reference)
+    nom, rot, P, prev = g[t + "_nom"].copy(), g[t + "_rot"].copy(), g[t + "_P"].copy(), g[t + "_prev"].copy()
+    with np.errstate(all="ignore"):
+        orc.predict(nom, rot, P, prev, g[t + "_acc"], g[t + "_gyr"], g[t + "_dt"])
+    sl = slice(1, None) if dialect == 0 else slice(None)
+    assert np.abs(nom[sl] - g[t + "_pred_nom"][sl]).max() < 1e-12
+    assert np.abs(rot[sl] - g[t + "_pred_rot"][sl]).max() < 1e-12
+    assert np.abs(P - g[t + "_pred_P"]).max() / np.abs(P).max() < 1e-12
+    if dialect == 0:
+        assert np.isnan(nom[0, 6:10]).all() and np.isnan(g[t + "_pred_nom"][0, 6:10]).all()
+    for mode, name in ((oc.NEAREST, "near"), (oc.STACKED, "stack")):
+        nom, rot, P, prev = g[t + "_nom"].copy(), g[t + "_rot"].copy(), g[t + "_P"].copy(), g[t + "_prev"].copy()
+        ok = orc.correct(nom, rot, P, prev, g[t + "_ids"], g[t + "_pos"], g[t + "_quat"], mode)
+        assert (ok == g[f"{t}_{name}_ok"]).all()
+        assert ok[2] == 0 and ok[3] == 0                     # nothing visible / id outside the map
+        assert (prev == g[f"{t}_{name}_prev"]).all()
+        assert np.abs(nom - g[f"{t}_{name}_nom"]).max() < 1e-9
+        assert np.abs(P - g[f"{t}_{name}_P"]).max() / np.abs(P).max() < 1e-10
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_c_oracle_matches_numpy_twin_free_running(dialect):
+    rng = np.random.default_rng(7)
+    n, B = 18, 6
+    orc = oc.Oracle(dialect, n)
+    prm = onp.Params(dialect, n)
+    g = np.load(os.path.join(GOLD, "ekf_random.npz"))
+    t = f"d{dialect}_n{n}"
+    nom, rot, P, prev = [g[t + k][4:4 + B].copy() for k in ("_nom", "_rot", "_P", "_prev")]
+    sts = _np_states(nom, rot, P, prev, n)
+    for step in range(12):
+        acc = rng.normal(0, 0.5, (B, 3)) + [0, 9.8, 0]
+        gyr = rng.normal(0, 0.02, (B, 3))
+        orc.predict(nom, rot, P, prev, acc, gyr, np.array([0.005]))
+        for b in range(B):
+            onp.predict(sts[b], prm, acc[b], gyr[b], 0.005)
+        if step % 3 == 2:
+            ids = np.stack([rng.choice([0, 1, 2, 16, 17], 3, replace=False) for _ in range(B)]).astype(np.int32)
+            pos = rng.normal(0, 0.5, (B, 3, 3))
+            quat = rng.normal(size=(B, 3, 4))
+            quat /= np.linalg.norm(quat, axis=2, keepdims=True)
+            mode = (step // 3) % 2
+            orc.correct(nom, rot, P, prev, ids, pos, quat, mode)
+            for b in range(B):
+                onp.correct(sts[b], prm, ids[b], pos[b], quat[b], mode)
+    for b in range(B):
+        s = sts[b]
+        assert np.abs(np.concatenate([s.p, s.v, s.q, s.ba, s.bg, s.g]) - nom[b]).max() < 1e-9
+        assert np.abs(s.P - P[b]).max() / np.abs(P[b]).max() < 1e-10
+        assert s.prev_id == prev[b]
+
+
+def test_land_slice_replay_matches_golden_and_stays_psd():
+    """config 1 plumbing: the land recording through the C oracle with the FBUS_EKF.m loop."""
+    d = np.load(os.path.join(GOLD, "land_slice.npz"))
+    from replay_ref import replay_with_oracle
+    for dialect, key in ((0, "states_matlab"), (1, "states_cpp")):
+        states, npred = replay_with_oracle(d["imu"], d["image"], dialect, len(d[key]))
+        assert (npred == d["npredict"]).all()
+        assert np.abs(states[:, :20] - d[key][:, :20]).max() < 1e-9
+        Pg = d[key][:, 29:].reshape(-1, 18, 18)
+        Pm = states[:, 29:].reshape(-1, 18, 18)
+        assert np.abs(Pm - Pg).max() / np.abs(Pg).max() < 1e-10
+        for Pk in Pm:
+            assert np.abs(Pk - Pk.T).max() == 0.0
+            assert np.linalg.eigvalsh(Pk).min() > 0
+        if dialect == 0:
+            # loose sanity against the reference's recorded (older-revision) fusion.txt: gyro-bias band
+            assert np.abs(states[-1, 14:17] - np.array([-0.0017, 0.00026, -0.00058])).max() < 2e-4
+
+
+# ---------------------------------------------------------------- invariants
+def _random_batch(n, B, seed, dialect):
+    g = np.load(os.path.join(GOLD, "ekf_random.npz"))
+    t = f"d{dialect}_n{n}"
+    return [g[t + k][4:4 + B].copy() for k in ("_nom", "_rot", "_P", "_prev")] + \
+           [g[t + k][4:4 + B].copy() for k in ("_acc", "_gyr", "_dt", "_ids", "_pos", "_quat")]
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_n15_is_n18_without_gravity_uncertainty(dialect):
+    nom, rot, P15, prev, acc, gyr, dt, ids, pos, quat = _random_batch(15, 8, 0, dialect)
+    B = nom.shape[0]
+    P18 = np.zeros((B, 18, 18))
+    P18[:, :15, :15] = P15
+    o15, o18 = oc.Oracle(dialect, 15), oc.Oracle(dialect, 18)
+    a = [nom.copy(), rot.copy(), P15.copy(), prev.copy()]
+    b = [nom.copy(), rot.copy(), P18.copy(), prev.copy()]
+    for _ in range(3):
+        o15.predict(*a, acc, gyr, dt)
+        o18.predict(*b, acc, gyr, dt)
+        o15.correct(*a, ids, pos, quat, oc.NEAREST)
+        o18.correct(*b, ids, pos, quat, oc.NEAREST)
+    assert np.abs(a[0] - b[0]).max() < 1e-12
+    assert np.abs(a[2] - b[2][:, :15, :15]).max() < 1e-12
+    assert np.abs(b[2][:, 15:, :]).max() < 1e-15
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_joseph_equals_simple_form(dialect):
+    nom, rot, P, prev, acc, gyr, dt, ids, pos, quat = _random_batch(18, 8, 0, dialect)
+    a = [nom.copy(), rot.copy(), P.copy(), prev.copy()]
+    b = [nom.copy(), rot.copy(), P.copy(), prev.copy()]
+    oc.Oracle(dialect, 18, oc.SIMPLE).correct(*a, ids, pos, quat, oc.STACKED)
+    oc.Oracle(dialect, 18, oc.JOSEPH).correct(*b, ids, pos, quat, oc.STACKED)
+    assert np.abs(a[0] - b[0]).max() == 0
+    assert np.abs(a[2] - b[2]).max() / np.abs(a[2]).max() < 1e-10
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_one_stacked_marker_is_the_nearest_marker_update(dialect):
+    nom, rot, P, prev, acc, gyr, dt, ids, pos, quat = _random_batch(18, 8, 0, dialect)
+    ids1, pos1, quat1 = ids[:, :1].copy(), pos[:, :1].copy(), quat[:, :1].copy()
+    ids1[:] = 16
+    prev[:] = 16
+    a = [nom.copy(), rot.copy(), P.copy(), prev.copy()]
+    b = [nom.copy(), rot.copy(), P.copy(), prev.copy()]
+    orc = oc.Oracle(dialect, 18)
+    orc.correct(*a, ids1, pos1, quat1, oc.NEAREST)
+    orc.correct(*b, ids1, pos1, quat1, oc.STACKED)
+    assert np.abs(a[0] - b[0]).max() == 0 and np.abs(a[2] - b[2]).max() == 0
+
+
+def test_predict_keeps_covariance_symmetric_psd_and_biases_constant():
+    nom, rot, P, prev, acc, gyr, dt, *_ = _random_batch(18, 8, 0, 0)
+    orc = oc.Oracle(0, 18)
+    before = nom.copy()
+    for _ in range(20):
+        orc.predict(nom, rot, P, prev, acc, gyr, dt)
+    assert np.abs(nom[:, 10:19] - before[:, 10:19]).max() == 0       # ba, bg, g untouched by predict
+    assert np.abs(np.linalg.norm(nom[:, 6:10], axis=1) - 1).max() < 1e-12
+    for Pk in P:
+        assert np.abs(Pk - Pk.T).max() == 0
+        assert np.linalg.eigvalsh(Pk).min() > 0

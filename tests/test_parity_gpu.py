@@ -1,0 +1,318 @@
+"""GPU suite: the HIP path, called through the C ABI (ctypes), against the fp64 oracle.
+
+Tolerances (BASELINE.json north_star): fp32 GPU vs fp64 oracle, state rel-err <= 1e-5,
+covariance rel-err <= 1e-4 (max-norm relative), asserted per step (re-seeded from the
+oracle) and over free-running windows of <= 100 frames; fp64 GPU vs oracle <= 1e-9.
+Nothing here reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_capi as oc
+from fbus_ekf import BatchedFilter, capi, replay, synth
+from replay_ref import OracleEngine
+from util import COV_TOL, STATE_TOL, cov_rel_err, rot_rel_err, state_rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DT = np.array([np.float64(np.float32(0.005))])
+
+
+def _params(dialect, cov_form=0):
+    p = capi.default_params(dialect)
+    p.cov_form = cov_form
+    return p
+
+
+def _r32(a):
+    """round to fp32-representable values so the GPU (fp32) and the oracle (fp64) see IDENTICAL inputs."""
+    return np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+
+
+def _batch(B, dialect, n, mixed=True, seed_off=0):
+    prm = _params(dialect)
+    nom, rot, P, prev = synth.initial_state(seed_off, seed_off + B, list(prm.p0_diag), n, mixed_cov=mixed)
+    return prm, _r32(nom), _r32(rot), _r32(P), prev
+
+
+def _imu(lo, hi, step, K, nom):
+    a, g = synth.imu_samples(lo, hi, step, K, nom)
+    return _r32(a), _r32(g)
+
+
+def _markers(lo, hi, frame, M, nom, prm):
+    ids, pos, quat = synth.marker_frame(lo, hi, frame, M, nom, prm)
+    return ids, _r32(pos), _r32(quat)
+
+
+def _check(flt, eng, dtype, what, state_tol=STATE_TOL, cov_tol=COV_TOL):
+    g_nom, g_rot, g_P, g_prev = flt.get_state()
+    o_nom, o_rot, o_P, o_prev = eng.get_state()
+    es, where = state_rel_err(g_nom, o_nom)
+    er = rot_rel_err(g_rot, o_rot)
+    ec = cov_rel_err(g_P, o_P)
+    if dtype == 64:
+        state_tol, cov_tol = 1e-9, 1e-9
+    assert es <= state_tol, f"{what}: state rel err {es:.3g} in block {where}"
+    assert er <= max(state_tol, 2e-6 if dtype == 32 else 0), f"{what}: rotation err {er:.3g}"
+    assert ec <= cov_tol, f"{what}: covariance rel err {ec:.3g}"
+    assert (g_prev == o_prev).all(), f"{what}: prev marker id"
+    assert np.abs(g_P - np.swapaxes(g_P, 1, 2)).max() == 0
+    return es, ec
+
+
+# ------------------------------------------------------------------ single steps
+@pytest.mark.parametrize("dtype", [32, 64])
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_predict_single_step(dialect, n, dtype):
+    B = 320                                   # five waves, last tile partial on purpose below
+    B -= 7
+    prm, nom, rot, P, prev = _batch(B, dialect, n)
+    acc, gyr = _imu(0, B, 0, 1, nom)
+    dt = _r32(np.random.default_rng(3).uniform(0.001, 0.01, B))
+    with BatchedFilter(B, prm, dtype=dtype, nstate=n) as flt:
+        eng = OracleEngine(B, dialect, n)
+        flt.set_state(nom, rot, P, prev)
+        eng.set_state(nom, rot, P, prev)
+        flt.predict(acc[0], gyr[0], dt)
+        eng.predict(acc[0], gyr[0], dt)
+        _check(flt, eng, dtype, "predict")
+        # scalar dt form
+        flt.predict(acc[0], gyr[0], DT)
+        eng.predict(acc[0], gyr[0], DT)
+        _check(flt, eng, dtype, "predict scalar dt")
+
+
+@pytest.mark.parametrize("dtype", [32, 64])
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_correct_single_step(dialect, mode, n, dtype):
+    B, M = 256, 4
+    prm, nom, rot, P, prev = _batch(B, dialect, n)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    rng = np.random.default_rng(5)
+    pos = _r32(pos + rng.normal(0, 0.02, pos.shape))      # non-trivial innovations
+    ids[0] = -1                                           # nothing visible
+    ids[1] = [9, -1, 9, -1]                               # only an id outside the map
+    ids[2, 1] = -1
+    ids[3, 0] = 9
+    prev = rng.choice([0, 1, 2, 16], B).astype(np.int32)
+    with BatchedFilter(B, prm, dtype=dtype, nstate=n) as flt:
+        eng = OracleEngine(B, dialect, n)
+        flt.set_state(nom, rot, P, prev)
+        eng.set_state(nom, rot, P, prev)
+        flt.correct(ids, pos, quat, mode)
+        ok = eng.correct(ids, pos, quat, mode)
+        assert (flt.applied() == ok).all()
+        assert ok[0] == 0 and ok[1] == 0 and ok[4:].all()
+        _check(flt, eng, dtype, f"correct mode {mode}")
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_golden_vectors(dialect):
+    """committed fixtures (tests/golden/ekf_random.npz, numpy twin) through the GPU."""
+    g = np.load(os.path.join(GOLD, "ekf_random.npz"))
+    for n in (18, 15):
+        t = f"d{dialect}_n{n}"
+        B = g[t + "_nom"].shape[0]
+        with BatchedFilter(B, _params(dialect), dtype=32, nstate=n) as flt:
+            flt.set_state(g[t + "_nom"], g[t + "_rot"], g[t + "_P"], g[t + "_prev"])
+            flt.predict(g[t + "_acc"], g[t + "_gyr"], g[t + "_dt"])
+            nom, rot, P, _ = flt.get_state()
+            sl = slice(1, None) if dialect == 0 else slice(None)   # filter 0: w == 0, reference NaN (guarded here)
+            assert state_rel_err(nom[sl], g[t + "_pred_nom"][sl])[0] <= STATE_TOL
+            assert cov_rel_err(P, g[t + "_pred_P"]) <= COV_TOL
+            assert np.isfinite(nom).all() and np.isfinite(P).all()          # the guard keeps w == 0 finite
+            for mode, name in ((0, "near"), (1, "stack")):
+                flt.set_state(g[t + "_nom"], g[t + "_rot"], g[t + "_P"], g[t + "_prev"])
+                flt.correct(g[t + "_ids"], g[t + "_pos"], g[t + "_quat"], mode)
+                nom, rot, P, prev = flt.get_state()
+                assert (flt.applied() == g[f"{t}_{name}_ok"]).all()
+                assert (prev == g[f"{t}_{name}_prev"]).all()
+                # random (inconsistent) measurements, large innovations: tolerances on the full state
+                assert state_rel_err(nom, g[f"{t}_{name}_nom"])[0] <= 5 * STATE_TOL
+                assert cov_rel_err(P, g[f"{t}_{name}_P"]) <= COV_TOL
+
+
+# ------------------------------------------------------------------ free-running windows
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_free_running_100_frames(dialect):
+    """200 Hz IMU + 30 Hz stereo pattern (7,7,6 predicts per correct), M = 4, 100 frames."""
+    B, M, n = 128, 4, 18
+    prm, nom, rot, P, prev = _batch(B, dialect, n, mixed=False)
+    with BatchedFilter(B, prm, dtype=32, nstate=n) as flt:
+        eng = OracleEngine(B, dialect, n)
+        flt.set_state(nom, rot, P, prev)
+        eng.set_state(nom, rot, P, prev)
+        step = 0
+        worst = (0.0, 0.0)
+        for frame in range(100):
+            K = (7, 7, 6)[frame % 3]
+            acc, gyr = _imu(0, B, step, K, nom)
+            step += K
+            for k in range(K):
+                flt.predict(acc[k], gyr[k], DT)
+                eng.predict(acc[k], gyr[k], DT)
+            ids, pos, quat = _markers(0, B, frame, M, nom, prm)
+            mode = 1 if frame % 2 else 0
+            flt.correct(ids, pos, quat, mode)
+            eng.correct(ids, pos, quat, mode)
+            if frame % 10 == 9:
+                es, ec = _check(flt, eng, 32, f"frame {frame}")
+                worst = (max(worst[0], es), max(worst[1], ec))
+        print(f"free-run dialect {dialect}: worst state {worst[0]:.3g} cov {worst[1]:.3g}")
+
+
+def test_land_recording_slice_replay():
+    """config 1 plumbing on the GPU: the committed land-recording slice through replay()."""
+    d = np.load(os.path.join(GOLD, "land_slice.npz"))
+    for dialect, key in ((0, "states_matlab"), (1, "states_cpp")):
+        prm = _params(dialect)
+        with BatchedFilter(1, prm, dtype=32, nstate=18) as flt:
+            states, npred = replay.replay(flt, d["imu"], d["image"], prm, max_frames=len(d[key]))
+        assert (npred == d["npredict"]).all()
+        gold = d[key]
+        assert state_rel_err(states[:, 1:20], gold[:, 1:20])[0] <= STATE_TOL * 2   # ~2000 fp32 steps free-running
+        assert cov_rel_err(states[:, 29:].reshape(-1, 18, 18), gold[:, 29:].reshape(-1, 18, 18)) <= COV_TOL
+        with BatchedFilter(1, prm, dtype=64, nstate=18) as flt:
+            states, _ = replay.replay(flt, d["imu"], d["image"], prm, max_frames=len(d[key]))
+        assert np.abs(states[:, 1:20] - gold[:, 1:20]).max() < 1e-9
+
+
+# ------------------------------------------------------------------ algebraic properties on the device
+def test_predict_n_equals_repeated_predict():
+    B, K = 192, 5
+    prm, nom, rot, P, prev = _batch(B, 0, 18)
+    acc, gyr = _imu(0, B, 0, K, nom)
+    dt = np.full(K, DT[0])
+    with BatchedFilter(B, prm) as a, BatchedFilter(B, prm) as b:
+        a.set_state(nom, rot, P, prev)
+        b.set_state(nom, rot, P, prev)
+        a.predict_n(acc, gyr, dt)
+        for k in range(K):
+            b.predict(acc[k], gyr[k], dt[k:k + 1])
+        sa, sb = a.get_state(), b.get_state()
+        assert state_rel_err(sa[0], sb[0])[0] < 2e-6
+        assert cov_rel_err(sa[2], sb[2]) < 2e-6
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_joseph_form_equals_simple_form(dialect):
+    B, M = 128, 4
+    prm, nom, rot, P, prev = _batch(B, dialect, 18)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    with BatchedFilter(B, _params(dialect, 0)) as a, BatchedFilter(B, _params(dialect, 1)) as b:
+        for f in (a, b):
+            f.set_state(nom, rot, P, prev)
+            f.correct(ids, pos, quat, 1)
+        sa, sb = a.get_state(), b.get_state()
+        assert state_rel_err(sa[0], sb[0])[0] < 1e-5
+        assert cov_rel_err(sa[2], sb[2]) < 1e-5
+        eng = OracleEngine(B, dialect, 18, cov_form=1)
+        eng.set_state(nom, rot, P, prev)
+        eng.correct(ids, pos, quat, 1)
+        _check(b, eng, 32, "joseph")
+
+
+def test_one_stacked_marker_is_the_nearest_marker_update():
+    B = 128
+    prm, nom, rot, P, prev = _batch(B, 1, 18)
+    ids, pos, quat = _markers(0, B, 0, 1, nom, prm)
+    prev = ids[:, 0].copy()
+    with BatchedFilter(B, prm) as a, BatchedFilter(B, prm) as b:
+        a.set_state(nom, rot, P, prev)
+        b.set_state(nom, rot, P, prev)
+        a.correct(ids, pos, quat, 0)
+        b.correct(ids, pos, quat, 1)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[2], sb[2])
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_n15_is_n18_without_gravity_uncertainty(dialect):
+    B, M = 128, 4
+    prm, nom, rot, P15, prev = _batch(B, dialect, 15)
+    P18 = np.zeros((B, 18, 18))
+    P18[:, :15, :15] = P15
+    acc, gyr = _imu(0, B, 0, 3, nom)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    with BatchedFilter(B, prm, nstate=15) as a, BatchedFilter(B, prm, nstate=18) as b:
+        a.set_state(nom, rot, P15, prev)
+        b.set_state(nom, rot, P18, prev)
+        for f in (a, b):
+            for k in range(3):
+                f.predict(acc[k], gyr[k], DT)
+            f.correct(ids, pos, quat, 1)
+        sa, sb = a.get_state(), b.get_state()
+        assert state_rel_err(sa[0], sb[0])[0] < 2e-6
+        assert cov_rel_err(sa[2], sb[2][:, :15, :15]) < 2e-6
+        assert np.abs(sb[2][:, 15:, :]).max() == 0
+
+
+def test_skip_mask_and_state_roundtrip():
+    B, M = 100, 2
+    prm, nom, rot, P, prev = _batch(B, 0, 18)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    skip = (np.arange(B) % 3 == 0).astype(np.uint8)
+    with BatchedFilter(B, prm, dtype=64) as flt:
+        flt.set_state(nom, rot, P, prev)
+        s0 = flt.get_state()
+        assert np.array_equal(s0[0], nom) and np.array_equal(s0[1], rot) and np.array_equal(s0[3], prev)
+        assert np.abs(s0[2] - P).max() < 1e-18
+        flt.correct(ids, pos, quat, 0, skip)
+        s1 = flt.get_state()
+        ap = flt.applied()
+        assert (ap == (1 - skip)).all()
+        assert np.array_equal(s1[0][skip == 1], nom[skip == 1])
+        assert not np.array_equal(s1[0][skip == 0], nom[skip == 0])
+        flt.reset_cov()
+        P0 = flt.get_state()[2]
+        assert np.allclose(P0, np.diag(np.repeat(np.array(list(prm.p0_diag)), 3))[None])
+
+
+# ------------------------------------------------------------------ full size (BASELINE.json batch)
+def test_full_batch_properties_and_shard_equality():
+    """B = 65 536 (the headline batch): size-independent properties instead of an oracle run --
+    unit quaternions, exactly symmetric and positive definite covariances on a sample, an oracle
+    spot check on a strided subset, and sharded == unsharded bit for bit."""
+    import torch
+    B, M, n = 65536, 4, 18
+    prm = _params(0)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), n)
+    nom, rot, P = _r32(nom), _r32(rot), _r32(P)
+    acc, gyr = _imu(0, B, 0, 3, nom)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_acc, d_gyr, d_dt = f32(acc), f32(gyr), f32(np.full(3, DT[0]))
+    d_ids, d_pos, d_quat = torch.from_numpy(ids).to(dev), f32(pos), f32(quat)
+
+    def run(lo, hi):
+        with BatchedFilter(hi - lo, prm) as flt:
+            flt.set_state(nom[lo:hi], rot[lo:hi], P[lo:hi], prev[lo:hi])
+            flt.frame(d_acc[:, lo:hi].contiguous(), d_gyr[:, lo:hi].contiguous(), d_dt,
+                      d_ids[lo:hi].contiguous(), d_pos[lo:hi].contiguous(), d_quat[lo:hi].contiguous(), 1)
+            flt.sync()
+            return flt.get_state()
+
+    full = run(0, B)
+    assert np.isfinite(full[0]).all() and np.isfinite(full[2]).all()
+    assert np.abs(np.linalg.norm(full[0][:, 6:10], axis=1) - 1).max() < 1e-6
+    assert np.abs(full[2] - np.swapaxes(full[2], 1, 2)).max() == 0
+    sample = full[2][::997].astype(np.float64)
+    assert np.linalg.eigvalsh(sample).min() > 0
+    halves = [run(0, B // 2), run(B // 2, B)]
+    for k in range(4):
+        assert np.array_equal(np.concatenate([halves[0][k], halves[1][k]]), full[k])
+    sub = np.arange(0, B, 509)
+    eng = OracleEngine(len(sub), 0, n)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    for k in range(3):
+        eng.predict(acc[k][sub], gyr[k][sub], DT)
+    eng.correct(ids[sub], pos[sub], quat[sub], 1)
+    assert state_rel_err(full[0][sub], eng.nominal)[0] <= STATE_TOL
+    assert cov_rel_err(full[2][sub], eng.P) <= COV_TOL

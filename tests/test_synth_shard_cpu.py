@@ -1,0 +1,124 @@
+"""CPU suite, part 3: host logic -- seeded streams are shard-invariant, shard ranges
+tile the batch, and the N > 1 path (shard -> step -> gather) gives the single-process
+result bit for bit (world_size-2 gloo, oracle standing in for the device engine)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from fbus_ekf import capi, shard, synth
+
+
+def test_shard_ranges_tile_the_batch():
+    for total in (1, 63, 64, 65, 4096, 65536, 262144, 100001):
+        for world in (1, 2, 3, 8):
+            r = [shard.shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            for (a0, a1), (b0, b1) in zip(r, r[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert all(lo % 64 == 0 for lo, _ in r)
+
+
+def test_streams_are_shard_invariant():
+    prm = capi.default_params(0)
+    full = synth.initial_state(0, 3000, list(prm.p0_diag), 18, mixed_cov=True)
+    for lo, hi in ((0, 1024), (1000, 2100), (2047, 3000)):
+        part = synth.initial_state(lo, hi, list(prm.p0_diag), 18, mixed_cov=True)
+        for f, p in zip(full, part):
+            assert np.array_equal(f[lo:hi], p)
+    acc, gyr = synth.imu_samples(0, 3000, 5, 3, full[0])
+    a2, g2 = synth.imu_samples(1500, 2500, 5, 3, full[0][1500:2500])
+    assert np.array_equal(acc[:, 1500:2500], a2) and np.array_equal(gyr[:, 1500:2500], g2)
+    ids, pos, quat = synth.marker_frame(0, 3000, 2, 4, full[0], prm)
+    i2, p2, q2 = synth.marker_frame(700, 1300, 2, 4, full[0][700:1300], prm)
+    assert np.array_equal(ids[700:1300], i2) and np.array_equal(pos[700:1300], p2) and np.array_equal(quat[700:1300], q2)
+    assert len({tuple(sorted(r)) for r in ids[:50].tolist()}) > 5           # markers vary across filters
+    assert all(len(set(r)) == 4 for r in ids[:200].tolist())                # drawn without replacement
+    assert np.abs(np.linalg.norm(quat, axis=-1) - 1).max() < 1e-12
+
+
+def test_synthetic_measurement_is_consistent_with_the_state():
+    """a correct() with the synthetic markers barely moves a filter sitting at x0 (h(x0) + 1e-3 noise)."""
+    from replay_ref import OracleEngine
+    prm = capi.default_params(0)
+    nom, rot, P, prev = synth.initial_state(0, 32, list(prm.p0_diag), 18)
+    ids, pos, quat = synth.marker_frame(0, 32, 0, 4, nom, prm)
+    eng = OracleEngine(32, 0, 18)
+    eng.set_state(nom, rot, P, prev)
+    ok = eng.correct(ids, pos, quat, 1)
+    assert ok.all()
+    assert np.abs(eng.nominal[:, 0:3] - nom[:, 0:3]).max() < 2e-2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import torch
+    import torch.distributed as dist
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for sub in ("../fbus-ekf_amd", "../oracle", "."):
+        sys.path.insert(0, os.path.join(here, sub))
+    from replay_ref import OracleEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard.shard_range(total, rank, world)
+    out = _run_shard(OracleEngine, lo, hi)
+    local = torch.from_numpy(np.concatenate([out[0].ravel(), out[2].ravel()]))
+    gathered = shard.gather_records(local, dist, world)
+    worst = shard.max_over_ranks(float(rank + 1), dist, world)
+    if rank == 0:
+        q.put(([g.numpy() for g in gathered], worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_shard(engine_cls, lo, hi):
+    prm = capi.default_params(0)
+    nom, rot, P, prev = synth.initial_state(lo, hi, list(prm.p0_diag), 18)
+    eng = engine_cls(hi - lo, 0, 18)
+    eng.set_state(nom, rot, P, prev)
+    step = 0
+    for frame in range(2):
+        acc, gyr = synth.imu_samples(lo, hi, step, 3, nom)
+        for k in range(3):
+            eng.predict(acc[k], gyr[k], np.array([0.005]))
+        step += 3
+        ids, pos, quat = synth.marker_frame(lo, hi, frame, 4, nom, prm)
+        eng.correct(ids, pos, quat, 1)
+    return eng.get_state()
+
+
+def test_two_rank_gloo_run_equals_single_process_bitwise():
+    import torch.multiprocessing as mp
+    total, world = 256, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered, worst = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert worst == 2.0
+    from replay_ref import OracleEngine
+    ref = _run_shard(OracleEngine, 0, total)
+    off = 0
+    for r in range(world):
+        lo, hi = shard.shard_range(total, r, world)
+        n = hi - lo
+        nom = gathered[r][:n * 19].reshape(n, 19)
+        P = gathered[r][n * 19:].reshape(n, 18, 18)
+        assert np.array_equal(nom, ref[0][lo:hi]) and np.array_equal(P, ref[2][lo:hi])
+        off += n
+    assert off == total
