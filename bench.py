@@ -69,15 +69,13 @@ def cpu_baseline(args, prm_dialect, seconds):
         nom, rot, P, prev = synth.initial_state(0, Bs, list(prm.p0_diag), 18)
         acc, gyr = synth.imu_samples(0, Bs, 0, sum(PATTERN), nom)
         frames = [synth.marker_frame(0, Bs, f, args.markers, nom, prm) for f in range(len(PATTERN))]
-        dt = np.array([0.005])
+        dt = np.full(max(PATTERN), 0.005)
         t0 = time.perf_counter()
         for _ in range(reps):
             k = 0
-            for f, K in enumerate(PATTERN):
-                for _k in range(K):
-                    orc.predict(nom, rot, P, prev, acc[k], gyr[k], dt)
-                    k += 1
-                orc.correct(nom, rot, P, prev, *frames[f], mode)
+            for f, K in enumerate(PATTERN):                  # one thread team per camera frame
+                orc.frame(nom, rot, P, prev, acc[k:k + K], gyr[k:k + K], dt[:K], *frames[f], mode)
+                k += K
         return Bs * STEPS_PER_BENCH_STEP * reps / (time.perf_counter() - t0)
 
     probe = run(256, 1, 1)                                   # steps/s of one thread, short probe

@@ -58,6 +58,13 @@ def load_library():
         raise FbusError(-1, "load_library",
                         f"{path} is missing -- build it with `python fbus-ekf_amd/build.py` "
                         "(there is no CPU fallback)")
+    # A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64.so.7; if this
+    # library pulled in /opt/rocm's copy first, a later `import torch` would end up with a second
+    # runtime and device discovery fails.  Loading torch first makes both share torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p
     H = C.c_void_p

@@ -112,9 +112,11 @@ def initial_state(lo, hi, p0_diag, nstate=18, seed=BASE_SEED, mixed_cov=False):
     rot = q2R(nominal[:, 6:10]).reshape(-1, 9)
     P0 = np.diag(np.repeat(np.asarray(p0_diag, float), 3)[:N])
     n = hi - lo
-    if mixed_cov:   # A P0 A' with A = I + small random: dense, symmetric positive definite
+    if mixed_cov:   # S C S with S = sqrt(P0) and C = A A' a random correlation-like matrix (A = I + small):
+        # dense, symmetric positive definite, every block at its physical scale
         A = np.eye(N) + raw[:, 19:].reshape(n, 18, 18)[:, :N, :N]
-        P = A @ P0 @ np.swapaxes(A, 1, 2)
+        S = np.sqrt(P0)
+        P = S @ (A @ np.swapaxes(A, 1, 2)) @ S
         P = (P + np.swapaxes(P, 1, 2)) / 2
     else:
         P = np.broadcast_to(P0, (n, N, N)).copy()

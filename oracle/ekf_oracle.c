@@ -633,7 +633,7 @@ static void store_state(const fbo_state* s, int n, double* nom, double* rot, dou
 }
 
 typedef struct {
-    int lo, hi, is_correct;
+    int lo, hi, is_correct, is_frame, K, B;
     double *nominal, *rot, *P;
     int* prev;
     const fbo_params* prm;
@@ -653,7 +653,14 @@ static void* batch_worker(void* arg)
     for (int b = j->lo; b < j->hi; ++b) {
         int prev = j->prev ? j->prev[b] : 0;
         load_state(&s, n, j->nominal + 19 * (size_t)b, j->rot + 9 * (size_t)b, j->P + (size_t)n * n * b, prev);
-        if (!j->is_correct) {
+        if (j->is_frame) {
+            for (int k = 0; k < j->K; ++k)
+                fbo_predict(&s, j->prm, j->accel + 3 * ((size_t)k * j->B + b), j->gyro + 3 * ((size_t)k * j->B + b),
+                            j->dt[k]);
+            if (j->M > 0)
+                fbo_correct(&s, j->prm, j->M, j->ids + (size_t)j->M * b, j->pos + 3 * (size_t)j->M * b,
+                            j->quat + 4 * (size_t)j->M * b, j->mode);
+        } else if (!j->is_correct) {
             fbo_predict(&s, j->prm, j->accel + 3 * (size_t)b, j->gyro + 3 * (size_t)b,
                         j->dt[(size_t)b * j->dt_stride]);
         } else {
@@ -704,5 +711,19 @@ void fbo_correct_batch(int B, double* nominal, double* rot, double* P, int* prev
     j.is_correct = 1;
     j.nominal = nominal; j.rot = rot; j.P = P; j.prev = prev; j.prm = prm;
     j.M = M; j.ids = ids; j.pos = pos; j.quat = quat; j.mode = mode; j.applied = applied;
+    run_batch(&j, B, nthreads);
+}
+
+void fbo_frame_batch(int B, double* nominal, double* rot, double* P, int* prev,
+                     const fbo_params* prm, int K, const double* accel, const double* gyro,
+                     const double* dt, int M, const int* ids, const double* pos,
+                     const double* quat, int mode, int nthreads)
+{
+    batch_job j;
+    memset(&j, 0, sizeof(j));
+    j.is_frame = 1; j.K = K; j.B = B;
+    j.nominal = nominal; j.rot = rot; j.P = P; j.prev = prev; j.prm = prm;
+    j.accel = accel; j.gyro = gyro; j.dt = dt;
+    j.M = M; j.ids = ids; j.pos = pos; j.quat = quat; j.mode = mode;
     run_batch(&j, B, nthreads);
 }

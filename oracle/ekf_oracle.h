@@ -106,6 +106,13 @@ void fbo_correct_batch(int B, double* nominal, double* rot, double* P, int* prev
                        const fbo_params* prm, int M, const int* ids, const double* pos,
                        const double* quat, int mode, int* applied, int nthreads);
 
+/* one camera frame per thread range: K predicts (accel/gyro K x B x 3, dt K values)
+ * followed by one correct; threads are spawned once per call (CPU-baseline driver). */
+void fbo_frame_batch(int B, double* nominal, double* rot, double* P, int* prev,
+                     const fbo_params* prm, int K, const double* accel, const double* gyro,
+                     const double* dt, int M, const int* ids, const double* pos,
+                     const double* quat, int mode, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

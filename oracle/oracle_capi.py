@@ -64,6 +64,8 @@ def load(native=False):
     lib.fbo_predict_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), dp, dp, dp, C.c_int, C.c_int]
     lib.fbo_correct_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, ip, dp, dp,
                                       C.c_int, ip, C.c_int]
+    lib.fbo_frame_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, dp, dp, dp, C.c_int,
+                                    ip, dp, dp, C.c_int, C.c_int]
     lib.fbv_default_params.argtypes = [C.POINTER(FbvParams)]
     lib.fbv_refraction_triangulate.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
     lib.fbv_normal_triangulate.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
@@ -118,6 +120,22 @@ class Oracle:
         self.lib.fbo_correct_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), M,
                                    _ip(ids), _dp(pos), _dp(quat), mode, _ip(applied), self.nthreads)
         return applied
+
+
+    def frame(self, nominal, rot, P, prev, accel, gyro, dt, ids, pos, quat, mode=NEAREST):
+        """K predicts + one correct per filter, threads spawned once (CPU-baseline driver)."""
+        B = nominal.shape[0]
+        accel = np.ascontiguousarray(accel, np.float64)
+        K = accel.size // (3 * B)
+        gyro = np.ascontiguousarray(gyro, np.float64)
+        dt = np.ascontiguousarray(dt, np.float64)
+        assert dt.size == K
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        pos = np.ascontiguousarray(pos, np.float64)
+        quat = np.ascontiguousarray(quat, np.float64)
+        self.lib.fbo_frame_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), K, _dp(accel),
+                                 _dp(gyro), _dp(dt), M, _ip(ids), _dp(pos), _dp(quat), mode, self.nthreads)
 
 
 def vision_params():

@@ -110,34 +110,33 @@ def land_slice():
 
 
 def ekf_random():
+    sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
+    from fbus_ekf import capi, synth
     rng = np.random.default_rng(20261002)
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)   # fp32-representable inputs
     out = {}
     B, M = 24, 4
     for dialect in (onp.MATLAB, onp.CPP):
+        cprm = capi.default_params(dialect)
         for n in (18, 15):
             prm = onp.Params(dialect, n)
             tag = f"d{dialect}_n{n}"
-            nom = np.zeros((B, 19)); rot = np.zeros((B, 9)); P = np.zeros((B, n, n))
-            nom[:, 0:3] = rng.uniform(-1, 1, (B, 3)); nom[:, 3:6] = rng.normal(0, 0.1, (B, 3))
-            q = rng.normal(size=(B, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); nom[:, 6:10] = q
-            nom[:, 10:13] = rng.normal(0, 0.05, (B, 3)); nom[:, 13:16] = rng.normal(0, 0.002, (B, 3))
-            nom[:, 16:19] = [9.8, 0, 0]
-            for b in range(B):
-                rot[b] = onp.q2R(q[b]).ravel()
-                A = np.eye(n) + 0.05 * rng.normal(size=(n, n))
-                P[b] = A @ prm.P0() @ A.T
-                P[b] = (P[b] + P[b].T) / 2
-            acc = rng.normal(0, 0.5, (B, 3)) + np.einsum("bji,j->bi", rot.reshape(B, 3, 3), [-9.8, 0, 0])
-            gyr = rng.normal(0, 0.02, (B, 3))
+            nom, rot, P, _ = synth.initial_state(5000, 5000 + B, list(cprm.p0_diag), n, mixed_cov=True)
+            nom, rot, P = r32(nom), r32(rot), r32(P)
+            acc, gyr = synth.imu_samples(5000, 5000 + B, 0, 1, nom)
+            acc, gyr = r32(acc[0]), r32(gyr[0])
             gyr[0] = nom[0, 13:16]                     # w == 0 exactly: the reference's NaN case (guarded)
-            gyr[1] = nom[1, 13:16] + [3e-5, 0, 0]      # below the C++ 1e-4 small-rate switch
-            dt = rng.uniform(0.001, 0.01, B)
-            ids = np.stack([rng.choice([0, 1, 2, 3, 4, 5, 6, 16, 17, 18, 9], M, replace=False) for _ in range(B)])
+            gyr[1] = r32(nom[1, 13:16] + [3e-5, 0, 0])  # below the C++ 1e-4 small-rate switch
+            dt = r32(rng.uniform(0.001, 0.01, B))
+            ids, pos, quat = synth.marker_frame(5000, 5000 + B, 0, M, nom, cprm)
+            pos = r32(pos + rng.normal(0, 0.03, pos.shape))        # innovations of a few cm
+            quat = quat + rng.normal(0, 0.01, quat.shape)
+            quat = r32(quat / np.linalg.norm(quat, axis=2, keepdims=True))
+            quat[5] = -quat[5]                         # opposite-sign measurement quaternion: sign unification
             ids[2] = [-1, -1, -1, -1]                  # nothing visible
             ids[3] = [9, -1, 9, -1]                    # only an id outside the map
             ids[4, 1] = -1
-            pos = rng.normal(0, 0.5, (B, M, 3)); quat = rng.normal(size=(B, M, 4))
-            quat /= np.linalg.norm(quat, axis=2, keepdims=True)
+            ids[6, 0] = 9
             prev = rng.choice([0, 1, 2, 16], B).astype(np.int32)
 
             def run(fn):

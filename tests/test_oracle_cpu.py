@@ -81,6 +81,7 @@ def test_c_oracle_matches_golden(dialect, n):
         ok = orc.correct(nom, rot, P, prev, g[t + "_ids"], g[t + "_pos"], g[t + "_quat"], mode)
         assert (ok == g[f"{t}_{name}_ok"]).all()
         assert ok[2] == 0 and ok[3] == 0                     # nothing visible / id outside the map
+        assert mode == oc.NEAREST or ok[6] == 1              # stacked: an unknown id beside known ones is skipped
         assert (prev == g[f"{t}_{name}_prev"]).all()
         assert np.abs(nom - g[f"{t}_{name}_nom"]).max() < 1e-9
         assert np.abs(P - g[f"{t}_{name}_P"]).max() / np.abs(P).max() < 1e-10
