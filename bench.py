@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--kernel-timing", choices=["on", "off"], default="on",
+                    help="bracket every launch with HIP events inside the timed region (feeds `roofline`)")
     return ap.parse_args()
 
 
@@ -145,7 +147,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    flt.timing_enable(True)
+    flt.timing_enable(args.kernel_timing == "on")
     for i in range(args.warmup):
         bench_step(i)
     torch.cuda.synchronize()
@@ -179,7 +181,8 @@ def main():
     if rank == 0:
         total_steps = world * B * STEPS_PER_BENCH_STEP * args.steps
         value = total_steps / elapsed
-        pred_avg_ms = pred_ms / max(pred_n, 1)
+        pred_avg_ms = pred_ms / max(pred_n, 1) if pred_n else float("nan")
+        corr_ms = corr_ms if corr_n else float("nan")
         achieved = PREDICT_BYTES * B / (pred_avg_ms * 1e-3) / 1e9
         out = {
             "metric": "EKF steps/s (ImuUpdate+MeasureUpdate), batch=65536, 4 markers",

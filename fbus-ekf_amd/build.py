@@ -29,7 +29,9 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     srcs = [s for s in SRC if os.path.exists(s)]
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + srcs
+    # -fno-slp-vectorize: the SLP pass packs the unrolled scalar FMAs into v_pk_fma_f32 and pays for it with
+    # ~1.9x more instructions (v_mov / v_accvgpr shuffles to form register pairs) -- measured on the .s
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", OUT] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

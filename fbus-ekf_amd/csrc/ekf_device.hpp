@@ -31,12 +31,20 @@ enum { COV_SIMPLE = 0, COV_JOSEPH = 1 };
 constexpr int MK_STRIDE = 24;   // per marker-map slot: pos3 quat4 C16 pad1
 
 // ---- record layout (elements of T inside one filter's record) ----------------
+// Order inside a record (NOT the API order): [p3 q4 R9 | v3 ba3 bg3 g3 | P packed | prev].
+// The first 16 elements are all that building the measurement rows needs, the next 12 are
+// touched only by the kinematics / the final injection, so a kernel can bring the groups
+// in when it needs them instead of holding them in registers across the covariance work;
+// ba, bg, g are never written by predict and their chunks are not stored back.
 template <int N>
 struct Lay {
     static constexpr int NP = N * (N + 1) / 2;
-    static constexpr int OFF_P3 = 0, OFF_V = 3, OFF_Q = 6, OFF_BA = 10, OFF_BG = 13, OFF_G = 16;
-    static constexpr int OFF_R = 19, OFF_PREV = 28, OFF_COV = 29;
-    static constexpr int NREC = OFF_COV + NP;
+    static constexpr int OFF_P3 = 0, OFF_Q = 3, OFF_R = 7, OFF_V = 16, OFF_BA = 19, OFF_BG = 22, OFF_G = 25;
+    static constexpr int NNOM = 28;                 // nominal + carried rotation
+    static constexpr int NPQR = 16;                 // p, q, R
+    static constexpr int NKIN = 19;                 // p, q, R, v: everything predict writes
+    static constexpr int OFF_COV = 28, OFF_PREV = OFF_COV + NP;
+    static constexpr int NREC = OFF_PREV + 1;
 };
 
 template <typename T, int N>
@@ -44,6 +52,12 @@ struct Rec {
     static constexpr int EPC = 16 / (int)sizeof(T);                       // elements per 16-byte chunk
     static constexpr int NRECP = (Lay<N>::NREC + EPC - 1) / EPC * EPC;    // padded record length
     static constexpr int NCH = NRECP / EPC;                               // chunks per record
+    static constexpr int CH_NOM = Lay<N>::NNOM / EPC;                     // chunks [0, CH_NOM): nominal + R
+    static constexpr int CH_PQR = Lay<N>::NPQR / EPC;                     // chunks [0, CH_PQR): p, q, R
+    static constexpr int CH_KIN = (Lay<N>::NKIN + EPC - 1) / EPC;         // chunks predict must store back
+    static constexpr int CH_PQ = (7 + EPC - 1) / EPC;                     // chunks holding p and q
+    static constexpr int NCOVP = NRECP - Lay<N>::NNOM;                    // P + prev + padding
+    static_assert(Lay<N>::NNOM % EPC == 0 && Lay<N>::NPQR % EPC == 0, "groups must end on chunk boundaries");
 };
 
 template <typename T> struct Vec16;
@@ -230,29 +244,54 @@ __device__ __forceinline__ void cov_propagate(T* P, const T* R, const T* a, cons
 #undef PS
 }
 
-// One ImuUpdate on the record held in registers.
+// One ImuUpdate: nom = the 28 nominal + rotation elements (record order), P = packed covariance.
 template <typename T, int N, int DIALECT>
-__device__ __forceinline__ void predict_step(T* rec, const T* accel, const T* gyro, T dt, const T* qd)
+__device__ __forceinline__ void predict_step(T* nom, T* P, const T* accel, const T* gyro, T dt, const T* qd)
 {
     using L = Lay<N>;
-    T* p = rec + L::OFF_P3; T* v = rec + L::OFF_V; T* q = rec + L::OFF_Q;
-    const T* ba = rec + L::OFF_BA; const T* bg = rec + L::OFF_BG; const T* g = rec + L::OFF_G;
-    T* R = rec + L::OFF_R; T* P = rec + L::OFF_COV;
+    T* p = nom + L::OFF_P3; T* v = nom + L::OFF_V; T* q = nom + L::OFF_Q;
+    const T* ba = nom + L::OFF_BA; const T* bg = nom + L::OFF_BG; const T* g = nom + L::OFF_G;
+    T* R = nom + L::OFF_R;
 
     const T a[3] = { accel[0] - ba[0], accel[1] - ba[1], accel[2] - ba[2] };   // ImuUpdate.m:37-38
     const T w[3] = { gyro[0] - bg[0], gyro[1] - bg[1], gyro[2] - bg[2] };
     const T wn = fb_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
 
-    T Th[9], qT[4], qH[4], R0[9], RH[9], RT[9];
+    // ---- phase 1: rotation increments (kept small: n, sin/cos) and F(theta,theta) ----------
+    T Th[9], n[3], s2, c2, s4, c4;
+    bool small_rate = false;
     if (DIALECT == DIALECT_MATLAB) {
-        // ImuUpdate.m:41-48,68.  axis/|axis| is NaN at w == 0 in the reference; guarded here
+        // ImuUpdate.m:41-43,68.  axis/|axis| is NaN at w == 0 in the reference; guarded here
         // (identity rotation), bit-identical away from zero.
         const T inv = (wn > T(0)) ? T(1) / wn : T(0);
-        const T n[3] = { w[0] * inv, w[1] * inv, w[2] * inv };
+        n[0] = w[0] * inv; n[1] = w[1] * inv; n[2] = w[2] * inv;
         const T dth = wn * fb_abs(dt);
-        T s2, c2, s4, c4;
         fb_sincos(dth * T(0.5), s2, c2);
         fb_sincos(dth * T(0.25), s4, c4);
+        // expm(-[w]x dt) in closed form: I - sin(phi)[n]x + (1-cos(phi))[n]x^2 with
+        // sin(phi) = 2 s2 c2 and 1-cos(phi) = 2 s2^2 (no cancellation in fp32).
+        const T sa = (dt < T(0) ? -T(2) : T(2)) * s2 * c2, sb = T(2) * s2 * s2;
+        Th[0] = T(1) - sb + sb * n[0] * n[0]; Th[1] = sb * n[0] * n[1] + sa * n[2]; Th[2] = sb * n[0] * n[2] - sa * n[1];
+        Th[3] = sb * n[1] * n[0] - sa * n[2]; Th[4] = T(1) - sb + sb * n[1] * n[1]; Th[5] = sb * n[1] * n[2] + sa * n[0];
+        Th[6] = sb * n[2] * n[0] + sa * n[1]; Th[7] = sb * n[2] * n[1] - sa * n[0]; Th[8] = T(1) - sb + sb * n[2] * n[2];
+    } else {
+        // filter.cpp:544-561,603
+        small_rate = !(wn > T(10e-5));
+        const T inv = small_rate ? T(0) : T(1) / wn;
+        n[0] = w[0] * inv; n[1] = w[1] * inv; n[2] = w[2] * inv;
+        fb_sincos(wn * dt * T(0.5), s2, c2);
+        fb_sincos(wn * dt * T(0.25), s4, c4);
+        Th[0] = T(1);        Th[1] = w[2] * dt;   Th[2] = -w[1] * dt;
+        Th[3] = -w[2] * dt;  Th[4] = T(1);        Th[5] = w[0] * dt;
+        Th[6] = w[1] * dt;   Th[7] = -w[0] * dt;  Th[8] = T(1);
+    }
+
+    // ---- phase 2: covariance; reads the pre-step (carried) rotation (filter.cpp:510) -----------
+    cov_propagate<T, N>(P, R, a, Th, dt, qd);
+
+    // ---- phase 3: quaternion, velocity, position   ImuUpdate.m:42-60 ; filter.cpp:539-581 -----
+    T qT[4], qH[4], R0[9], RH[9], RT[9];
+    if (DIALECT == DIALECT_MATLAB) {
         const T dqT[4] = { c2, n[0] * s2, n[1] * s2, n[2] * s2 };
         const T dqH[4] = { c4, n[0] * s4, n[1] * s4, n[2] * s4 };
         quat_mul(q, dqT, qT);
@@ -261,44 +300,24 @@ __device__ __forceinline__ void predict_step(T* rec, const T* accel, const T* gy
         for (int i = 0; i < 9; ++i) R0[i] = R[i];                 // carried, possibly stale (:46)
         quat_to_rotmat_m(qH, RH);
         quat_to_rotmat_m(qT, RT);
-        // expm(-[w]x dt) in closed form: I - sin(phi)[n]x + (1-cos(phi))[n]x^2 with
-        // sin(phi) = 2 s2 c2 and 1-cos(phi) = 2 s2^2 (no cancellation in fp32).
-        const T sa = (dt < T(0) ? -T(2) : T(2)) * s2 * c2, sb = T(2) * s2 * s2;
-        Th[0] = T(1) - sb + sb * n[0] * n[0]; Th[1] = sb * n[0] * n[1] + sa * n[2]; Th[2] = sb * n[0] * n[2] - sa * n[1];
-        Th[3] = sb * n[1] * n[0] - sa * n[2]; Th[4] = T(1) - sb + sb * n[1] * n[1]; Th[5] = sb * n[1] * n[2] + sa * n[0];
-        Th[6] = sb * n[2] * n[0] + sa * n[1]; Th[7] = sb * n[2] * n[1] - sa * n[0]; Th[8] = T(1) - sb + sb * n[2] * n[2];
     } else {
-        // filter.cpp:539-564,603
-        quat_to_rotmat_e(q, R0);                                   // fresh (:542)
-        if (wn > T(10e-5)) {
-            const T inv = T(1) / wn;
-            const T n[3] = { w[0] * inv, w[1] * inv, w[2] * inv };
-            T s2, c2, s4, c4;
-            fb_sincos(wn * dt * T(0.5), s2, c2);
-            fb_sincos(wn * dt * T(0.25), s4, c4);
-            const T dqT[4] = { c2, n[0] * s2, n[1] * s2, n[2] * s2 };
-            const T dqH[4] = { c4, n[0] * s4, n[1] * s4, n[2] * s4 };
-            quat_mul(q, dqT, qT);
-            quat_mul(q, dqH, qH);
-        } else {
-            const T dqT[4] = { T(1), T(0.5) * dt * w[0], T(0.5) * dt * w[1], T(0.5) * dt * w[2] };
-            const T dqH[4] = { T(1), T(0.25) * dt * w[0], T(0.25) * dt * w[1], T(0.25) * dt * w[2] };
-            quat_mul(q, dqT, qT);
-            quat_mul(q, dqH, qH);
+        quat_to_rotmat_e(q, R0);                                   // fresh (filter.cpp:542)
+        T dqT[4], dqH[4];
+        if (!small_rate) {
+            dqT[0] = c2; dqT[1] = n[0] * s2; dqT[2] = n[1] * s2; dqT[3] = n[2] * s2;
+            dqH[0] = c4; dqH[1] = n[0] * s4; dqH[2] = n[1] * s4; dqH[3] = n[2] * s4;
+        } else {                                                   // filter.cpp:553-560
+            dqT[0] = T(1); dqT[1] = T(0.5) * dt * w[0]; dqT[2] = T(0.5) * dt * w[1]; dqT[3] = T(0.5) * dt * w[2];
+            dqH[0] = T(1); dqH[1] = T(0.25) * dt * w[0]; dqH[2] = T(0.25) * dt * w[1]; dqH[3] = T(0.25) * dt * w[2];
         }
+        quat_mul(q, dqT, qT);
+        quat_mul(q, dqH, qH);
         quat_normalize(qH);
         quat_normalize(qT);
         quat_to_rotmat_e(qH, RH);
         quat_to_rotmat_e(qT, RT);
-        Th[0] = T(1);        Th[1] = w[2] * dt;   Th[2] = -w[1] * dt;
-        Th[3] = -w[2] * dt;  Th[4] = T(1);        Th[5] = w[0] * dt;
-        Th[6] = w[1] * dt;   Th[7] = -w[0] * dt;  Th[8] = T(1);
     }
-
-    // covariance first: it reads the pre-step (carried) rotation (filter.cpp:510)
-    cov_propagate<T, N>(P, R, a, Th, dt, qd);
-
-    // velocity / position, RK4-style   ImuUpdate.m:49-60 ; filter.cpp:567-581
+    // RK4-style   ImuUpdate.m:49-60 ; filter.cpp:567-581
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T kv1 = R0[3 * i] * a[0] + R0[3 * i + 1] * a[1] + R0[3 * i + 2] * a[2] + g[i];
@@ -322,8 +341,8 @@ __device__ __forceinline__ void predict_step(T* rec, const T* accel, const T* gy
 // ================================================================================
 // One scalar measurement row h (non-zeros hA in columns 0..2, hB in columns 6..8),
 // residual rk, noise Rk, applied to P and accumulated into dx.
-template <typename T, int N, bool HAS_A>
-__device__ __forceinline__ void scalar_update(T* P, T* dx, const T* hA, const T* hB, T rk, T Rk, int cov_form)
+template <typename T, int N, bool HAS_A, int COV>
+__device__ __forceinline__ void scalar_update(T* P, T* dx, const T* hA, const T* hB, T rk, T Rk)
 {
 #define PS(i, j) P[pidx<N>((i), (j))]
     T Ph[N];
@@ -340,42 +359,44 @@ __device__ __forceinline__ void scalar_update(T* P, T* dx, const T* hA, const T*
         inn -= hA[0] * dx[0] + hA[1] * dx[1] + hA[2] * dx[2];
     }
     const T is = T(1) / s;
-    T K[N];
+    // gain entries K_i = Ph_i / s are formed row by row, never stored
+    if (COV == COV_JOSEPH) {
+        // P - K Ph' - Ph K' + s K K'  ==  P - K Ph'  for the optimal gain; kept as an option
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        K[i] = Ph[i] * is;
-        dx[i] += K[i] * inn;
-    }
-    if (cov_form == COV_JOSEPH) {
+        for (int i = 0; i < N; ++i) {
+            const T ki = Ph[i] * is;
+            dx[i] += ki * inn;
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-#pragma unroll
-            for (int j = i; j < N; ++j) PS(i, j) += s * K[i] * K[j] - K[i] * Ph[j] - Ph[i] * K[j];
+            for (int j = i; j < N; ++j) {
+                const T kj = Ph[j] * is;
+                PS(i, j) += s * ki * kj - ki * Ph[j] - Ph[i] * kj;
+            }
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i)
+        for (int i = 0; i < N; ++i) {
+            const T ki = Ph[i] * is;
+            dx[i] += ki * inn;
 #pragma unroll
-            for (int j = i; j < N; ++j) PS(i, j) -= K[i] * Ph[j];
+            for (int j = i; j < N; ++j) PS(i, j) -= ki * Ph[j];
+        }
     }
 #undef PS
 }
 
 // The 7 rows of one marker (map slot constants mk), linearised at the record's
 // nominal state (which is not modified until inject()).
-template <typename T, int N, int DIALECT>
-__device__ __forceinline__ void marker_update(T* rec, T* dx, const DevConst<T>& dc, const T* __restrict__ mk,
-                                              const T* yp, const T* yq)
+template <typename T, int N, int DIALECT, int COV>
+__device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const DevConst<T>& dc,
+                                              const T* __restrict__ mk, const T* yp, const T* yq)
 {
     using L = Lay<N>;
-    const T* p = rec + L::OFF_P3; const T* q = rec + L::OFF_Q; const T* R = rec + L::OFF_R;
-    T* P = rec + L::OFF_COV;
-    T Pm[3], Qm[4], Cm[16];
+    const T* p = pqr + L::OFF_P3; const T* q = pqr + L::OFF_Q; const T* R = pqr + L::OFF_R;
+    T Pm[3], Qm[4];
 #pragma unroll
     for (int i = 0; i < 3; ++i) Pm[i] = mk[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Qm[i] = mk[3 + i];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Cm[i] = mk[7 + i];
 
     // hp = R_IL R' (Pm - p - R P_IL)          MeasureUpdate.m:67 ; filter.cpp:684-685
     T d[3], u[3], t[3], hp[3];
@@ -409,7 +430,14 @@ __device__ __forceinline__ void marker_update(T* rec, T* dx, const DevConst<T>& 
         Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
         Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        scalar_update<T, N, true, COV>(P, dx, Hpp + 3 * k, Hpt + 3 * k, yp[k] - hp[k], dc.r_pos);
+
     // H(4:7,7:9) = Rq(Qm) Lq(Q_IL) L2 Lq(q) L1 = C * (Lq(q) L1)   MeasureUpdate.m:74-75 ; filter.cpp:693-694
+    T Cm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Cm[i] = mk[7 + i];
     const T w = q[0], x = q[1], y = q[2], z = q[3];
     const T LL[12] = { -x, -y, -z,   w, -z, y,   z, w, -x,   -y, x, w };   // Lq(q)(:,2:4)
     // sign unification                          MeasureUpdate.m:77-81 ; filter.cpp:698-706
@@ -427,21 +455,17 @@ __device__ __forceinline__ void marker_update(T* rec, T* dx, const DevConst<T>& 
         for (int j = 0; j < 3; ++j)
             Hq[3 * i + j] = sg * (Cm[4 * i] * LL[j] + Cm[4 * i + 1] * LL[3 + j] + Cm[4 * i + 2] * LL[6 + j] + Cm[4 * i + 3] * LL[9 + j]);
     const T sq = (k1 > k2) ? T(-1) : T(1);
-
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        scalar_update<T, N, true>(P, dx, Hpp + 3 * k, Hpt + 3 * k, yp[k] - hp[k], dc.r_pos, dc.cov_form);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         // Matlab zeroes the quaternion residual (MeasureUpdate.m:88); C++ uses it (filter.cpp:718-721)
         const T rk = (DIALECT == DIALECT_CPP) ? (yq[k] - sq * hq[k]) : T(0);
-        scalar_update<T, N, false>(P, dx, Hq + 3 * k, Hq + 3 * k, rk, dc.r_quat, dc.cov_form);
+        scalar_update<T, N, false, COV>(P, dx, Hq + 3 * k, Hq + 3 * k, rk, dc.r_quat);
     }
 }
 
 // State injection   MeasureUpdate.m:92-98 ; filter.cpp:726-733.  R is NOT refreshed.
 template <typename T, int N>
-__device__ __forceinline__ void inject(T* rec, const T* dx)
+__device__ __forceinline__ void inject(T* rec /* the 28 nominal + rotation elements */, const T* dx)
 {
     using L = Lay<N>;
 #pragma unroll

@@ -44,31 +44,32 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const T* recs, unsig
     return __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)TILE_BYTES, 0x00020000);
 }
 
-template <typename T, int N>
-__device__ __forceinline__ void load_record(__amdgpu_buffer_rsrc_t rs, unsigned lane, T* rec)
+// chunks [C0, C1) of the lane's record -> dst[0 .. (C1-C0)*EPC)
+template <typename T, int N, int C0, int C1>
+__device__ __forceinline__ void load_chunks(__amdgpu_buffer_rsrc_t rs, unsigned lane, T* dst)
 {
     constexpr int EPC = Rec<T, N>::EPC;
     const unsigned off = lane * 16u;
 #pragma unroll
-    for (int c = 0; c < Rec<T, N>::NCH; ++c) {
+    for (int c = C0; c < C1; ++c) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (c & 3) * 1024u, (c >> 2) * 4096, 0);
         const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
-        for (int k = 0; k < EPC; ++k) rec[c * EPC + k] = e[k];
+        for (int k = 0; k < EPC; ++k) dst[(c - C0) * EPC + k] = e[k];
     }
 }
 
-template <typename T, int N>
-__device__ __forceinline__ void store_record(__amdgpu_buffer_rsrc_t rs, unsigned lane, const T* rec)
+template <typename T, int N, int C0, int C1>
+__device__ __forceinline__ void store_chunks(__amdgpu_buffer_rsrc_t rs, unsigned lane, const T* src)
 {
     constexpr int EPC = Rec<T, N>::EPC;
     const unsigned off = lane * 16u;
 #pragma unroll
-    for (int c = 0; c < Rec<T, N>::NCH; ++c) {
+    for (int c = C0; c < C1; ++c) {
         u32x4 v;
         T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
-        for (int k = 0; k < EPC; ++k) e[k] = rec[c * EPC + k];
+        for (int k = 0; k < EPC; ++k) e[k] = src[(c - C0) * EPC + k];
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c & 3) * 1024u, (c >> 2) * 4096, 0);
     }
 }
@@ -93,28 +94,32 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
 {
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     if (b >= B) return;
+    using RC = Rec<T, N>;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
-    T rec[Rec<T, N>::NRECP];
-    load_record<T, N>(rs, threadIdx.x, rec);
+    T nom[Lay<N>::NNOM], P[RC::NCOVP];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, threadIdx.x, nom);
+    load_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
     if (MULTI) {
         for (int k = 0; k < K; ++k) {
             const size_t o = ((size_t)k * B + b) * 3;
             const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
             const T w[3] = { gyro[o], gyro[o + 1], gyro[o + 2] };
             const T h = dt_stride ? dt[(size_t)k * B + b] : dt[k];
-            predict_step<T, N, DIALECT>(rec, a, w, h, dc.qd);
+            predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
         }
     } else {
         const size_t o = (size_t)b * 3;
         const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
         const T w[3] = { gyro[o], gyro[o + 1], gyro[o + 2] };
         const T h = dt_stride ? dt[b] : dt[0];
-        predict_step<T, N, DIALECT>(rec, a, w, h, dc.qd);
+        predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
     }
-    store_record<T, N>(rs, threadIdx.x, rec);
+    // ba, bg, g are not written by ImuUpdate: their chunks stay as they are in HBM
+    store_chunks<T, N, 0, RC::CH_KIN>(rs, threadIdx.x, nom);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
 }
 
-template <typename T, int N, int DIALECT>
+template <typename T, int N, int DIALECT, int COV>
 __global__ void __launch_bounds__(BLOCK)
 correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
                const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
@@ -157,9 +162,10 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         first = min_i; last = min_i + 1;
     }
 
+    using RC = Rec<T, N>;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
-    T rec[Rec<T, N>::NRECP];
-    load_record<T, N>(rs, threadIdx.x, rec);
+    T P[RC::NCOVP];
+    load_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
@@ -171,13 +177,22 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         if (slot < 0) continue;
         const T yp[3] = { my_pos[3 * i], my_pos[3 * i + 1], my_pos[3 * i + 2] };
         const T yq[4] = { my_quat[4 * i], my_quat[4 * i + 1], my_quat[4 * i + 2], my_quat[4 * i + 3] };
-        marker_update<T, N, DIALECT>(rec, dx, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
+        // the linearisation point (p, q, R) is not modified until inject(): it is re-read per marker
+        // (an L2 hit) instead of being held in registers across the seven rank-1 updates
+        T pqr[L::NPQR];
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, threadIdx.x, pqr);
+        marker_update<T, N, DIALECT, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
         ++used;
     }
     if (used == 0) { applied[b] = 0; return; }
-    inject<T, N>(rec, dx);
-    if (new_prev >= 0) rec[L::OFF_PREV] = (T)new_prev;
-    store_record<T, N>(rs, threadIdx.x, rec);
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, threadIdx.x, nom);
+    inject<T, N>(nom, dx);
+    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    // the carried rotation is NOT refreshed by MeasureUpdate: chunks holding only R are left alone
+    store_chunks<T, N, 0, RC::CH_PQ>(rs, threadIdx.x, nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, threadIdx.x, nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
     applied[b] = 1;
 }
 
@@ -190,7 +205,11 @@ __global__ void pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ n
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     auto put = [&](int e, T v) { recs[elem_index<T, N>(b, e)] = v; };
-    if (nominal) for (int i = 0; i < 19; ++i) put(i, nominal[(size_t)b * 19 + i]);
+    // API order p v q ba bg g -> record order
+    const int map[19] = { L::OFF_P3, L::OFF_P3 + 1, L::OFF_P3 + 2, L::OFF_V, L::OFF_V + 1, L::OFF_V + 2,
+                          L::OFF_Q, L::OFF_Q + 1, L::OFF_Q + 2, L::OFF_Q + 3, L::OFF_BA, L::OFF_BA + 1, L::OFF_BA + 2,
+                          L::OFF_BG, L::OFF_BG + 1, L::OFF_BG + 2, L::OFF_G, L::OFF_G + 1, L::OFF_G + 2 };
+    if (nominal) for (int i = 0; i < 19; ++i) put(map[i], nominal[(size_t)b * 19 + i]);
     if (rot) for (int i = 0; i < 9; ++i) put(L::OFF_R + i, rot[(size_t)b * 9 + i]);
     if (prev) put(L::OFF_PREV, (T)prev[b]);
     if (P)
@@ -209,7 +228,10 @@ __global__ void unpack_kernel(const T* __restrict__ recs, int B, T* __restrict__
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     auto get = [&](int e) { return recs[elem_index<T, N>(b, e)]; };
-    if (nominal) for (int i = 0; i < 19; ++i) nominal[(size_t)b * 19 + i] = get(i);
+    const int map[19] = { L::OFF_P3, L::OFF_P3 + 1, L::OFF_P3 + 2, L::OFF_V, L::OFF_V + 1, L::OFF_V + 2,
+                          L::OFF_Q, L::OFF_Q + 1, L::OFF_Q + 2, L::OFF_Q + 3, L::OFF_BA, L::OFF_BA + 1, L::OFF_BA + 2,
+                          L::OFF_BG, L::OFF_BG + 1, L::OFF_BG + 2, L::OFF_G, L::OFF_G + 1, L::OFF_G + 2 };
+    if (nominal) for (int i = 0; i < 19; ++i) nominal[(size_t)b * 19 + i] = get(map[i]);
     if (rot) for (int i = 0; i < 9; ++i) rot[(size_t)b * 9 + i] = get(L::OFF_R + i);
     if (prev) prev[b] = (int)get(L::OFF_PREV);
     if (P)
@@ -335,7 +357,8 @@ struct fbus_ekf {
     std::string err;
     // timing
     bool timing = false;
-    struct EvPair { hipEvent_t a, b; int kind; };
+    struct EvPair { hipEvent_t a, b; int kind; int count; };
+    bool timing_suspended = false;   // frame_dev brackets its run of predicts with ONE pair
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
     double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0 };
@@ -384,16 +407,16 @@ int flush_events(fbus_ekf_t h)
         float ms = 0.f;
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
         h->t_ms[h->ev_pool[i].kind] += ms;
-        h->t_n[h->ev_pool[i].kind] += 1;
+        h->t_n[h->ev_pool[i].kind] += h->ev_pool[i].count;
     }
     h->ev_used = 0;
     return FBUS_OK;
 }
 
 // returns the index of the event pair to close after the launch, or -1
-int timing_begin(fbus_ekf_t h, int kind)
+int timing_begin(fbus_ekf_t h, int kind, int count = 1)
 {
-    if (!h->timing) return -1;
+    if (!h->timing || h->timing_suspended) return -1;
     if (h->ev_used == h->ev_pool.size()) {
         if (h->ev_pool.size() >= 8192) {
             if (flush_events(h) != FBUS_OK) return -1;
@@ -405,6 +428,7 @@ int timing_begin(fbus_ekf_t h, int kind)
     }
     const int i = (int)h->ev_used++;
     h->ev_pool[i].kind = kind;
+    h->ev_pool[i].count = count;
     (void)hipEventRecord(h->ev_pool[i].a, h->stream);
     return i;
 }
@@ -436,9 +460,14 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
 {
     const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
-    hipLaunchKernelGGL((correct_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, M,
-                       (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied,
-                       make_dc<T>(h));
+    if (h->prm.cov_form == FBUS_COV_JOSEPH)
+        hipLaunchKernelGGL((correct_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs,
+                           h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip,
+                           h->d_applied, make_dc<T>(h));
+    else
+        hipLaunchKernelGGL((correct_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs,
+                           h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip,
+                           h->d_applied, make_dc<T>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -842,13 +871,20 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
 {
     if (!h || K < 0) return FBUS_ERR_INVALID;
     const size_t es = esize(h), B = (size_t)h->B;
-    for (int k = 0; k < K; ++k) {
+    // one event pair around the whole run of K back-to-back predict launches: a pair per launch
+    // would cost ~8 us of stream time each and read ~3 us long; duration / K is the per-launch time
+    const int ev = K > 0 ? timing_begin(h, FBUS_KERNEL_PREDICT, K) : -1;
+    h->timing_suspended = true;
+    int rc = FBUS_OK;
+    for (int k = 0; k < K && rc == FBUS_OK; ++k) {
         const char* a = (const char*)accel + (size_t)k * B * 3 * es;
         const char* g = (const char*)gyro + (size_t)k * B * 3 * es;
         const char* d = (const char*)dt + (size_t)k * (dt_per_filter ? B : 1) * es;
-        const int rc = launch_predict(h, 1, a, g, d, dt_per_filter);
-        if (rc != FBUS_OK) return rc;
+        rc = launch_predict(h, 1, a, g, d, dt_per_filter);
     }
+    h->timing_suspended = false;
+    timing_end(h, ev);
+    if (rc != FBUS_OK) return rc;
     if (M > 0) return fbus_ekf_correct_dev(h, M, ids, pos, quat, mode, skip);
     return FBUS_OK;
 }
