@@ -85,3 +85,35 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"oracle_capi|ekf_oracle|libfbus_oracle|vision_oracle", text), f
+
+
+def test_cpp_host_class_compiles_links_and_fails_loudly_without_gpu(tmp_path):
+    """include/fbus/batched_filter.hpp is a usable C++ binding of the C ABI (plain g++, no HIP headers)."""
+    import subprocess
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(capi.library_path()), "..", ".."))
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <fbus/batched_filter.hpp>
+#include <cstdio>
+int main() {
+    try {
+        fbus::BatchedFilter<float> f(64, FBUS_DIALECT_CPP);
+        std::printf("created %d\n", f.batch());
+        return 0;
+    } catch (const fbus::Error& e) {
+        std::printf("error %d: %s\n", e.code, e.what());
+        return e.code == FBUS_ERR_NO_DEVICE ? 42 : 1;
+    }
+}
+''')
+    exe = tmp_path / "t"
+    libdir = os.path.dirname(capi.library_path())
+    subprocess.run(["g++", "-std=c++14", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lfbus_ekf", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 42, r.stdout + r.stderr
+        assert "no CPU fallback" in r.stdout
