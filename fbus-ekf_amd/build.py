@@ -5,8 +5,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "fbus_ekf.hip"), os.path.join(HERE, "csrc", "fbus_vision.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "..", "include", "fbus_ekf.h")]
+SRC = [os.path.join(HERE, "csrc", "fbus_ekf.hip")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "csrc", "vision_device.hpp"),
+              os.path.join(HERE, "..", "include", "fbus_ekf.h")]
 OUT = os.path.join(HERE, "lib", "libfbus_ekf.so")
 
 

@@ -10,6 +10,7 @@
 // NCH KiB region, and a rank's records are one contiguous block for the RCCL gather.
 #include "../../include/fbus_ekf.h"
 #include "ekf_device.hpp"
+#include "vision_device.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -196,6 +197,42 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     applied[b] = 1;
 }
 
+// One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
+template <typename T>
+__global__ void __launch_bounds__(256)
+marker_pose_kernel(int n, int geometry, const T* __restrict__ left, const T* __restrict__ right,
+                   T* __restrict__ pos, T* __restrict__ quat, T* __restrict__ corners3d, VisConst<T> vc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T C[12];
+    if (geometry == VIS_CORNERS3D) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) C[k] = left[(size_t)i * 12 + k];
+    } else {
+        T l[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { l[k] = left[(size_t)i * 8 + k]; r[k] = right[(size_t)i * 8 + k]; }
+        if (geometry == VIS_REFRACTIVE) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) refraction_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], C + 3 * c);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pinhole_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], C + 3 * c);
+        }
+    }
+    T p[3], q[4];
+    marker_pose(C, p, q);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos[(size_t)i * 3 + k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) quat[(size_t)i * 4 + k] = q[k];
+    if (corners3d) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) corners3d[(size_t)i * 12 + k] = C[k];
+    }
+}
+
 // AoS (API arrays) <-> records.  Not on the hot path.
 template <typename T, int N>
 __global__ void pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ nominal,
@@ -361,8 +398,8 @@ struct fbus_ekf {
     bool timing_suspended = false;   // frame_dev brackets its run of predicts with ONE pair
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
-    double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0 };
-    int64_t t_n[FBUS_KERNEL_COUNT] = { 0, 0, 0 };
+    double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0 };
+    int64_t t_n[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0 };
 };
 
 namespace {
@@ -543,6 +580,52 @@ int reset_cov_t(fbus_ekf_t h)
 int do_pack(fbus_ekf_t h, const void* n, const void* r, const void* P, const int32_t* pv) { DISPATCH2(h, pack_t, h, n, r, P, pv); }
 int do_unpack(fbus_ekf_t h, void* n, void* r, void* P, int32_t* pv) { DISPATCH2(h, unpack_t, h, n, r, P, pv); }
 int do_reset_cov(fbus_ekf_t h) { DISPATCH2(h, reset_cov_t, h); }
+
+template <typename T>
+VisConst<T> make_vc(const fbus_ekf* h)
+{
+    const fbus_params& p = h->prm;
+    double RL[9], RR[9], PL[3], PR[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { RL[3 * i + j] = p.T_SC_left[4 * i + j]; RR[3 * i + j] = p.T_SC_right[4 * i + j]; }
+        PL[i] = p.T_SC_left[4 * i + 3]; PR[i] = p.T_SC_right[4 * i + 3];
+    }
+    VisConst<T> vc;
+    double Rrl[9], Rlr[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0, b = 0;
+            for (int k = 0; k < 3; ++k) { a += RL[3 * i + k] * RR[3 * j + k]; b += RR[3 * i + k] * RL[3 * j + k]; }
+            Rrl[3 * i + j] = a; Rlr[3 * i + j] = b;
+        }
+    for (int i = 0; i < 3; ++i) {
+        double a = 0, b = 0;
+        for (int k = 0; k < 3; ++k) { a += Rrl[3 * i + k] * PR[k]; b += Rlr[3 * i + k] * PR[k]; }
+        vc.P_LR[i] = (T)(PL[i] - a);
+        vc.t_LRn[i] = (T)(PL[i] - b);
+    }
+    for (int i = 0; i < 9; ++i) { vc.R_RL[i] = (T)Rrl[i]; vc.R_LRn[i] = (T)Rlr[i]; }
+    vc.alpha0 = (T)(p.n_air / p.n_glass);
+    vc.alpha1 = (T)(p.n_glass / p.n_water);
+    vc.sqrt_minus0 = p.n_air < p.n_glass;       // vision.cpp:513
+    vc.sqrt_minus1 = p.n_glass > p.n_water;     // vision.cpp:532
+    vc.d_air = (T)p.d_air; vc.d_glass = (T)p.d_glass;
+    for (int i = 0; i < 3; ++i) vc.nrm[i] = (T)p.port_normal[i];
+    return vc;
+}
+
+template <typename T>
+int launch_marker_pose_t(fbus_ekf_t h, int n, int geometry, const void* left, const void* right, void* pos,
+                         void* quat, void* corners3d)
+{
+    const int grid = (n + 255) / 256;
+    const int ev = timing_begin(h, FBUS_KERNEL_MARKER_POSE);
+    hipLaunchKernelGGL((marker_pose_kernel<T>), dim3(grid), dim3(256), 0, h->stream, n, geometry, (const T*)left,
+                       (const T*)right, (T*)pos, (T*)quat, (T*)corners3d, make_vc<T>(h));
+    timing_end(h, ev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
 
 int ensure_stage(fbus_ekf_t h, int slot, size_t bytes)
 {
@@ -886,6 +969,39 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
     timing_end(h, ev);
     if (rc != FBUS_OK) return rc;
     if (M > 0) return fbus_ekf_correct_dev(h, M, ids, pos, quat, mode, skip);
+    return FBUS_OK;
+}
+
+int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left, const void* right, void* pos,
+                             void* quat, void* corners3d)
+{
+    if (!h || n < 1 || !left || !pos || !quat) return FBUS_ERR_INVALID;
+    if (geometry != FBUS_VIS_REFRACTIVE && geometry != FBUS_VIS_PINHOLE && geometry != FBUS_VIS_CORNERS3D)
+        return FBUS_ERR_UNSUPPORTED;
+    if (geometry != FBUS_VIS_CORNERS3D && !right) return FBUS_ERR_INVALID;
+    if (h->dtype == 32) return launch_marker_pose_t<float>(h, n, geometry, left, right, pos, quat, corners3d);
+    return launch_marker_pose_t<double>(h, n, geometry, left, right, pos, quat, corners3d);
+}
+
+int fbus_ekf_marker_pose(fbus_ekf_t h, int n, int geometry, const void* left, const void* right, void* pos,
+                         void* quat, void* corners3d)
+{
+    if (!h || n < 1 || !left || !pos || !quat) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), nn = (size_t)n;
+    const size_t in_w = geometry == FBUS_VIS_CORNERS3D ? 12 : 8;
+    const void *dl, *dr;
+    int rc;
+    if ((rc = stage_in(h, 0, left, nn * in_w * es, &dl)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, geometry == FBUS_VIS_CORNERS3D ? nullptr : right, nn * 8 * es, &dr)) != FBUS_OK) return rc;
+    if ((rc = ensure_stage(h, 2, nn * 3 * es)) != FBUS_OK) return rc;
+    if ((rc = ensure_stage(h, 3, nn * 4 * es)) != FBUS_OK) return rc;
+    if (corners3d && (rc = ensure_stage(h, 4, nn * 12 * es)) != FBUS_OK) return rc;
+    if ((rc = fbus_ekf_marker_pose_dev(h, n, geometry, dl, dr, h->stage[2], h->stage[3],
+                                       corners3d ? h->stage[4] : nullptr)) != FBUS_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(pos, h->stage[2], nn * 3 * es, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(quat, h->stage[3], nn * 4 * es, hipMemcpyDeviceToHost, h->stream));
+    if (corners3d) HIP_TRY(h, hipMemcpyAsync(corners3d, h->stage[4], nn * 12 * es, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FBUS_OK;
 }
 

@@ -193,6 +193,34 @@ class BatchedFilter:
                                           self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
         self._check(rc, "frame_dev")
 
+    # ---- marker pose from stereo corners (vision.cpp:472-759) ---------------------------
+    def marker_pose(self, left, right=None, geometry=capi.VIS_REFRACTIVE, want_corners=False):
+        """left/right: (n, 8) normalised corner coordinates (or left = (n, 12) 3-D corners with
+        geometry VIS_CORNERS3D).  Host arrays in -> (pos (n,3), quat (n,4)[, corners (n,4,3)]) host arrays out;
+        device arrays in -> device arrays of the same kind out (torch)."""
+        w = 12 if geometry == capi.VIS_CORNERS3D else 8
+        if _is_dev(left):
+            import torch
+            n = left.numel() // w
+            pos = torch.empty((n, 3), dtype=left.dtype, device=left.device)
+            quat = torch.empty((n, 4), dtype=left.dtype, device=left.device)
+            c3 = torch.empty((n, 4, 3), dtype=left.dtype, device=left.device) if want_corners else None
+            self._keep += [left, right, pos, quat, c3]
+            rc = self._lib.fbus_ekf_marker_pose_dev(self._h, n, geometry, self._p(left), self._p(right),
+                                                    self._p(pos), self._p(quat), self._p(c3))
+            self._check(rc, "marker_pose_dev")
+            return (pos, quat, c3) if want_corners else (pos, quat)
+        left = np.ascontiguousarray(left, self.np_dtype).reshape(-1, w)
+        n = left.shape[0]
+        right = None if right is None else self._host(right, (n, 8))
+        pos = np.empty((n, 3), self.np_dtype)
+        quat = np.empty((n, 4), self.np_dtype)
+        c3 = np.empty((n, 4, 3), self.np_dtype) if want_corners else None
+        rc = self._lib.fbus_ekf_marker_pose(self._h, n, geometry, self._p(left), self._p(right), self._p(pos),
+                                            self._p(quat), self._p(c3))
+        self._check(rc, "marker_pose")
+        return (pos, quat, c3) if want_corners else (pos, quat)
+
     # ---- timing -------------------------------------------------------------------------
     def timing_enable(self, on=True):
         self._check(self._lib.fbus_ekf_timing_enable(self._h, 1 if on else 0), "timing_enable")

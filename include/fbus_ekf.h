@@ -151,8 +151,26 @@ int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host);
 int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                        int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
 
+/* ---- marker pose from stereo corners (the step in front of correct) --------- */
+/* Replaces: VISION::RefractionTriangulation (C++/src/vision.cpp:472-618) or
+ * VISION::NormalTriangulation (:395-466) followed by VISION::ComputeMarkerPose
+ * (:624-759), for n markers at once (n = B x M when the output feeds correct()).
+ * geometry FBUS_VIS_REFRACTIVE / FBUS_VIS_PINHOLE: left/right are n x 8 undistorted
+ * normalised image coordinates of the four corners (x0 y0 .. x3 y3, the corners.txt
+ * layout written at vision.cpp:111-119).  FBUS_VIS_CORNERS3D: `left` is n x 12 corner
+ * positions in the left camera frame (the alternative log at vision.cpp:120-124) and
+ * `right` is ignored.  Outputs: pos n x 3, quat n x 4 (wxyz) -- exactly the arrays
+ * correct() takes -- and, if not NULL, corners3d n x 12.  Uses the handle's
+ * T_SC_left/right and refraction constants, dtype and stream. */
+enum { FBUS_VIS_REFRACTIVE = 0, FBUS_VIS_PINHOLE = 1, FBUS_VIS_CORNERS3D = 2 };
+int fbus_ekf_marker_pose(fbus_ekf_t h, int n, int geometry, const void* left, const void* right,
+                         void* pos, void* quat, void* corners3d);
+int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left, const void* right,
+                             void* pos, void* quat, void* corners3d);
+
 /* ---- measurement support (bench / profiling) -------------------------------- */
-enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N = 2, FBUS_KERNEL_COUNT = 3 };
+enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N = 2, FBUS_KERNEL_MARKER_POSE = 3,
+       FBUS_KERNEL_COUNT = 4 };
 /* When enabled, every launch of the listed kernels is bracketed by HIP events
  * on the handle's stream; read() synchronises and returns the summed device
  * time and launch count since the last reset. */
