@@ -197,6 +197,86 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     applied[b] = 1;
 }
 
+// One camera frame in ONE launch: K ImuUpdates then one MeasureUpdate with the record resident in
+// registers in between (the reference's BatchImuProcessing + ObservationUpdate, filter.cpp:232-235).
+// Same device functions, same arithmetic as K predict launches + one correct launch; the record makes
+// one HBM round trip per frame instead of one per EKF step.
+template <typename T, int N, int DIALECT, int COV>
+__global__ void __launch_bounds__(BLOCK)
+frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
+             const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+             const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
+             unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
+    T nom[L::NNOM], P[RC::NCOVP];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, threadIdx.x, nom);
+    load_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
+    for (int k = 0; k < K; ++k) {
+        const size_t o = ((size_t)k * B + b) * 3;
+        const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
+        const T w[3] = { gyro[o], gyro[o + 1], gyro[o + 2] };
+        const T h = dt_stride ? dt[(size_t)k * B + b] : dt[k];
+        predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
+    }
+
+    int first = 0, last = (M > 0 && !(skip && skip[b])) ? M : 0;
+    int new_prev = -1;
+    const int* my_ids = ids + (size_t)b * M;
+    const T* my_pos = pos + (size_t)b * M * 3;
+    const T* my_quat = quat + (size_t)b * M * 4;
+    if (last > 0 && mode == MODE_NEAREST) {
+        const int prev_id = (DIALECT == DIALECT_CPP) ? (int)P[L::OFF_PREV - L::OFF_COV] : 0;
+        int min_i = -1, prev_i = -1;
+        T min_d = T(10), prev_d = T(0);
+        for (int i = 0; i < M; ++i) {
+            const int id = my_ids[i];
+            if (id < 0) continue;
+            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
+            const T dist = fb_sqrt(x * x + y * y + z * z);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i >= 0 && DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0))
+            min_i = prev_i;
+        int slot = -1, id = -1;
+        if (min_i >= 0) {
+            id = my_ids[min_i];
+            slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+        }
+        if (slot < 0) { first = last = 0; }
+        else {
+            if (DIALECT == DIALECT_CPP) new_prev = id;
+            first = min_i; last = min_i + 1;
+        }
+    }
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    int used = 0;
+    for (int i = first; i < last; ++i) {
+        const int id = my_ids[i];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+        const int slot = dc.id2slot[id];
+        if (slot < 0) continue;
+        const T yp[3] = { my_pos[3 * i], my_pos[3 * i + 1], my_pos[3 * i + 2] };
+        const T yq[4] = { my_quat[4 * i], my_quat[4 * i + 1], my_quat[4 * i + 2], my_quat[4 * i + 3] };
+        marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
+        ++used;
+    }
+    if (used > 0) {
+        inject<T, N>(nom, dx);
+        if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    }
+    if (M > 0) applied[b] = used > 0 ? 1 : 0;
+    store_chunks<T, N, 0, RC::CH_NOM>(rs, threadIdx.x, nom);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
+}
+
 // One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -398,8 +478,8 @@ struct fbus_ekf {
     bool timing_suspended = false;   // frame_dev brackets its run of predicts with ONE pair
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
-    double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0 };
-    int64_t t_n[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0 };
+    double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0, 0 };
+    int64_t t_n[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0, 0 };
 };
 
 namespace {
@@ -534,6 +614,31 @@ int launch_correct(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, con
                    const uint8_t* skip)
 {
     DISPATCH(h, launch_correct_t, h, M, ids, pos, quat, mode, skip);
+}
+
+template <typename T, int N, int D>
+int launch_frame_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter, int M,
+                   const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
+{
+    const int grid = (h->B + BLOCK - 1) / BLOCK;
+    const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
+    if (h->prm.cov_form == FBUS_COV_JOSEPH)
+        hipLaunchKernelGGL((frame_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,
+                           K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, M, (const int*)ids,
+                           (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+    else
+        hipLaunchKernelGGL((frame_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,
+                           K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, M, (const int*)ids,
+                           (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+    timing_end(h, ev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+int launch_frame(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int per, int M,
+                 const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
+{
+    DISPATCH(h, launch_frame_t, h, K, accel, gyro, dt, per, M, ids, pos, quat, mode, skip);
 }
 
 template <typename T, int N>
@@ -947,6 +1052,16 @@ int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host)
     HIP_TRY(h, hipMemcpyAsync(applied_host, h->d_applied, (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FBUS_OK;
+}
+
+int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
+                             int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
+{
+    if (!h || K < 0 || M < 0 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (K > 0 && (!accel || !gyro || !dt)) return FBUS_ERR_INVALID;
+    if (M > 0 && (!ids || !pos || !quat)) return FBUS_ERR_INVALID;
+    if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    return launch_frame(h, K, accel, gyro, dt, dt_per_filter, M, ids, pos, quat, mode, skip);
 }
 
 int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,

@@ -9,7 +9,7 @@ fallback: importing works without a GPU (so that symbols can be checked), but
 creating a filter raises if the library or a HIP device is missing.
 """
 from .capi import (DIALECT_CPP, DIALECT_MATLAB, MODE_NEAREST, MODE_STACKED, COV_SIMPLE, COV_JOSEPH,
-                   KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE,
+                   KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE, KERNEL_FRAME,
                    VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D,
                    FbusError, FbusParams, default_params, declared_symbols, load_library, library_path)
 from .filter import BatchedFilter
@@ -17,7 +17,7 @@ from . import synth, shard
 
 __all__ = [
     "DIALECT_CPP", "DIALECT_MATLAB", "MODE_NEAREST", "MODE_STACKED", "COV_SIMPLE", "COV_JOSEPH",
-    "KERNEL_PREDICT", "KERNEL_CORRECT", "KERNEL_PREDICT_N", "KERNEL_MARKER_POSE",
+    "KERNEL_PREDICT", "KERNEL_CORRECT", "KERNEL_PREDICT_N", "KERNEL_MARKER_POSE", "KERNEL_FRAME",
     "VIS_REFRACTIVE", "VIS_PINHOLE", "VIS_CORNERS3D",
     "FbusError", "FbusParams", "default_params", "declared_symbols", "load_library", "library_path",
     "BatchedFilter", "synth", "shard",

@@ -10,7 +10,7 @@ _HEADER = os.path.join(os.path.dirname(_ROOT), "include", "fbus_ekf.h")
 DIALECT_MATLAB, DIALECT_CPP = 0, 1
 MODE_NEAREST, MODE_STACKED = 0, 1
 COV_SIMPLE, COV_JOSEPH = 0, 1
-KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE = 0, 1, 2, 3
+KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE, KERNEL_FRAME = 0, 1, 2, 3, 4
 VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D = 0, 1, 2
 MAX_MARKERS, MAX_VISIBLE = 32, 16
 
@@ -92,6 +92,7 @@ def load_library():
         "fbus_ekf_correct_dev": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_get_applied": ([H, u8p], C.c_int),
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_marker_pose": ([H, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "fbus_ekf_marker_pose_dev": ([H, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "fbus_ekf_timing_enable": ([H, C.c_int], C.c_int),

@@ -180,8 +180,9 @@ class BatchedFilter:
         self._check(self._lib.fbus_ekf_get_applied(self._h, self._p(out)), "get_applied")
         return out
 
-    def frame(self, accel, gyro, dt, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
-        """K per-sample predict launches followed by one correct launch (device arrays only)."""
+    def frame(self, accel, gyro, dt, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None, fused=False):
+        """K per-sample predict launches followed by one correct launch (device arrays only);
+        fused=True: the same frame as ONE launch with the records resident in registers."""
         B = self.B
         K = accel.numel() // (3 * B)
         per = 1 if (dt.numel() == K * B and B > 1) else 0
@@ -189,7 +190,8 @@ class BatchedFilter:
         for a in (accel, gyro, dt, ids, pos, quat, skip):
             if a is not None:
                 self._keep.append(a)
-        rc = self._lib.fbus_ekf_frame_dev(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per, M,
+        fn = self._lib.fbus_ekf_frame_fused_dev if fused else self._lib.fbus_ekf_frame_dev
+        rc = fn(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per, M,
                                           self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
         self._check(rc, "frame_dev")
 

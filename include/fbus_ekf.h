@@ -151,6 +151,12 @@ int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host);
 int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                        int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
 
+/* Same frame in ONE launch: the records stay in registers between the K predicts and the correct
+ * (one HBM round trip per frame instead of one per EKF step).  Same arithmetic and results as
+ * fbus_ekf_frame_dev.  M = 0: predicts only. */
+int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
+                             int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
+
 /* ---- marker pose from stereo corners (the step in front of correct) --------- */
 /* Replaces: VISION::RefractionTriangulation (C++/src/vision.cpp:472-618) or
  * VISION::NormalTriangulation (:395-466) followed by VISION::ComputeMarkerPose
@@ -170,7 +176,7 @@ int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left
 
 /* ---- measurement support (bench / profiling) -------------------------------- */
 enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N = 2, FBUS_KERNEL_MARKER_POSE = 3,
-       FBUS_KERNEL_COUNT = 4 };
+       FBUS_KERNEL_FRAME = 4, FBUS_KERNEL_COUNT = 5 };
 /* When enabled, every launch of the listed kernels is bracketed by HIP events
  * on the handle's stream; read() synchronises and returns the summed device
  * time and launch count since the last reset. */

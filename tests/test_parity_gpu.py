@@ -323,3 +323,63 @@ def test_full_batch_properties_and_shard_equality():
     eng.correct(ids[sub], pos[sub], quat[sub], 1)
     assert state_rel_err(full[0][sub], eng.nominal, eng.P)[0] <= STATE_TOL
     assert cov_rel_err(full[2][sub], eng.P) <= COV_TOL
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_fused_frame_equals_per_call_launches(dialect, mode):
+    """one launch per frame (records resident in registers) vs K predict launches + one correct launch"""
+    import torch
+    B, M, K = 1000, 4, 7
+    prm, nom, rot, P, prev = _batch(B, dialect, 18)
+    acc, gyr = _imu(0, B, 0, 2 * K, nom)
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_acc, d_gyr, d_dt = f32(acc), f32(gyr), f32(np.full(K, DT[0]))
+    frames = []
+    for f in range(2):
+        ids, pos, quat = _markers(0, B, f, M, nom, prm)
+        ids[5] = -1
+        ids[6, :] = 9
+        frames.append((torch.from_numpy(ids).to(dev), f32(pos), f32(quat)))
+    skip = torch.from_numpy((np.arange(B) % 7 == 3).astype(np.uint8)).to(dev)
+    with BatchedFilter(B, prm) as a, BatchedFilter(B, prm) as b:
+        for flt, fused in ((a, False), (b, True)):
+            flt.set_state(nom, rot, P, prev)
+            for f in range(2):
+                ids, pos, quat = frames[f]
+                flt.frame(d_acc[f * K:(f + 1) * K], d_gyr[f * K:(f + 1) * K], d_dt, ids, pos, quat, mode,
+                          skip if f == 1 else None, fused=fused)
+            flt.sync()
+        sa, sb = a.get_state(), b.get_state()
+        assert (a.applied() == b.applied()).all()
+        assert (sa[3] == sb[3]).all()
+        # same device functions, but two separately compiled kernels: fp contraction / association may differ,
+        # so the two fp32 results agree to rounding (compounded over 16 steps), not bit for bit
+        assert state_rel_err(sb[0], sa[0], sa[2])[0] < WINDOW_TOL and cov_rel_err(sb[2], sa[2]) < 1e-5
+        eng = OracleEngine(B, dialect, 18)
+        eng.set_state(nom, rot, P, prev)
+        skip_h = skip.cpu().numpy()
+        for f in range(2):
+            for k in range(K):
+                eng.predict(acc[f * K + k], gyr[f * K + k], DT)
+            ids_h, pos_h, quat_h = frames[f][0].cpu().numpy(), frames[f][1].cpu().numpy().astype(np.float64), frames[f][2].cpu().numpy().astype(np.float64)
+            keep = eng.get_state()
+            ok = eng.correct(ids_h, pos_h, quat_h, mode)
+            if f == 1:                                    # emulate the skip mask on the oracle side
+                now = eng.get_state()
+                for x, y in zip(now[:3], keep[:3]):
+                    x[skip_h == 1] = y[skip_h == 1]
+                now[3][skip_h == 1] = keep[3][skip_h == 1]
+                eng.set_state(*now)
+                ok[skip_h == 1] = 0
+        assert (b.applied() == ok).all()
+        assert state_rel_err(sb[0], eng.nominal, eng.P)[0] < WINDOW_TOL and cov_rel_err(sb[2], eng.P) < COV_TOL
+        # predicts only (M = 0) through the fused entry point
+        b.set_state(nom, rot, P, prev)
+        a.set_state(nom, rot, P, prev)
+        b.frame(d_acc[:K], d_gyr[:K], d_dt, None, None, None, mode, fused=True)
+        a.predict_n(d_acc[:K], d_gyr[:K], d_dt)
+        a.sync(); b.sync()
+        sa, sb = a.get_state(), b.get_state()
+        assert state_rel_err(sb[0], sa[0], sa[2])[0] < STATE_TOL and cov_rel_err(sb[2], sa[2]) < 1e-5
