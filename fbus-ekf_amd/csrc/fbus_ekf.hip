@@ -313,6 +313,136 @@ marker_pose_kernel(int n, int geometry, const T* __restrict__ left, const T* __r
     }
 }
 
+// ---- init / reset / front door (rows f-2, f-4): one filter per lane, element-wise record access -------
+// gravity = (0, 0, -|mean accel|), gyro bias = mean gyro over T samples (accel/gyro T x B x 3).
+// InitGravityAndGyrobias.m:36-40 ; FILTER::InitializeGravityAndBias filter.cpp:256-285
+template <typename T, int N>
+__global__ void init_gravity_bias_kernel(T* __restrict__ recs, int B, int Tn, const T* __restrict__ accel,
+                                         const T* __restrict__ gyro)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    T ma[3] = { T(0), T(0), T(0) }, mg[3] = { T(0), T(0), T(0) };
+    for (int t = 0; t < Tn; ++t) {
+        const size_t o = ((size_t)t * B + b) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ma[i] += accel[o + i]; mg[i] += gyro[o + i]; }
+    }
+    const T inv = T(1) / T(Tn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ma[i] *= inv; recs[elem_index<T, N>(b, L::OFF_BG + i)] = mg[i] * inv; }
+    recs[elem_index<T, N>(b, L::OFF_G + 0)] = T(0);
+    recs[elem_index<T, N>(b, L::OFF_G + 1)] = T(0);
+    recs[elem_index<T, N>(b, L::OFF_G + 2)] = -fb_sqrt(ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]);
+}
+
+// IMU pose from the nearest marker: init / reset / vision-only (what = 0 / 1 / 2).
+// InitPositionAndQuaternion.m:38-80, ResetState.m:37-80, ComputeVisionOnlyResults.m:39-79 ;
+// FILTER::InitializePose filter.cpp:291-399, FILTER::ResetSystemState filter.cpp:405-477
+template <typename T, int N, int DIALECT>
+__global__ void pose_init_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids,
+                                 const T* __restrict__ pos, const T* __restrict__ quat, int what, T max_dist,
+                                 const unsigned char* __restrict__ mask, T* __restrict__ out7,
+                                 unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    applied[b] = 0;
+    if (mask && !mask[b]) return;
+    int mi = -1;
+    T md = T(10);
+    for (int i = 0; i < M; ++i) {
+        if (ids[(size_t)b * M + i] < 0) continue;
+        const T* y = pos + ((size_t)b * M + i) * 3;
+        const T d = fb_sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+        if (d < md) { md = d; mi = i; }
+    }
+    if (mi < 0) return;
+    if (DIALECT == DIALECT_CPP && max_dist > T(0) && md > max_dist) return;     // filter.cpp:343-347,432-436
+    const int id = ids[(size_t)b * M + mi];
+    const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+    if (slot < 0) return;                                                        // filter.cpp:355-359,444-448
+    const T* mk = dc.mk + (size_t)slot * MK_STRIDE;
+    const T* yp = pos + ((size_t)b * M + mi) * 3;
+    const T* yq = quat + ((size_t)b * M + mi) * 4;
+    const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
+    const T qc[4] = { yq[0], -yq[1], -yq[2], -yq[3] };
+    T t4[4], q[4], R[9];
+    quat_mul(Qm, qc, t4);
+    quat_mul(t4, dc.Q_IL, q);                       // Q_IG = Q_MG (x) Q_ML* (x) Q_IL
+    if (what == 2) quat_normalize(q);               // ComputeVisionOnlyResults.m:67
+    if (DIALECT == DIALECT_CPP) quat_to_rotmat_e(q, R); else quat_to_rotmat_m(q, R);
+    T a[3], p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = dc.R_IL[i] * yp[0] + dc.R_IL[3 + i] * yp[1] + dc.R_IL[6 + i] * yp[2];   // R_IL' P_ML
+#pragma unroll
+    for (int i = 0; i < 3; ++i)                     // P_IG = -R_IG R_IL' P_ML + P_MG - R_IG P_IL
+        p[i] = -(R[3 * i] * a[0] + R[3 * i + 1] * a[1] + R[3 * i + 2] * a[2]) + mk[i]
+               - (R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2]);
+    applied[b] = 1;
+    if (what == 2) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out7[(size_t)b * 7 + i] = p[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out7[(size_t)b * 7 + 3 + i] = q[i];
+        return;
+    }
+    auto put = [&](int e, T v) { recs[elem_index<T, N>(b, e)] = v; };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) put(L::OFF_P3 + i, p[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(L::OFF_Q + i, q[i]);
+    if (what == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) put(L::OFF_R + i, R[i]);
+        put(L::OFF_G, T(9.8)); put(L::OFF_G + 1, T(0)); put(L::OFF_G + 2, T(0));   // InitPositionAndQuaternion.m:79
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { put(L::OFF_V + i, T(0)); put(L::OFF_BA + i, T(0)); }
+        if (DIALECT == DIALECT_CPP) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) put(L::OFF_BG + i, T(0));                    // filter.cpp:470 ; rotmatI2G stays stale
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) put(L::OFF_R + i, R[i]);                     // ResetState.m:77
+        }
+    }
+}
+
+// y[t] = 0.9 y[t-1] + 0.1 x[t] per filter over T samples, in place (FILTER::SetImuData filter.cpp:36-47).
+// accel/gyro: T x B x 3; carry: B x 6 previous filtered sample (read if have_carry, always written).
+template <typename T>
+__global__ void imu_ema_kernel(int B, int Tn, T* __restrict__ accel, T* __restrict__ gyro, T* __restrict__ carry,
+                               int have_carry)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const T c = T(0.1);
+    T prev[6];
+    if (have_carry) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) prev[i] = carry[(size_t)b * 6 + i];
+    }
+    for (int t = 0; t < Tn; ++t) {
+        const size_t o = ((size_t)t * B + b) * 3;
+        T x[6] = { accel[o], accel[o + 1], accel[o + 2], gyro[o], gyro[o + 1], gyro[o + 2] };
+        if (t > 0 || have_carry) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = prev[i] * (T(1) - c) + x[i] * c;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { accel[o + i] = x[i]; gyro[o + i] = x[3 + i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) prev[i] = x[i];
+    }
+    if (Tn > 0 && carry) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) carry[(size_t)b * 6 + i] = prev[i];
+    }
+}
+
 // AoS (API arrays) <-> records.  Not on the hot path.
 template <typename T, int N>
 __global__ void pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ nominal,
@@ -468,6 +598,8 @@ struct fbus_ekf {
     void* d_mk = nullptr;
     short* d_id2slot = nullptr;
     unsigned char* d_applied = nullptr;
+    void* d_ema_carry = nullptr;        // B x 6, previous EMA-filtered IMU sample
+    bool ema_has_carry = false;
     // staging for the host-pointer entry points (grown on demand)
     void* stage[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     size_t stage_cap[6] = { 0, 0, 0, 0, 0, 0 };
@@ -732,6 +864,32 @@ int launch_marker_pose_t(fbus_ekf_t h, int n, int geometry, const void* left, co
     return FBUS_OK;
 }
 
+template <typename T, int N>
+int init_gb_t(fbus_ekf_t h, int Tn, const void* accel, const void* gyro)
+{
+    hipLaunchKernelGGL((init_gravity_bias_kernel<T, N>), dim3((h->B + 255) / 256), dim3(256), 0, h->stream, (T*)h->recs,
+                       h->B, Tn, (const T*)accel, (const T*)gyro);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+int do_init_gb(fbus_ekf_t h, int Tn, const void* a, const void* g) { DISPATCH2(h, init_gb_t, h, Tn, a, g); }
+
+template <typename T, int N, int D>
+int pose_init_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
+                const uint8_t* mask, void* out7)
+{
+    hipLaunchKernelGGL((pose_init_kernel<T, N, D>), dim3((h->B + 255) / 256), dim3(256), 0, h->stream, (T*)h->recs, h->B,
+                       M, (const int*)ids, (const T*)pos, (const T*)quat, what, (T)h->prm.max_dist,
+                       (const unsigned char*)mask, (T*)out7, h->d_applied, make_dc<T>(h));
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+int do_pose_init(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
+                 const uint8_t* mask, void* out7)
+{
+    DISPATCH(h, pose_init_t, h, M, ids, pos, quat, what, mask, out7);
+}
+
 int ensure_stage(fbus_ekf_t h, int slot, size_t bytes)
 {
     if (bytes <= h->stage_cap[slot]) return FBUS_OK;
@@ -893,6 +1051,7 @@ int fbus_ekf_destroy(fbus_ekf_t h)
     for (int i = 0; i < 6; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     if (h->own_recs && h->recs) (void)hipFree(h->recs);
     if (h->d_applied) (void)hipFree(h->d_applied);
+    if (h->d_ema_carry) (void)hipFree(h->d_ema_carry);
     if (h->d_mk) (void)hipFree(h->d_mk);
     if (h->d_id2slot) (void)hipFree(h->d_id2slot);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1116,6 +1275,107 @@ int fbus_ekf_marker_pose(fbus_ekf_t h, int n, int geometry, const void* left, co
     HIP_TRY(h, hipMemcpyAsync(pos, h->stage[2], nn * 3 * es, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(quat, h->stage[3], nn * 4 * es, hipMemcpyDeviceToHost, h->stream));
     if (corners3d) HIP_TRY(h, hipMemcpyAsync(corners3d, h->stage[4], nn * 12 * es, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_init_gravity_bias_dev(fbus_ekf_t h, int T, const void* accel, const void* gyro)
+{
+    if (!h || T < 1 || !accel || !gyro) return FBUS_ERR_INVALID;
+    return do_init_gb(h, T, accel, gyro);
+}
+
+int fbus_ekf_init_gravity_bias(fbus_ekf_t h, int T, const void* accel, const void* gyro)
+{
+    if (!h || T < 1 || !accel || !gyro) return FBUS_ERR_INVALID;
+    const size_t bytes = (size_t)T * h->B * 3 * esize(h);
+    const void *da, *dg;
+    int rc;
+    if ((rc = stage_in(h, 0, accel, bytes, &da)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, gyro, bytes, &dg)) != FBUS_OK) return rc;
+    if ((rc = do_init_gb(h, T, da, dg)) != FBUS_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_pose_init_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
+                           const uint8_t* mask)
+{
+    if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (what != FBUS_POSE_INIT && what != FBUS_POSE_RESET) return FBUS_ERR_INVALID;
+    return do_pose_init(h, M, ids, pos, quat, what, mask, nullptr);
+}
+
+int fbus_ekf_vision_only_pose_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat,
+                                  void* out_pose)
+{
+    if (!h || !ids || !pos || !quat || !out_pose || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    return do_pose_init(h, M, ids, pos, quat, 2, nullptr, out_pose);
+}
+
+static int pose_host(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
+                     const uint8_t* mask, void* out_pose)
+{
+    const size_t es = esize(h), B = (size_t)h->B;
+    const void *di, *dp, *dq, *dm;
+    int rc;
+    if ((rc = stage_in(h, 0, ids, B * M * 4, &di)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, pos, B * M * 3 * es, &dp)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 2, quat, B * M * 4 * es, &dq)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 3, mask, B, &dm)) != FBUS_OK) return rc;
+    if (out_pose && (rc = ensure_stage(h, 4, B * 7 * es)) != FBUS_OK) return rc;
+    if (out_pose) HIP_TRY(h, hipMemsetAsync(h->stage[4], 0, B * 7 * es, h->stream));
+    if ((rc = do_pose_init(h, M, (const int32_t*)di, dp, dq, what, (const uint8_t*)dm, out_pose ? h->stage[4] : nullptr)) != FBUS_OK)
+        return rc;
+    if (out_pose) HIP_TRY(h, hipMemcpyAsync(out_pose, h->stage[4], B * 7 * es, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_pose_init(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
+                       const uint8_t* mask)
+{
+    if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (what != FBUS_POSE_INIT && what != FBUS_POSE_RESET) return FBUS_ERR_INVALID;
+    return pose_host(h, M, ids, pos, quat, what, mask, nullptr);
+}
+
+int fbus_ekf_vision_only_pose(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, void* out_pose)
+{
+    if (!h || !ids || !pos || !quat || !out_pose || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    return pose_host(h, M, ids, pos, quat, 2, nullptr, out_pose);
+}
+
+int fbus_ekf_imu_ema_dev(fbus_ekf_t h, int T, void* accel, void* gyro, int restart)
+{
+    if (!h || T < 0 || (T > 0 && (!accel || !gyro))) return FBUS_ERR_INVALID;
+    if (!h->d_ema_carry) HIP_TRY(h, hipMalloc(&h->d_ema_carry, (size_t)h->B * 6 * esize(h)));
+    if (restart) h->ema_has_carry = false;
+    if (T == 0) return FBUS_OK;
+    const int grid = (h->B + 255) / 256;
+    if (h->dtype == 32)
+        hipLaunchKernelGGL((imu_ema_kernel<float>), dim3(grid), dim3(256), 0, h->stream, h->B, T, (float*)accel,
+                           (float*)gyro, (float*)h->d_ema_carry, h->ema_has_carry ? 1 : 0);
+    else
+        hipLaunchKernelGGL((imu_ema_kernel<double>), dim3(grid), dim3(256), 0, h->stream, h->B, T, (double*)accel,
+                           (double*)gyro, (double*)h->d_ema_carry, h->ema_has_carry ? 1 : 0);
+    HIP_TRY(h, hipGetLastError());
+    h->ema_has_carry = true;
+    return FBUS_OK;
+}
+
+int fbus_ekf_imu_ema(fbus_ekf_t h, int T, void* accel, void* gyro, int restart)
+{
+    if (!h || T < 0 || (T > 0 && (!accel || !gyro))) return FBUS_ERR_INVALID;
+    if (T == 0) return fbus_ekf_imu_ema_dev(h, 0, nullptr, nullptr, restart);
+    const size_t bytes = (size_t)T * h->B * 3 * esize(h);
+    const void *da, *dg;
+    int rc;
+    if ((rc = stage_in(h, 0, accel, bytes, &da)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, gyro, bytes, &dg)) != FBUS_OK) return rc;
+    if ((rc = fbus_ekf_imu_ema_dev(h, T, h->stage[0], h->stage[1], restart)) != FBUS_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(accel, h->stage[0], bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(gyro, h->stage[1], bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FBUS_OK;
 }

@@ -10,7 +10,7 @@ creating a filter raises if the library or a HIP device is missing.
 """
 from .capi import (DIALECT_CPP, DIALECT_MATLAB, MODE_NEAREST, MODE_STACKED, COV_SIMPLE, COV_JOSEPH,
                    KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE, KERNEL_FRAME,
-                   VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D,
+                   VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D, POSE_INIT, POSE_RESET,
                    FbusError, FbusParams, default_params, declared_symbols, load_library, library_path)
 from .filter import BatchedFilter
 from . import synth, shard
@@ -18,7 +18,7 @@ from . import synth, shard
 __all__ = [
     "DIALECT_CPP", "DIALECT_MATLAB", "MODE_NEAREST", "MODE_STACKED", "COV_SIMPLE", "COV_JOSEPH",
     "KERNEL_PREDICT", "KERNEL_CORRECT", "KERNEL_PREDICT_N", "KERNEL_MARKER_POSE", "KERNEL_FRAME",
-    "VIS_REFRACTIVE", "VIS_PINHOLE", "VIS_CORNERS3D",
+    "VIS_REFRACTIVE", "VIS_PINHOLE", "VIS_CORNERS3D", "POSE_INIT", "POSE_RESET",
     "FbusError", "FbusParams", "default_params", "declared_symbols", "load_library", "library_path",
     "BatchedFilter", "synth", "shard",
 ]

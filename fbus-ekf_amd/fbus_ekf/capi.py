@@ -12,6 +12,7 @@ MODE_NEAREST, MODE_STACKED = 0, 1
 COV_SIMPLE, COV_JOSEPH = 0, 1
 KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE, KERNEL_FRAME = 0, 1, 2, 3, 4
 VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D = 0, 1, 2
+POSE_INIT, POSE_RESET = 0, 1
 MAX_MARKERS, MAX_VISIBLE = 32, 16
 
 
@@ -93,6 +94,14 @@ def load_library():
         "fbus_ekf_get_applied": ([H, u8p], C.c_int),
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_init_gravity_bias": ([H, C.c_int, vp, vp], C.c_int),
+        "fbus_ekf_init_gravity_bias_dev": ([H, C.c_int, vp, vp], C.c_int),
+        "fbus_ekf_pose_init": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_pose_init_dev": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_vision_only_pose": ([H, C.c_int, ip, vp, vp, vp], C.c_int),
+        "fbus_ekf_vision_only_pose_dev": ([H, C.c_int, ip, vp, vp, vp], C.c_int),
+        "fbus_ekf_imu_ema": ([H, C.c_int, vp, vp, C.c_int], C.c_int),
+        "fbus_ekf_imu_ema_dev": ([H, C.c_int, vp, vp, C.c_int], C.c_int),
         "fbus_ekf_marker_pose": ([H, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "fbus_ekf_marker_pose_dev": ([H, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "fbus_ekf_timing_enable": ([H, C.c_int], C.c_int),

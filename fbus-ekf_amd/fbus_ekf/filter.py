@@ -195,6 +195,42 @@ class BatchedFilter:
                                           self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
         self._check(rc, "frame_dev")
 
+    # ---- init / reset / front door (host arrays) --------------------------------------------
+    def init_gravity_bias(self, accel, gyro):
+        """InitGravityAndGyrobias.m:36-40: accel, gyro (T, B, 3) -> g, bg of every filter."""
+        accel = np.ascontiguousarray(accel, self.np_dtype)
+        T = accel.size // (3 * self.B)
+        gyro = self._host(gyro, (T, self.B, 3))
+        self._check(self._lib.fbus_ekf_init_gravity_bias(self._h, T, self._p(accel), self._p(gyro)), "init_gravity_bias")
+
+    def pose_init(self, ids, pos, quat, what=capi.POSE_INIT, mask=None):
+        """InitPositionAndQuaternion.m / ResetState.m (what = POSE_INIT / POSE_RESET) from the nearest marker."""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(self.B, -1)
+        M = ids.shape[1]
+        pos = self._host(pos, (self.B, M, 3)); quat = self._host(quat, (self.B, M, 4))
+        mask = None if mask is None else self._host(mask, (self.B,), np.uint8)
+        rc = self._lib.fbus_ekf_pose_init(self._h, M, self._p(ids), self._p(pos), self._p(quat), what, self._p(mask))
+        self._check(rc, "pose_init")
+
+    def vision_only_pose(self, ids, pos, quat):
+        """ComputeVisionOnlyResults.m:39-79 -> (B, 7) [p3, q4]; the state is not touched."""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(self.B, -1)
+        M = ids.shape[1]
+        pos = self._host(pos, (self.B, M, 3)); quat = self._host(quat, (self.B, M, 4))
+        out = np.zeros((self.B, 7), self.np_dtype)
+        rc = self._lib.fbus_ekf_vision_only_pose(self._h, M, self._p(ids), self._p(pos), self._p(quat), self._p(out))
+        self._check(rc, "vision_only_pose")
+        return out
+
+    def imu_ema(self, accel, gyro, restart=False):
+        """IMU pre-filter of FILTER::SetImuData (filter.cpp:36-47); returns filtered copies (T, B, 3)."""
+        accel = np.array(accel, self.np_dtype, order="C", copy=True)
+        gyro = np.array(gyro, self.np_dtype, order="C", copy=True)
+        T = accel.size // (3 * self.B)
+        rc = self._lib.fbus_ekf_imu_ema(self._h, T, self._p(accel), self._p(gyro), 1 if restart else 0)
+        self._check(rc, "imu_ema")
+        return accel.reshape(T, self.B, 3), gyro.reshape(T, self.B, 3)
+
     # ---- marker pose from stereo corners (vision.cpp:472-759) ---------------------------
     def marker_pose(self, left, right=None, geometry=capi.VIS_REFRACTIVE, want_corners=False):
         """left/right: (n, 8) normalised corner coordinates (or left = (n, 12) 3-D corners with

@@ -157,6 +157,39 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
 int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                              int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
 
+/* ---- initialisation / reset (the callers' side of the path) ------------------- */
+/* Replaces: InitGravityAndGyrobias (matlab/InitGravityAndGyrobias.m:36-40) /
+ * FILTER::InitializeGravityAndBias (filter.cpp:256-285).  accel, gyro: T x B x 3.
+ * Writes g = (0, 0, -|mean accel|) and bg = mean gyro of every filter. */
+int fbus_ekf_init_gravity_bias(fbus_ekf_t h, int T, const void* accel, const void* gyro);
+int fbus_ekf_init_gravity_bias_dev(fbus_ekf_t h, int T, const void* accel, const void* gyro);
+/* Replaces: InitPositionAndQuaternion (matlab/InitPositionAndQuaternion.m:38-80) /
+ * FILTER::InitializePose (filter.cpp:291-399) [FBUS_POSE_INIT: p, q, R from the nearest
+ * marker, g = (9.8, 0, 0)] and ResetState (matlab/ResetState.m:37-80) /
+ * FILTER::ResetSystemState (filter.cpp:405-477) [FBUS_POSE_RESET: p, q, v = 0, ba = 0;
+ * Matlab dialect also refreshes R, C++ dialect also zeroes bg and leaves R stale].
+ * mask (B bytes, may be NULL = all): non-zero selects the filters to (re)initialise.
+ * C++ dialect: markers farther than params.max_dist are refused (filter.cpp:343-347).
+ * fbus_ekf_get_applied() tells which filters were changed. */
+enum { FBUS_POSE_INIT = 0, FBUS_POSE_RESET = 1 };
+int fbus_ekf_pose_init(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
+                       const uint8_t* mask);
+int fbus_ekf_pose_init_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
+                           const uint8_t* mask);
+/* Replaces: ComputeVisionOnlyResults (matlab/ComputeVisionOnlyResults.m:39-79) /
+ * positionOnlyVisual, quaternionOnlyVisual (filter.cpp:449-456).  out_pose: B x 7 (p3, q4 wxyz);
+ * the state is not touched. */
+int fbus_ekf_vision_only_pose(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat,
+                              void* out_pose);
+int fbus_ekf_vision_only_pose_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat,
+                                  void* out_pose);
+/* Replaces: the IMU pre-filter of FILTER::SetImuData (filter.cpp:36-47):
+ * y[t] = 0.9 y[t-1] + 0.1 x[t] per filter, in place on T x B x 3 accel / gyro arrays; the last
+ * filtered sample is carried in the handle to the next call (restart != 0 forgets it: the next
+ * sample passes through, as the first buffered sample does in the reference). */
+int fbus_ekf_imu_ema(fbus_ekf_t h, int T, void* accel, void* gyro, int restart);
+int fbus_ekf_imu_ema_dev(fbus_ekf_t h, int T, void* accel, void* gyro, int restart);
+
 /* ---- marker pose from stereo corners (the step in front of correct) --------- */
 /* Replaces: VISION::RefractionTriangulation (C++/src/vision.cpp:472-618) or
  * VISION::NormalTriangulation (:395-466) followed by VISION::ComputeMarkerPose

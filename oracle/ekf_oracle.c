@@ -727,3 +727,120 @@ void fbo_frame_batch(int B, double* nominal, double* rot, double* P, int* prev,
     j.M = M; j.ids = ids; j.pos = pos; j.quat = quat; j.mode = mode;
     run_batch(&j, B, nthreads);
 }
+
+/* ------------------------------------------------------------------ */
+/* init / reset                          */
+/* ------------------------------------------------------------------ */
+void fbo_init_gravity_bias(int T, const double* accel /*T x 3*/, const double* gyro /*T x 3*/,
+                           double g[3], double bg[3])
+{   /* InitGravityAndGyrobias.m:36-40 ; filter.cpp:263-276 */
+    double ma[3] = { 0, 0, 0 }, mg[3] = { 0, 0, 0 };
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < 3; ++i) { ma[i] += accel[3 * t + i]; mg[i] += gyro[3 * t + i]; }
+    for (int i = 0; i < 3; ++i) { ma[i] /= T; bg[i] = mg[i] / T; }
+    g[0] = 0; g[1] = 0; g[2] = -norm3(ma);
+}
+
+/* nearest marker, start threshold 10; -1 if none (shared by init / reset / vision-only) */
+static int nearest_marker(int M, const int* ids, const double* pos, double* dist)
+{
+    int mi = -1;
+    double md = 10.0;
+    for (int i = 0; i < M; ++i) {
+        if (ids[i] < 0) continue;
+        double d = norm3(pos + 3 * i);
+        if (d < md) { md = d; mi = i; }
+    }
+    *dist = md;
+    return mi;
+}
+
+/* IMU pose from one marker measurement:
+ * Q_IG = Q_MG (x) Q_ML* (x) Q_IL ; P_IG = -R_IG R_IL' P_ML + P_MG - R_IG P_IL
+ * (InitPositionAndQuaternion.m:63-72, ResetState.m:63-72, ComputeVisionOnlyResults.m:64-73,
+ *  filter.cpp:374-384,449-456).  normalise = ComputeVisionOnlyResults.m:67 only. */
+static void pose_from_marker(const fbo_params* prm, int slot, const double* yp, const double* yq,
+                             int normalise, double p[3], double q[4], double R[9])
+{
+    double qc[4] = { yq[0], -yq[1], -yq[2], -yq[3] }, t[4];
+    fbo_quat_mul(prm->marker_quat[slot], qc, t);
+    fbo_quat_mul(t, prm->Q_IL, q);
+    if (normalise) { double n = norm4(q); for (int i = 0; i < 4; ++i) q[i] /= n; }
+    if (prm->dialect == FBO_DIALECT_CPP) fbo_quat_to_rotmat_eigen(q, R);
+    else fbo_quat_to_rotmat(q, R);
+    double a[3], b[3], c[3];
+    mat3t_vec(prm->R_IL, yp, a);            /* R_IL' P_ML */
+    mat3_vec(R, a, b);
+    mat3_vec(R, prm->P_IL, c);
+    for (int i = 0; i < 3; ++i) p[i] = -b[i] + prm->marker_pos[slot][i] - c[i];
+}
+
+/* what: 0 = init (InitPositionAndQuaternion.m:38-80 / FILTER::InitializePose filter.cpp:291-399),
+ *       1 = reset (ResetState.m:37-80 / FILTER::ResetSystemState filter.cpp:405-477),
+ *       2 = vision-only pose into out7 = [p3 q4], state untouched (ComputeVisionOnlyResults.m:39-79).
+ * max_dist <= 0 disables the C++ range check (filter.cpp:343-347,432-436).  Returns 1 if applied. */
+int fbo_pose_init(fbo_state* s, const fbo_params* prm, int M, const int* ids, const double* pos,
+                  const double* quat, int what, double max_dist, double* out7)
+{
+    double dist;
+    int mi = nearest_marker(M, ids, pos, &dist);
+    if (mi < 0) return 0;
+    if (prm->dialect == FBO_DIALECT_CPP && max_dist > 0 && dist > max_dist) return 0;
+    int slot = find_marker(prm, ids[mi]);
+    if (slot < 0) return 0;
+    double p[3], q[4], R[9];
+    pose_from_marker(prm, slot, pos + 3 * mi, quat + 4 * mi, what == 2, p, q, R);
+    if (what == 2) {
+        memcpy(out7, p, sizeof(p));
+        memcpy(out7 + 3, q, sizeof(q));
+        return 1;
+    }
+    memcpy(s->p, p, sizeof(p));
+    memcpy(s->q, q, sizeof(q));
+    if (what == 0) {
+        memcpy(s->R, R, sizeof(R));
+        s->g[0] = 9.8; s->g[1] = 0; s->g[2] = 0;           /* InitPositionAndQuaternion.m:79 ; filter.cpp:387 */
+    } else {
+        for (int i = 0; i < 3; ++i) { s->v[i] = 0; s->ba[i] = 0; }
+        if (prm->dialect == FBO_DIALECT_CPP) for (int i = 0; i < 3; ++i) s->bg[i] = 0;   /* filter.cpp:470 */
+        else memcpy(s->R, R, sizeof(R));                    /* ResetState.m:77 ; C++ leaves rotmatI2G stale */
+    }
+    return 1;
+}
+
+void fbo_pose_init_batch(int B, double* nominal, double* rot, const fbo_params* prm, int M, const int* ids,
+                         const double* pos, const double* quat, int what, double max_dist,
+                         const unsigned char* mask, double* out7, int* applied)
+{
+    fbo_state s;
+    for (int b = 0; b < B; ++b) {
+        if (applied) applied[b] = 0;
+        if (mask && !mask[b]) continue;
+        memset(&s, 0, sizeof(s));
+        load_state(&s, prm->nstate, nominal + 19 * (size_t)b, rot + 9 * (size_t)b, s.P, 0);
+        int ok = fbo_pose_init(&s, prm, M, ids + (size_t)M * b, pos + 3 * (size_t)M * b, quat + 4 * (size_t)M * b,
+                               what, max_dist, out7 ? out7 + 7 * (size_t)b : 0);
+        if (applied) applied[b] = ok;
+        if (what != 2) {
+            double Pd[FBO_NMAX * FBO_NMAX];
+            int prev;
+            store_state(&s, prm->nstate, nominal + 19 * (size_t)b, rot + 9 * (size_t)b, Pd, &prev);
+        }
+    }
+}
+
+/* IMU pre-filter of the live pipeline: y[t] = 0.9 y[t-1] + 0.1 x[t], first sample passed through
+ * (FILTER::SetImuData, filter.cpp:36-47).  x: T x 6 (accel, gyro), carry: previous filtered sample or
+ * NULL at stream start; in place. */
+void fbo_imu_ema(int T, double* x, double* carry, int have_carry)
+{
+    const double c = 0.1;
+    double prev[6];
+    if (have_carry) memcpy(prev, carry, sizeof(prev));
+    for (int t = 0; t < T; ++t) {
+        if (t > 0 || have_carry)
+            for (int i = 0; i < 6; ++i) x[6 * t + i] = prev[i] * (1 - c) + x[6 * t + i] * c;
+        memcpy(prev, x + 6 * t, sizeof(prev));
+    }
+    if (T > 0 && carry) memcpy(carry, prev, sizeof(prev));
+}

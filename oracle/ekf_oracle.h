@@ -106,6 +106,15 @@ void fbo_correct_batch(int B, double* nominal, double* rot, double* P, int* prev
                        const fbo_params* prm, int M, const int* ids, const double* pos,
                        const double* quat, int mode, int* applied, int nthreads);
 
+/* ---- init / reset / front door ---- */
+void fbo_init_gravity_bias(int T, const double* accel, const double* gyro, double g[3], double bg[3]);
+int  fbo_pose_init(fbo_state* s, const fbo_params* prm, int M, const int* ids, const double* pos,
+                   const double* quat, int what, double max_dist, double* out7);
+void fbo_pose_init_batch(int B, double* nominal, double* rot, const fbo_params* prm, int M, const int* ids,
+                         const double* pos, const double* quat, int what, double max_dist,
+                         const unsigned char* mask, double* out7, int* applied);
+void fbo_imu_ema(int T, double* x, double* carry, int have_carry);
+
 /* one camera frame per thread range: K predicts (accel/gyro K x B x 3, dt K values)
  * followed by one correct; threads are spawned once per call (CPU-baseline driver). */
 void fbo_frame_batch(int B, double* nominal, double* rot, double* P, int* prev,

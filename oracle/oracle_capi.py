@@ -66,6 +66,11 @@ def load(native=False):
                                       C.c_int, ip, C.c_int]
     lib.fbo_frame_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, dp, dp, dp, C.c_int,
                                     ip, dp, dp, C.c_int, C.c_int]
+    u8 = C.POINTER(C.c_ubyte)
+    lib.fbo_init_gravity_bias.argtypes = [C.c_int, dp, dp, dp, dp]
+    lib.fbo_pose_init_batch.argtypes = [C.c_int, dp, dp, C.POINTER(FboParams), C.c_int, ip, dp, dp, C.c_int, C.c_double,
+                                        u8, dp, ip]
+    lib.fbo_imu_ema.argtypes = [C.c_int, dp, dp, C.c_int]
     lib.fbv_default_params.argtypes = [C.POINTER(FbvParams)]
     lib.fbv_refraction_triangulate.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
     lib.fbv_normal_triangulate.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
@@ -136,6 +141,39 @@ class Oracle:
         quat = np.ascontiguousarray(quat, np.float64)
         self.lib.fbo_frame_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), K, _dp(accel),
                                  _dp(gyro), _dp(dt), M, _ip(ids), _dp(pos), _dp(quat), mode, self.nthreads)
+
+
+    def pose_init(self, nominal, rot, ids, pos, quat, what, max_dist=2.0, mask=None):
+        """what 0 init / 1 reset / 2 vision-only (returns out7); modifies nominal/rot in place for 0/1."""
+        B = nominal.shape[0]
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        pos = np.ascontiguousarray(pos, np.float64); quat = np.ascontiguousarray(quat, np.float64)
+        out7 = np.zeros((B, 7))
+        applied = np.zeros(B, np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.lib.fbo_pose_init_batch(B, _dp(nominal), _dp(rot), C.byref(self.prm), M, _ip(ids), _dp(pos), _dp(quat),
+                                     what, max_dist, None if m is None else m.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                     _dp(out7), _ip(applied))
+        return applied, out7
+
+
+def init_gravity_bias(accel, gyro):
+    """accel, gyro (T, 3) of ONE filter -> g, bg"""
+    lib = load()
+    a = np.ascontiguousarray(accel, np.float64); w = np.ascontiguousarray(gyro, np.float64)
+    g, bg = np.zeros(3), np.zeros(3)
+    lib.fbo_init_gravity_bias(a.shape[0], _dp(a), _dp(w), _dp(g), _dp(bg))
+    return g, bg
+
+
+def imu_ema(x6, carry=None):
+    """x6 (T, 6) of ONE filter, filtered copy; carry (6,) previous filtered sample or None"""
+    lib = load()
+    x = np.array(x6, np.float64, order="C", copy=True)
+    c = np.zeros(6) if carry is None else np.array(carry, np.float64, copy=True)
+    lib.fbo_imu_ema(x.shape[0], _dp(x), _dp(c), 0 if carry is None else 1)
+    return x, c
 
 
 def vision_params():

@@ -1,0 +1,151 @@
+"""Rows f-2 / f-4: gravity+bias init, pose init / reset / vision-only pose, IMU EMA pre-filter.
+CPU part: the C oracle against the independent host implementation in fbus_ekf/replay.py and closed forms.
+GPU part (-m gpu): the HIP kernels through the C ABI against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_capi as oc
+from fbus_ekf import capi, replay, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _meas(B, M, dialect, seed=0):
+    prm = capi.default_params(dialect)
+    nom, rot, P, prev = synth.initial_state(seed, seed + B, list(prm.p0_diag), 18)
+    ids, pos, quat = synth.marker_frame(seed, seed + B, 0, M, nom, prm)
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    return prm, r32(nom), r32(rot), ids, r32(pos), r32(quat)
+
+
+# ------------------------------------------------------------------ CPU
+def test_oracle_gravity_bias_is_the_mean_of_the_first_rows():
+    d = np.load(os.path.join(GOLD, "land_slice.npz"))["imu"][:500]
+    g, bg = oc.init_gravity_bias(d[:, 1:4], d[:, 4:7])
+    g2, bg2 = replay.init_gravity_gyrobias(d)
+    assert np.allclose(g, g2, atol=1e-13) and np.allclose(bg, bg2, atol=1e-16)
+    assert g[0] == 0 and g[1] == 0 and abs(-g[2] - 9.8) < 0.05
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_oracle_pose_init_matches_host_replay_and_inverts_the_measurement_model(dialect):
+    B, M = 64, 3
+    prm, nom, rot, ids, pos, quat = _meas(B, M, dialect)
+    orc = oc.Oracle(dialect, 18)
+    n2, r2 = nom.copy(), rot.copy()
+    n2[:, 0:3] += 0.3                                   # wrong pose before init
+    ok, _ = orc.pose_init(n2, r2, ids, pos, quat, 0, 0.0)      # 0.0: no range check (markers up to 4 m away)
+    assert ok.all()
+    for b in range(B):
+        k = replay.nearest(np.concatenate([ids[b][:, None], pos[b], quat[b]], axis=1))
+        p, q, R = replay.pose_from_marker(np.concatenate([[ids[b, k]], pos[b, k], quat[b, k]]), prm)
+        # C++ dialect: Eigen's toRotationMatrix (1 - 2(y^2+z^2)) vs the Matlab formula in replay.py differ by the
+        # non-unit part of the fp32-rounded measurement quaternion (~1e-7)
+        tol = 1e-12 if dialect == 0 else 1e-6
+        assert np.abs(n2[b, 0:3] - p).max() < tol and np.abs(n2[b, 6:10] - q).max() < 1e-12
+        assert np.abs(r2[b].reshape(3, 3) - R).max() < tol
+    # the synthetic measurement is h(x0) + 1e-3 noise, so init must land on x0
+    assert np.abs(n2[:, 0:3] - nom[:, 0:3]).max() < 2e-2
+    assert (n2[:, 16:19] == [9.8, 0, 0]).all()
+    # reset: v, ba zeroed; C++ also zeroes bg and leaves R stale, Matlab refreshes R
+    n3, r3 = nom.copy(), rot.copy() * 0 + 7.0
+    ok, _ = orc.pose_init(n3, r3, ids, pos, quat, 1, 0.0)
+    assert (n3[:, 3:6] == 0).all() and (n3[:, 10:13] == 0).all()
+    if dialect == 1:
+        assert (n3[:, 13:16] == 0).all() and (r3 == 7.0).all()
+    else:
+        assert (n3[:, 13:16] == nom[:, 13:16]).all() and np.abs(r3 - r2).max() < 1e-12
+    # vision-only: normalised quaternion, state untouched
+    n4, r4 = nom.copy(), rot.copy()
+    ok, out7 = orc.pose_init(n4, r4, ids, pos, quat, 2, 0.0)
+    assert np.array_equal(n4, nom) and np.abs(np.linalg.norm(out7[:, 3:], axis=1) - 1).max() < 1e-14
+    assert np.abs(out7[:, :3] - n2[:, 0:3]).max() < 1e-6
+
+
+def test_oracle_pose_init_refuses_far_and_unknown_markers():
+    B, M = 8, 2
+    prm, nom, rot, ids, pos, quat = _meas(B, M, 1)
+    orc = oc.Oracle(1, 18)
+    pos2 = pos / np.linalg.norm(pos, axis=2, keepdims=True)      # every marker at 1 m: inside marker_max_dist
+    pos2[0] *= 100.0                  # beyond both max_dist and the 10 m threshold
+    pos2[1] = pos[1] / np.linalg.norm(pos[1], axis=1, keepdims=True) * 3.0   # 3 m > marker_max_dist 2
+    ids2 = ids.copy(); ids2[2] = 9
+    mask = np.ones(B, np.uint8); mask[3] = 0
+    n2, r2 = nom.copy(), rot.copy()
+    ok, _ = orc.pose_init(n2, r2, ids2, pos2, quat, 0, 2.0, mask)
+    assert list(ok[:4]) == [0, 0, 0, 0] and ok[4:].all()
+    assert np.array_equal(n2[:4], nom[:4])
+    assert oc.Oracle(0, 18).pose_init(nom.copy(), rot.copy(), ids, pos2, quat, 0, 2.0)[0][1] == 1   # Matlab: no range check
+
+
+def test_oracle_ema_matches_the_recurrence_and_carries_across_calls():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(50, 6))
+    y, c = oc.imu_ema(x)
+    ref = x.copy()
+    for t in range(1, 50):
+        ref[t] = 0.9 * ref[t - 1] + 0.1 * x[t]
+    assert np.abs(y - ref).max() < 1e-15 and np.array_equal(c, y[-1])
+    y1, c1 = oc.imu_ema(x[:20])
+    y2, _ = oc.imu_ema(x[20:], c1)
+    assert np.abs(np.concatenate([y1, y2]) - ref).max() < 1e-15
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(64, 1e-12), (32, 2e-6)])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_gpu_init_reset_vision_only(dialect, dtype, tol):
+    from fbus_ekf import BatchedFilter
+    B, M = 300, 3
+    prm, nom, rot, ids, pos, quat = _meas(B, M, dialect, seed=2000)
+    ids[0] = -1
+    ids[1] = 9
+    pos[2] = pos[2] / np.linalg.norm(pos[2], axis=1, keepdims=True) * 3.0
+    mask = (np.arange(B) % 5 != 4).astype(np.uint8)
+    P = np.broadcast_to(np.eye(18), (B, 18, 18)).copy()
+    prev = np.zeros(B, np.int32)
+    orc = oc.Oracle(dialect, 18)
+    for what in (0, 1):
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            flt.set_state(nom, rot, P, prev)
+            flt.pose_init(ids, pos, quat, what, mask)
+            g_nom, g_rot, _, _ = flt.get_state()
+            ap = flt.applied()
+        o_nom, o_rot = nom.copy(), rot.copy()
+        ok, _ = orc.pose_init(o_nom, o_rot, ids, pos, quat, what, 2.0, mask)
+        assert (ap == ok).all()
+        assert np.abs(g_nom - o_nom).max() < tol * 10 and np.abs(g_rot - o_rot).max() < tol * 10
+    with BatchedFilter(B, prm, dtype=dtype) as flt:
+        flt.set_state(nom, rot, P, prev)
+        out = flt.vision_only_pose(ids, pos, quat)
+        assert np.array_equal(flt.get_state()[0], nom.astype(flt.np_dtype))
+    ok, o7 = orc.pose_init(nom.copy(), rot.copy(), ids, pos, quat, 2)
+    assert np.abs(out[ok == 1] - o7[ok == 1]).max() < tol * 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(64, 1e-13), (32, 2e-6)])
+def test_gpu_gravity_bias_and_ema(dtype, tol):
+    from fbus_ekf import BatchedFilter
+    B, T = 200, 64
+    prm = capi.default_params(0)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18)
+    acc, gyr = synth.imu_samples(0, B, 0, T, nom)
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    acc, gyr = r32(acc), r32(gyr)
+    with BatchedFilter(B, prm, dtype=dtype) as flt:
+        flt.set_state(nom, rot, P, prev)
+        flt.init_gravity_bias(acc, gyr)
+        g_nom = flt.get_state()[0]
+        fa1, fg1 = flt.imu_ema(acc[:24], gyr[:24], restart=True)
+        fa2, fg2 = flt.imu_ema(acc[24:], gyr[24:])
+    for b in (0, 57, B - 1):
+        g, bg = oc.init_gravity_bias(acc[:, b], gyr[:, b])
+        assert np.abs(g_nom[b, 16:19] - g).max() < tol * 10 and np.abs(g_nom[b, 13:16] - bg).max() < tol
+        y, _ = oc.imu_ema(np.concatenate([acc[:, b], gyr[:, b]], axis=1))
+        got = np.concatenate([np.concatenate([fa1[:, b], fa2[:, b]]), np.concatenate([fg1[:, b], fg2[:, b]])], axis=1)
+        assert np.abs(got - y).max() < tol * 10
+    assert np.array_equal(g_nom[:, :13], nom[:, :13].astype(g_nom.dtype))      # only bg and g were written
