@@ -6,9 +6,10 @@ BatchedFilter interface (set_state / get_state / predict / correct) with B = 1.
 File formats: SURVEY.md App. C (imu.txt `t ax ay az gx gy gz`, image.txt
 `t id px py pz qw qx qy qz`).
 
-The one-off initialisation (InitGravityAndGyrobias.m:36-40,
-InitPositionAndQuaternion.m:38-80, ResetState.m:37-80) is a handful of 3-vector
-operations per run and is done here on the host, as in the reference.
+The initialisation (InitGravityAndGyrobias.m:36-40, InitPositionAndQuaternion.m:38-80)
+and the reset after a vision gap (ResetState.m:37-80) are engine calls too
+(`init_gravity_bias`, `pose_init`): HIP kernels for BatchedFilter.  The small numpy
+helpers below restate the same formulas for the tests.
 """
 import numpy as np
 
@@ -49,14 +50,13 @@ def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
     imu = np.asarray(imu, float)
     image = np.asarray(image, float)
     N = engine.N
-    g0, bg0 = init_gravity_gyrobias(imu[:500])                      # FBUS_EKF.m:118
-    meas0 = image[0:1, 1:9]
-    p, q, R = pose_from_marker(meas0[nearest(meas0)], params)       # FBUS_EKF.m:124-132
-    nominal = np.zeros((1, 19))
-    nominal[0, 0:3], nominal[0, 6:10], nominal[0, 13:16] = p, q, bg0
-    nominal[0, 16:19] = [9.8, 0.0, 0.0]                             # InitPositionAndQuaternion.m:79
     P0 = np.diag(np.repeat(np.array(list(params.p0_diag)), 3)[:N])[None]
-    engine.set_state(nominal, R.reshape(1, 9), P0, np.zeros(1, np.int32))
+    engine.set_state(np.zeros((1, 19)), np.zeros((1, 9)), P0, np.zeros(1, np.int32))
+    # FBUS_EKF.m:118 (gravity, gyro bias from the first 500 IMU rows) and :124-132 (pose from the first frame):
+    # both run inside the engine (device kernels for BatchedFilter)
+    engine.init_gravity_bias(imu[:500, None, 1:4], imu[:500, None, 4:7])
+    meas0 = image[0:1, 1:9]
+    engine.pose_init(meas0[:, 0].astype(np.int32)[None], meas0[None, :, 1:4], meas0[None, :, 4:8], 0)
     idx = int(np.argmax(imu[:, 0] > image[0, 0]))
     pre_img, n_img = 0.0, 0
     out, npred = [], []
@@ -69,12 +69,7 @@ def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
         n_img = j
         cnt = 0
         if cur - pre_img > 0.1 and pre_img != 0 and matlab_reset:   # FBUS_EKF.m:168-171, ResetState.m:75-79
-            nominal, rot, P, prev = engine.get_state()
-            p, q, R = pose_from_marker(meas[nearest(meas)], params)
-            nominal[0, 0:3], nominal[0, 6:10] = p, q
-            nominal[0, 3:6] = 0
-            nominal[0, 10:13] = 0
-            engine.set_state(nominal, R.reshape(1, 9), None, None)
+            engine.pose_init(meas[:, 0].astype(np.int32)[None], meas[None, :, 1:4], meas[None, :, 4:8], 1)
             pre_img = cur
         else:
             pre_imu = imu[idx - 1, 0]                               # FBUS_EKF.m:175-191

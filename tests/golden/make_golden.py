@@ -56,7 +56,7 @@ def replay(imu, img, dialect, nframes):
     mid, yp, yq = int(img[0, 1]), img[0, 2:5], img[0, 5:9]
     Pm, Qm = prm.markers[mid]
     Q_IG = onp.qmul(onp.qmul(Qm, yq * np.array([1, -1, -1, -1.0])), prm.Q_IL)
-    R_IG = onp.q2R(Q_IG)
+    R_IG = onp.q2R(Q_IG) if dialect == onp.MATLAB else onp.q2R_eigen(Q_IG)   # filter.cpp:383 toRotationMatrix
     s.q, s.R = Q_IG, R_IG
     s.p = -R_IG @ prm.R_IL.T @ yp + Pm - R_IG @ prm.P_IL
     s.g = np.array([9.8, 0, 0])

@@ -30,6 +30,16 @@ class OracleEngine:
                          np.asarray(accel, float).reshape(self.B, 3), np.asarray(gyro, float).reshape(self.B, 3),
                          np.asarray(dt, float))
 
+    def init_gravity_bias(self, accel, gyro):
+        accel = np.asarray(accel, float).reshape(-1, self.B, 3)
+        gyro = np.asarray(gyro, float).reshape(-1, self.B, 3)
+        for b in range(self.B):
+            g, bg = oc.init_gravity_bias(accel[:, b], gyro[:, b])
+            self.nominal[b, 16:19], self.nominal[b, 13:16] = g, bg
+
+    def pose_init(self, ids, pos, quat, what=0, mask=None):
+        return self.orc.pose_init(self.nominal, self.rot, ids, pos, quat, what, 2.0, mask)[0]
+
     def correct(self, ids, pos, quat, mode=0, skip=None):
         return self.orc.correct(self.nominal, self.rot, self.P, self.prev, ids, pos, quat, mode)
 
