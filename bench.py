@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PREDICT_BYTES = 2 * 796 + 28        # packed record round trip + IMU sample
 CORRECT_BYTES_M4 = 2 * 796 + 32 * 4
 POOL = 4                            # distinct bench steps of input data resident in HBM, cycled
+TIMING_STRIDE = 4                   # HIP-event brackets on every 4th camera frame of the timed region
 
 
 def parse():
@@ -51,6 +52,22 @@ def parse():
     ap.add_argument("--kernel-timing", choices=["on", "off"], default="on",
                     help="bracket every launch with HIP events inside the timed region (feeds `roofline`)")
     return ap.parse_args()
+
+
+def pmc_traffic(kernel_prefix="predict_kernel<float, 18"):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_digest.json, written by tools/profile_digest.py: separate FETCH_SIZE / WRITE_SIZE
+    passes, KiB units, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  bench.py cannot
+    collect PMC counters itself; None if the digest is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_digest.json")
+    try:
+        d = json.load(open(path))
+        for name, v in d.items():
+            if name.startswith(kernel_prefix) and "fetch_bytes" in v:
+                return v["fetch_bytes"] + v["write_bytes"], os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_baseline(args, prm_dialect, seconds):
@@ -147,7 +164,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    flt.timing_enable(args.kernel_timing == "on")
+    flt.timing_enable(args.kernel_timing == "on", stride=TIMING_STRIDE)
     for i in range(args.warmup):
         bench_step(i)
     torch.cuda.synchronize()
@@ -206,6 +223,7 @@ def main():
         pred_avg_ms = pred_ms / max(pred_n, 1) if pred_n else float("nan")
         corr_ms = corr_ms if corr_n else float("nan")
         achieved = PREDICT_BYTES * B / (pred_avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic() if (B == 65536 and world == 1) else (None, None)
         out = {
             "metric": "EKF steps/s (ImuUpdate+MeasureUpdate), batch=65536, 4 markers",
             "value": value, "unit": "EKF steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,7 +235,8 @@ def main():
                        "batch_per_gpu": B, "markers": M, "ekf_steps_per_bench_step": STEPS_PER_BENCH_STEP,
                        "parallelism": f"independent filter shards x{world}, one RCCL gather at the end"},
             "roofline": {"bound": "hbm", "kernel": "predict_kernel<float,18>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "avg_launch_us": pred_avg_ms * 1e3, "launches": pred_n,
                          "algorithmic_bytes_per_launch": PREDICT_BYTES * B},
             "correct_kernel": {"avg_launch_us": corr_ms / max(corr_n, 1) * 1e3, "launches": corr_n,

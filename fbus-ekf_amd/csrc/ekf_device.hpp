@@ -64,11 +64,39 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float>  { using type = float4;  };
 template <> struct Vec16<double> { using type = double2; };
 
+// Packed storage order of the upper triangle.
+//  odd N : plain row-major upper triangle.
+//  even N: "pair-aligned rows" -- every row is stored from an EVEN column on, so that (P(i,c), P(i,c+1)),
+//          c even, are neighbours at an even offset and one v_pk_fma_f32 updates both: even rows start at
+//          their diagonal, odd rows at column i+1, and the N/2 diagonal elements of the odd rows are
+//          collected at the end.  Still exactly N(N+1)/2 elements, no duplicates.
 template <int N>
-__host__ __device__ constexpr int pidx(int i, int j)
+__host__ __device__ constexpr int pair_cols(int i) { return (i & 1) ? (N - i - 1) : (N - i); }
+template <int N>
+__host__ __device__ constexpr int row_base(int i)
 {
-    return (i <= j) ? (i * N - (i * (i - 1)) / 2 + (j - i)) : (j * N - (j * (j - 1)) / 2 + (i - j));
+    int s = 0;
+    for (int r = 0; r < i; ++r) s += pair_cols<N>(r);
+    return s;
 }
+template <int N>
+__host__ __device__ constexpr int pidx_ord(int i, int j)        // i <= j
+{
+    if (N % 2) return i * N - (i * (i - 1)) / 2 + (j - i);
+    if ((i & 1) && j == i) return (N * (N + 1) / 2 - N / 2) + (i - 1) / 2;
+    return row_base<N>(i) + (j - i - (i & 1));
+}
+template <int N>
+__host__ __device__ constexpr int pidx(int i, int j) { return (i <= j) ? pidx_ord<N>(i, j) : pidx_ord<N>(j, i); }
+// (P(r,c), P(r,c+1)) with r <= c is an aligned storage pair
+template <int N>
+__host__ __device__ constexpr bool is_pair(int r, int c)
+{
+    return (N % 2 == 0) && c + 1 < N && r <= c && (pidx<N>(r, c) % 2 == 0) && (pidx<N>(r, c + 1) == pidx<N>(r, c) + 1);
+}
+using f32x2 = float __attribute__((ext_vector_type(2)));
+template <typename T, int N> struct PackedMath { static constexpr bool on = false; };
+template <int N> struct PackedMath<float, N> { static constexpr bool on = (N % 2 == 0); };
 
 // ---- scalar helpers -------------------------------------------------------------
 __device__ __forceinline__ void fb_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
@@ -341,9 +369,67 @@ __device__ __forceinline__ void predict_step(T* nom, T* P, const T* accel, const
 // ================================================================================
 // One scalar measurement row h (non-zeros hA in columns 0..2, hB in columns 6..8),
 // residual rk, noise Rk, applied to P and accumulated into dx.
+// fp32, even N, simple covariance form: the same update with the row-wise work on aligned pairs
+// (v_pk_fma_f32: two FMAs per issue slot; at one wave per SIMD the correct kernel is VALU-issue bound).
+template <int N, bool HAS_A>
+__device__ __forceinline__ void scalar_update_packed(float* P, float* dx, const float* hA, const float* hB, float rk,
+                                                     float Rk)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+#define LD2(r, c) f32x2{ P[pidx<N>((r), (c))], P[pidx<N>((r), (c)) + 1] }
+    float Ph[N];
+#pragma unroll
+    for (int c = 0; c < N; c += 2) {
+        constexpr int dummy = 0; (void)dummy;
+        float lo, hi;
+        if (is_pair<N>(6, c) && is_pair<N>(7, c) && is_pair<N>(8, c)) {
+            const f32x2 v = hB[0] * LD2(6, c) + hB[1] * LD2(7, c) + hB[2] * LD2(8, c);
+            lo = v.x; hi = v.y;
+        } else {
+            lo = hB[0] * PS(c, 6) + hB[1] * PS(c, 7) + hB[2] * PS(c, 8);
+            hi = hB[0] * PS(c + 1, 6) + hB[1] * PS(c + 1, 7) + hB[2] * PS(c + 1, 8);
+        }
+        if (HAS_A) {
+            if (is_pair<N>(0, c) && is_pair<N>(1, c) && is_pair<N>(2, c)) {
+                const f32x2 v = hA[0] * LD2(0, c) + hA[1] * LD2(1, c) + hA[2] * LD2(2, c);
+                lo += v.x; hi += v.y;
+            } else {
+                lo += hA[0] * PS(c, 0) + hA[1] * PS(c, 1) + hA[2] * PS(c, 2);
+                hi += hA[0] * PS(c + 1, 0) + hA[1] * PS(c + 1, 1) + hA[2] * PS(c + 1, 2);
+            }
+        }
+        Ph[c] = lo; Ph[c + 1] = hi;
+    }
+    float s = Rk + hB[0] * Ph[6] + hB[1] * Ph[7] + hB[2] * Ph[8];
+    float inn = rk - (hB[0] * dx[6] + hB[1] * dx[7] + hB[2] * dx[8]);
+    if (HAS_A) {
+        s += hA[0] * Ph[0] + hA[1] * Ph[1] + hA[2] * Ph[2];
+        inn -= hA[0] * dx[0] + hA[1] * dx[1] + hA[2] * dx[2];
+    }
+    const float is = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float ki = Ph[i] * is;
+        dx[i] += ki * inn;
+        if (i & 1) PS(i, i) -= ki * Ph[i];
+#pragma unroll
+        for (int c = i + (i & 1); c < N; c += 2) {
+            const int o = pidx<N>(i, c);
+            const f32x2 v = f32x2{ P[o], P[o + 1] } - ki * f32x2{ Ph[c], Ph[c + 1] };
+            P[o] = v.x; P[o + 1] = v.y;
+        }
+    }
+#undef LD2
+#undef PS
+}
+
 template <typename T, int N, bool HAS_A, int COV>
 __device__ __forceinline__ void scalar_update(T* P, T* dx, const T* hA, const T* hB, T rk, T Rk)
 {
+    if constexpr (PackedMath<T, N>::on && COV == COV_SIMPLE) {
+        scalar_update_packed<N, HAS_A>(P, dx, hA, hB, rk, Rk);
+        return;
+    }
 #define PS(i, j) P[pidx<N>((i), (j))]
     T Ph[N];
 #pragma unroll

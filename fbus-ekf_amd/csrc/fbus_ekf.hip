@@ -608,6 +608,8 @@ struct fbus_ekf {
     bool timing = false;
     struct EvPair { hipEvent_t a, b; int kind; int count; };
     bool timing_suspended = false;   // frame_dev brackets its run of predicts with ONE pair
+    int timing_stride = 1;           // frame_dev: bracket every stride-th frame only
+    int64_t frame_count = 0;
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
     double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0, 0 };
@@ -1230,7 +1232,8 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
     const size_t es = esize(h), B = (size_t)h->B;
     // one event pair around the whole run of K back-to-back predict launches: a pair per launch
     // would cost ~8 us of stream time each and read ~3 us long; duration / K is the per-launch time
-    const int ev = K > 0 ? timing_begin(h, FBUS_KERNEL_PREDICT, K) : -1;
+    const bool sampled = (h->frame_count++ % h->timing_stride) == 0;
+    const int ev = (K > 0 && sampled) ? timing_begin(h, FBUS_KERNEL_PREDICT, K) : -1;
     h->timing_suspended = true;
     int rc = FBUS_OK;
     for (int k = 0; k < K && rc == FBUS_OK; ++k) {
@@ -1239,11 +1242,12 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
         const char* d = (const char*)dt + (size_t)k * (dt_per_filter ? B : 1) * es;
         rc = launch_predict(h, 1, a, g, d, dt_per_filter);
     }
-    h->timing_suspended = false;
     timing_end(h, ev);
-    if (rc != FBUS_OK) return rc;
-    if (M > 0) return fbus_ekf_correct_dev(h, M, ids, pos, quat, mode, skip);
-    return FBUS_OK;
+    if (rc != FBUS_OK) { h->timing_suspended = false; return rc; }
+    h->timing_suspended = !sampled;
+    if (M > 0) rc = fbus_ekf_correct_dev(h, M, ids, pos, quat, mode, skip);
+    h->timing_suspended = false;
+    return rc;
 }
 
 int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left, const void* right, void* pos,
@@ -1385,6 +1389,7 @@ int fbus_ekf_timing_enable(fbus_ekf_t h, int on)
     if (!h) return FBUS_ERR_INVALID;
     if (!on) { const int rc = flush_events(h); if (rc != FBUS_OK) return rc; }
     h->timing = on != 0;
+    h->timing_stride = on > 1 ? on : 1;
     return FBUS_OK;
 }
 

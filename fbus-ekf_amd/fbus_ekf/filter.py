@@ -260,8 +260,9 @@ class BatchedFilter:
         return (pos, quat, c3) if want_corners else (pos, quat)
 
     # ---- timing -------------------------------------------------------------------------
-    def timing_enable(self, on=True):
-        self._check(self._lib.fbus_ekf_timing_enable(self._h, 1 if on else 0), "timing_enable")
+    def timing_enable(self, on=True, stride=1):
+        """stride: frame() brackets only every stride-th frame with HIP events"""
+        self._check(self._lib.fbus_ekf_timing_enable(self._h, int(stride) if on else 0), "timing_enable")
 
     def timing_reset(self):
         self._check(self._lib.fbus_ekf_timing_reset(self._h), "timing_reset")

@@ -210,9 +210,11 @@ int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left
 /* ---- measurement support (bench / profiling) -------------------------------- */
 enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N = 2, FBUS_KERNEL_MARKER_POSE = 3,
        FBUS_KERNEL_FRAME = 4, FBUS_KERNEL_COUNT = 5 };
-/* When enabled, every launch of the listed kernels is bracketed by HIP events
- * on the handle's stream; read() synchronises and returns the summed device
- * time and launch count since the last reset. */
+/* When enabled (on >= 1), launches of the listed kernels are bracketed by HIP events on
+ * the handle's stream; read() synchronises and returns the summed device time and launch
+ * count since the last reset.  fbus_ekf_frame_dev uses ONE pair around its run of K
+ * back-to-back predict launches (a pair per launch costs ~8 us of stream time and reads
+ * ~3 us long) and brackets only every `on`-th frame (on = 1: every frame). */
 int fbus_ekf_timing_enable(fbus_ekf_t h, int on);
 int fbus_ekf_timing_reset(fbus_ekf_t h);
 int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* launches);
