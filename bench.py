@@ -88,22 +88,20 @@ def cpu_baseline(args, prm_dialect, seconds):
         nom, rot, P, prev = synth.initial_state(0, Bs, list(prm.p0_diag), 18)
         acc, gyr = synth.imu_samples(0, Bs, 0, sum(PATTERN), nom)
         frames = [synth.marker_frame(0, Bs, f, args.markers, nom, prm) for f in range(len(PATTERN))]
-        dt = np.full(max(PATTERN), 0.005)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            k = 0
-            for f, K in enumerate(PATTERN):                  # one thread team per camera frame
-                orc.frame(nom, rot, P, prev, acc[k:k + K], gyr[k:k + K], dt[:K], *frames[f], mode)
-                k += K
+        ids = np.stack([f[0] for f in frames]); pos = np.stack([f[1] for f in frames]); quat = np.stack([f[2] for f in frames])
+        dt = np.full(sum(PATTERN), 0.005)
+        t0 = time.perf_counter()                             # one thread team runs the whole schedule
+        orc.schedule(nom, rot, P, prev, PATTERN, reps, acc, gyr, dt, ids, pos, quat, mode)
         return Bs * STEPS_PER_BENCH_STEP * reps / (time.perf_counter() - t0)
 
     probe = run(256, 1, 1)                                   # steps/s of one thread, short probe
     Bs1 = int(min(8192, max(256, probe * min(seconds, 4.0) / STEPS_PER_BENCH_STEP)))
     one = run(Bs1, 1, 1)
-    BsN = int(min(65536, max(1024, one * cores * 0.7 * seconds / STEPS_PER_BENCH_STEP)))
-    allc = run(BsN, cores, 1)
+    BsN = 64 * cores                                         # 64 filters per thread, reps sized for ~`seconds`
+    reps = int(max(1, min(200, one * cores * 0.6 * seconds / (BsN * STEPS_PER_BENCH_STEP))))
+    allc = run(BsN, cores, reps)
     return {"value": allc, "unit": "EKF steps/s", "cores": cores, "kind": "port",
-            "sample": f"{BsN} filters x 1 bench step (20 predict + 3 correct, M={args.markers}, {args.mode}), "
+            "sample": f"{BsN} filters x {reps} bench steps (20 predict + 3 correct each, M={args.markers}, {args.mode}), "
                       f"fp64 dense oracle port, {cores} threads, {'-march=native' if native else 'generic x86-64'}",
             "value_1thread": one}
 

@@ -65,8 +65,8 @@ static void symmetrise(double* P, int n)
  * Matlab's inv, MeasureUpdate.m:84). Returns 0 on success.                */
 static int mat_inv(double* A, int n)
 {
-    double* W = (double*)malloc(sizeof(double) * n * 2 * n);
-    if (!W) return -1;
+    double W[FBO_MMAX * 2 * FBO_MMAX];     /* stack scratch: thread-friendly, no allocator in the timed path */
+    if (n > FBO_MMAX) return -1;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             W[i * 2 * n + j] = A[i * n + j];
@@ -76,7 +76,7 @@ static int mat_inv(double* A, int n)
         int piv = c;
         for (int r = c + 1; r < n; ++r)
             if (fabs(W[r * 2 * n + c]) > fabs(W[piv * 2 * n + c])) piv = r;
-        if (W[piv * 2 * n + c] == 0.0) { free(W); return -2; }
+        if (W[piv * 2 * n + c] == 0.0) return -2;
         if (piv != c)
             for (int j = 0; j < 2 * n; ++j) {
                 double t = W[c * 2 * n + j];
@@ -94,7 +94,6 @@ static int mat_inv(double* A, int n)
     }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) A[i * n + j] = W[i * 2 * n + n + j];
-    free(W);
     return 0;
 }
 
@@ -102,8 +101,8 @@ static int mat_inv(double* A, int n)
  * for Eigen's S.ldlt().solve(H*P), filter.cpp:711.  X overwrites B.        */
 static void ldlt_solve(const double* S, double* B, int m, int n)
 {
-    double* L = (double*)calloc((size_t)m * m, sizeof(double));
-    double* D = (double*)calloc((size_t)m, sizeof(double));
+    double L[FBO_MMAX * FBO_MMAX], D[FBO_MMAX];
+    memset(L, 0, sizeof(double) * (size_t)m * m);
     for (int j = 0; j < m; ++j) {
         double d = S[j * m + j];
         for (int k = 0; k < j; ++k) d -= L[j * m + k] * L[j * m + k] * D[k];
@@ -128,8 +127,6 @@ static void ldlt_solve(const double* S, double* B, int m, int n)
             B[i * n + c] = v;
         }
     }
-    free(L);
-    free(D);
 }
 
 /* ------------------------------------------------------------------ */
@@ -546,11 +543,7 @@ int fbo_correct(fbo_state* s, const fbo_params* prm, int M,
     }
 
     const int m = 7 * nsel;
-    double* H  = (double*)malloc(sizeof(double) * m * n);
-    double* r  = (double*)malloc(sizeof(double) * m);
-    double* HP = (double*)malloc(sizeof(double) * m * n);
-    double* S  = (double*)malloc(sizeof(double) * m * m);
-    double* K  = (double*)malloc(sizeof(double) * n * m);
+    double H[FBO_MMAX * FBO_NMAX], r[FBO_MMAX], HP[FBO_MMAX * FBO_NMAX], S[FBO_MMAX * FBO_MMAX], K[FBO_NMAX * FBO_MMAX];
     for (int j = 0; j < nsel; ++j)
         marker_rows(s, prm, slot[j], pos + 3 * sel[j], quat + 4 * sel[j], H + 7 * j * n, r + 7 * j);
 
@@ -559,18 +552,16 @@ int fbo_correct(fbo_state* s, const fbo_params* prm, int M,
     mat_mul_bt(HP, H, S, m, n, m);
     for (int j = 0; j < m; ++j) S[j * m + j] += ((j % 7) < 3) ? prm->r_pos : prm->r_quat;
     if (!cpp) {                             /* K = P H' inv(S) */
-        double* PHt = (double*)malloc(sizeof(double) * n * m);
+        double PHt[FBO_NMAX * FBO_MMAX];
         mat_mul_bt(s->P, H, PHt, n, n, m);
         mat_inv(S, m);
         mat_mul(PHt, S, K, n, m, m);
-        free(PHt);
     } else {                                /* K' = S.ldlt().solve(H P) */
-        double* X = (double*)malloc(sizeof(double) * m * n);
+        double X[FBO_MMAX * FBO_NMAX];
         memcpy(X, HP, sizeof(double) * m * n);
         ldlt_solve(S, X, m, n);
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < m; ++j) K[i * m + j] = X[j * n + i];
-        free(X);
     }
     double dx[FBO_NMAX];
     mat_mul(K, r, dx, n, m, 1);             /* MeasureUpdate.m:89 ; filter.cpp:723 */
@@ -605,7 +596,6 @@ int fbo_correct(fbo_state* s, const fbo_params* prm, int M,
     symmetrise(Pn, n);
     memcpy(s->P, Pn, sizeof(double) * n * n);
     /* rotateMat / rotmatI2G deliberately NOT refreshed (both dialects) */
-    free(H); free(r); free(HP); free(S); free(K);
     return 1;
 }
 
@@ -634,6 +624,7 @@ static void store_state(const fbo_state* s, int n, double* nom, double* rot, dou
 
 typedef struct {
     int lo, hi, is_correct, is_frame, K, B;
+    int nframes, reps; const int* Ks;
     double *nominal, *rot, *P;
     int* prev;
     const fbo_params* prm;
@@ -653,7 +644,19 @@ static void* batch_worker(void* arg)
     for (int b = j->lo; b < j->hi; ++b) {
         int prev = j->prev ? j->prev[b] : 0;
         load_state(&s, n, j->nominal + 19 * (size_t)b, j->rot + 9 * (size_t)b, j->P + (size_t)n * n * b, prev);
-        if (j->is_frame) {
+        if (j->nframes > 0) {       /* whole schedule: reps x (frames of K_f predicts + one correct) */
+            for (int rep = 0; rep < j->reps; ++rep) {
+                int k0 = 0;
+                for (int f = 0; f < j->nframes; ++f) {
+                    for (int k = 0; k < j->Ks[f]; ++k, ++k0)
+                        fbo_predict(&s, j->prm, j->accel + 3 * ((size_t)k0 * j->B + b), j->gyro + 3 * ((size_t)k0 * j->B + b),
+                                    j->dt[k0]);
+                    fbo_correct(&s, j->prm, j->M, j->ids + ((size_t)f * j->B + b) * j->M,
+                                j->pos + 3 * ((size_t)f * j->B + b) * j->M, j->quat + 4 * ((size_t)f * j->B + b) * j->M,
+                                j->mode);
+                }
+            }
+        } else if (j->is_frame) {
             for (int k = 0; k < j->K; ++k)
                 fbo_predict(&s, j->prm, j->accel + 3 * ((size_t)k * j->B + b), j->gyro + 3 * ((size_t)k * j->B + b),
                             j->dt[k]);
@@ -843,4 +846,21 @@ void fbo_imu_ema(int T, double* x, double* carry, int have_carry)
         memcpy(prev, x + 6 * t, sizeof(prev));
     }
     if (T > 0 && carry) memcpy(carry, prev, sizeof(prev));
+}
+
+/* CPU-baseline driver: `reps` repetitions of a schedule of nframes camera frames (frame f = Ks[f] predicts +
+ * one correct) per filter, one thread team for the whole call.  accel/gyro: sum(Ks) x B x 3, dt: sum(Ks),
+ * ids/pos/quat: nframes x B x M x {1,3,4}. */
+void fbo_schedule_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                        int nframes, const int* Ks, int reps, const double* accel, const double* gyro,
+                        const double* dt, int M, const int* ids, const double* pos, const double* quat,
+                        int mode, int nthreads)
+{
+    batch_job j;
+    memset(&j, 0, sizeof(j));
+    j.nframes = nframes; j.Ks = Ks; j.reps = reps; j.B = B;
+    j.nominal = nominal; j.rot = rot; j.P = P; j.prev = prev; j.prm = prm;
+    j.accel = accel; j.gyro = gyro; j.dt = dt;
+    j.M = M; j.ids = ids; j.pos = pos; j.quat = quat; j.mode = mode;
+    run_batch(&j, B, nthreads);
 }

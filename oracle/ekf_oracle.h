@@ -37,6 +37,7 @@ extern "C" {
 #define FBO_NMAX 18
 #define FBO_MAX_MARKERS 32      /* map entries */
 #define FBO_MAX_VISIBLE 16      /* markers per frame */
+#define FBO_MMAX (7 * FBO_MAX_VISIBLE)   /* stacked measurement rows */
 
 enum { FBO_DIALECT_MATLAB = 0, FBO_DIALECT_CPP = 1 };
 enum { FBO_MODE_NEAREST = 0,    /* reference behaviour: one 7-row update, nearest marker */
@@ -121,6 +122,11 @@ void fbo_frame_batch(int B, double* nominal, double* rot, double* P, int* prev,
                      const fbo_params* prm, int K, const double* accel, const double* gyro,
                      const double* dt, int M, const int* ids, const double* pos,
                      const double* quat, int mode, int nthreads);
+
+void fbo_schedule_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                        int nframes, const int* Ks, int reps, const double* accel, const double* gyro,
+                        const double* dt, int M, const int* ids, const double* pos, const double* quat,
+                        int mode, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,8 @@ def load(native=False):
                                       C.c_int, ip, C.c_int]
     lib.fbo_frame_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, dp, dp, dp, C.c_int,
                                     ip, dp, dp, C.c_int, C.c_int]
+    lib.fbo_schedule_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, ip, C.c_int, dp, dp, dp,
+                                       C.c_int, ip, dp, dp, C.c_int, C.c_int]
     u8 = C.POINTER(C.c_ubyte)
     lib.fbo_init_gravity_bias.argtypes = [C.c_int, dp, dp, dp, dp]
     lib.fbo_pose_init_batch.argtypes = [C.c_int, dp, dp, C.POINTER(FboParams), C.c_int, ip, dp, dp, C.c_int, C.c_double,
@@ -142,6 +144,20 @@ class Oracle:
         self.lib.fbo_frame_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), K, _dp(accel),
                                  _dp(gyro), _dp(dt), M, _ip(ids), _dp(pos), _dp(quat), mode, self.nthreads)
 
+
+    def schedule(self, nominal, rot, P, prev, Ks, reps, accel, gyro, dt, ids, pos, quat, mode=NEAREST):
+        """reps x (frames of Ks[f] predicts + one correct) per filter inside ONE thread team (CPU baseline)."""
+        B = nominal.shape[0]
+        Ks = np.ascontiguousarray(Ks, np.int32)
+        accel = np.ascontiguousarray(accel, np.float64); gyro = np.ascontiguousarray(gyro, np.float64)
+        dt = np.ascontiguousarray(dt, np.float64)
+        ids = np.ascontiguousarray(ids, np.int32)
+        M = ids.size // (len(Ks) * B)
+        pos = np.ascontiguousarray(pos, np.float64); quat = np.ascontiguousarray(quat, np.float64)
+        assert accel.size == int(Ks.sum()) * B * 3 and dt.size == int(Ks.sum())
+        self.lib.fbo_schedule_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), len(Ks), _ip(Ks),
+                                    reps, _dp(accel), _dp(gyro), _dp(dt), M, _ip(ids), _dp(pos), _dp(quat), mode,
+                                    self.nthreads)
 
     def pose_init(self, nominal, rot, ids, pos, quat, what, max_dist=2.0, mask=None):
         """what 0 init / 1 reset / 2 vision-only (returns out7); modifies nominal/rot in place for 0/1."""
