@@ -383,3 +383,22 @@ def test_fused_frame_equals_per_call_launches(dialect, mode):
         a.sync(); b.sync()
         sa, sb = a.get_state(), b.get_state()
         assert state_rel_err(sb[0], sa[0], sa[2])[0] < STATE_TOL and cov_rel_err(sb[2], sa[2]) < 1e-5
+
+
+def test_sixteen_marker_slots_stacked():
+    """config 5 shape: M = 16 slots per frame (12 distinct map markers + 4 absent), stacked 84-row update"""
+    B = 192
+    prm, nom, rot, P, prev = _batch(B, 0, 18)
+    ids, pos, quat = _markers(0, B, 0, 12, nom, prm)
+    ids16 = np.full((B, 16), -1, np.int32); ids16[:, 2:14] = ids
+    pos16 = np.zeros((B, 16, 3)); pos16[:, 2:14] = pos
+    quat16 = np.zeros((B, 16, 4)); quat16[:, :, 0] = 1; quat16[:, 2:14] = quat
+    for dtype in (32, 64):
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            eng = OracleEngine(B, 0, 18)
+            flt.set_state(nom, rot, P, prev)
+            eng.set_state(nom, rot, P, prev)
+            flt.correct(ids16, pos16, quat16, 1)
+            ok = eng.correct(ids16, pos16, quat16, 1)
+            assert ok.all() and (flt.applied() == 1).all()
+            _check(flt, eng, dtype, "16 slots stacked", state_tol=STATE_TOL * 3)    # 84 sequential rank-1 updates
