@@ -118,7 +118,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # FBUS_BENCH_DEBUG_SHARED_GPU=1: rehearsal of the N > 1 code path on a 1-GPU box (all ranks on cuda:0,
+        # gloo instead of RCCL for the control collectives); never used by the driver's multi-GPU runs.
+        shared = os.environ.get("FBUS_BENCH_DEBUG_SHARED_GPU") == "1"
+        dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
+        if shared:
+            local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -177,7 +182,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dist, world, dev)
+    ctl_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev
+    elapsed = shard.max_over_ranks(elapsed, dist, world, ctl_dev)
 
     pred_ms, pred_n = flt.timing_read(capi.KERNEL_PREDICT)
     corr_ms, corr_n = flt.timing_read(capi.KERNEL_CORRECT)
@@ -202,14 +208,14 @@ def main():
         fused_step(args.warmup + i)
     torch.cuda.synchronize()
     barrier()
-    fused_elapsed = shard.max_over_ranks(time.perf_counter() - tf0, dist, world, dev)
+    fused_elapsed = shard.max_over_ranks(time.perf_counter() - tf0, dist, world, ctl_dev)
     flt._keep.clear()
 
     # ---- the single end-of-run collective: gather the packed records (timed separately) ----
     torch.cuda.synchronize()
     barrier()
     tg = time.perf_counter()
-    gathered = shard.gather_records(rec, dist, world)
+    gathered = shard.gather_records(rec.cpu() if ctl_dev == "cpu" else rec, dist, world)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - tg) * 1e3
     nomf, _, Pf, _ = flt.get_state()

@@ -149,3 +149,72 @@ def test_gpu_gravity_bias_and_ema(dtype, tol):
         got = np.concatenate([np.concatenate([fa1[:, b], fa2[:, b]]), np.concatenate([fg1[:, b], fg2[:, b]])], axis=1)
         assert np.abs(got - y).max() < tol * 10
     assert np.array_equal(g_nom[:, :13], nom[:, :13].astype(g_nom.dtype))      # only bg and g were written
+
+
+def test_frame_batcher_sequences_like_the_reference_filter_thread(tmp_path):
+    """include/fbus/frame_batcher.hpp (EMA against the last buffered sample, window start <= t <= end,
+    dt from the state time, buffer trimming) against a Python restatement of filter.cpp:24-55,483-531."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    src = tmp_path / "fb.cpp"
+    src.write_text(r'''
+#include <fbus/frame_batcher.hpp>
+#include <cstdio>
+#include <vector>
+struct Recorder {
+    void predict(const double* a, const double* w, double dt) { std::printf("P %.9f %.9f %.9f\n", dt, a[0], w[5]); }
+    void correct(int M, const int32_t* ids, const double*, const double*, int mode, const unsigned char*) {
+        std::printf("C %d %d %d\n", M, ids[0], mode); }
+};
+int main() {
+    Recorder r;
+    fbus::FrameBatcher<double, Recorder> fb(r, 2, 0.0105, true, 40, 10);
+    double t = 0.0;
+    int k = 0;
+    for (int frame = 0; frame < 6; ++frame) {
+        const int n = (frame == 3) ? 55 : 9;              // frame 3 overflows the 40-sample buffer once
+        for (int i = 0; i < n; ++i, ++k) {
+            t += 0.001;
+            double a[3] = { 0.1 * k, 1, 2 }, w[3] = { 3, 4, 0.01 * k };
+            fb.set_imu(t, a, w);
+        }
+        int32_t ids[2] = { frame, 7 };
+        double pos[6] = {0}, quat[8] = {1,0,0,0,1,0,0,0};
+        int used = fb.on_detections(t - 0.0005, 2, ids, pos, quat, 1);
+        std::printf("F %d %zu %.9f\n", used, fb.buffered(), fb.state_time());
+    }
+}
+''')
+    exe = tmp_path / "fb"
+    subprocess.run(["g++", "-std=c++14", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+
+    exp = []
+    buf, t_state, t, k = [], 0.0105, 0.0, 0
+    for frame in range(6):
+        n = 55 if frame == 3 else 9
+        for _ in range(n):
+            t += 0.001
+            a0, w2 = 0.1 * k, 0.01 * k
+            k += 1
+            if buf:
+                a0 = buf[-1][1] * 0.9 + a0 * 0.1
+                w2 = buf[-1][2] * 0.9 + w2 * 0.1
+            buf.append((t, a0, w2))
+            if len(buf) > 40:
+                del buf[:10]
+        end, used, consumed = t - 0.0005, 0, 0
+        for (ts, a0, w2) in buf:
+            if ts < t_state:
+                consumed += 1
+                continue
+            if ts > end:
+                break
+            consumed += 1
+            exp.append(f"P {ts - t_state:.9f} {a0:.9f} {w2:.9f}")
+            t_state = ts
+            used += 1
+        del buf[:consumed]
+        exp.append(f"C 2 {frame} 1")
+        exp.append(f"F {used} {len(buf)} {t_state:.9f}")
+    assert got == exp
