@@ -70,6 +70,26 @@ def pmc_traffic(kernel_prefix="predict_kernel<float, 18"):
     return None, None
 
 
+def usable_cores():
+    """host cores this process may actually use: cgroup CPU quota, else the affinity mask, else cpu_count"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(args, prm_dialect, seconds):
     """fp64 dense oracle port on the host cores, on a bounded sample of the same workload."""
     import oracle_capi as oc
@@ -79,7 +99,7 @@ def cpu_baseline(args, prm_dialect, seconds):
         native = True
     except Exception:
         native = False
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     prm = capi.default_params(prm_dialect)
     mode = 1 if args.mode == "stacked" else 0
 
@@ -97,8 +117,8 @@ def cpu_baseline(args, prm_dialect, seconds):
     probe = run(256, 1, 1)                                   # steps/s of one thread, short probe
     Bs1 = int(min(8192, max(256, probe * min(seconds, 4.0) / STEPS_PER_BENCH_STEP)))
     one = run(Bs1, 1, 1)
-    BsN = 64 * cores                                         # 64 filters per thread, reps sized for ~`seconds`
-    reps = int(max(1, min(200, one * cores * 0.6 * seconds / (BsN * STEPS_PER_BENCH_STEP))))
+    BsN = 256 * cores                                        # 256 filters per thread, reps sized for ~`seconds`
+    reps = int(max(1, min(2000, one * cores * 0.6 * seconds / (BsN * STEPS_PER_BENCH_STEP))))
     allc = run(BsN, cores, reps)
     return {"value": allc, "unit": "EKF steps/s", "cores": cores, "kind": "port",
             "sample": f"{BsN} filters x {reps} bench steps (20 predict + 3 correct each, M={args.markers}, {args.mode}), "

@@ -380,7 +380,6 @@ __device__ __forceinline__ void scalar_update_packed(float* P, float* dx, const 
     float Ph[N];
 #pragma unroll
     for (int c = 0; c < N; c += 2) {
-        constexpr int dummy = 0; (void)dummy;
         float lo, hi;
         if (is_pair<N>(6, c) && is_pair<N>(7, c) && is_pair<N>(8, c)) {
             const f32x2 v = hB[0] * LD2(6, c) + hB[1] * LD2(7, c) + hB[2] * LD2(8, c);
