@@ -402,3 +402,39 @@ def test_sixteen_marker_slots_stacked():
             ok = eng.correct(ids16, pos16, quat16, 1)
             assert ok.all() and (flt.applied() == 1).all()
             _check(flt, eng, dtype, "16 slots stacked", state_tol=STATE_TOL * 3)    # 84 sequential rank-1 updates
+
+
+def test_long_run_stability_and_degenerate_inputs():
+    """10 s of simulated time at B = 4096 through the fused frame kernel: the filters stay finite, the covariance
+    stays symmetric positive definite and the quaternion unit; then the degenerate inputs the reference mishandles
+    (w == 0 and a zero correction, which are 0/0 in both reference dialects) leave the state finite."""
+    import torch
+    B, M = 4096, 4
+    prm = _params(0)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18)
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    with BatchedFilter(B, prm) as flt:
+        flt.set_state(nom, rot, P, prev)
+        step = 0
+        d_dt = f32(np.full(7, DT[0]))
+        for frame in range(300):
+            K = (7, 7, 6)[frame % 3]
+            acc, gyr = synth.imu_samples(0, B, step, K, nom)
+            step += K
+            ids, pos, quat = synth.marker_frame(0, B, frame, M, nom, prm)
+            flt.frame(f32(acc), f32(gyr), d_dt[:K], torch.from_numpy(ids).to(dev), f32(pos), f32(quat), 1, fused=True)
+        flt.sync()
+        g_nom, _, g_P, _ = flt.get_state()
+        assert np.isfinite(g_nom).all() and np.isfinite(g_P).all()
+        assert np.abs(np.linalg.norm(g_nom[:, 6:10], axis=1) - 1).max() < 1e-6
+        assert np.linalg.eigvalsh(g_P[::37].astype(np.float64)).min() > 0
+        assert np.abs(g_nom[:, 0:3] - nom[:, 0:3]).max() < 0.05          # held at the measured pose
+        assert np.abs(g_nom[:, 16:19] - [9.8, 0, 0]).max() < 0.5           # gravity estimate converged near truth
+        # degenerate inputs: gyro == gyro bias (w == 0) and a measurement equal to the prediction
+        flt.set_state(nom, rot, P, prev)
+        acc, _ = synth.imu_samples(0, B, 0, 1, nom)
+        flt.predict(acc[0], nom[:, 13:16].astype(np.float32).astype(np.float64), DT)
+        s = flt.get_state()
+        assert np.isfinite(s[0]).all() and np.isfinite(s[2]).all()
+        assert np.abs(s[0][:, 6:10] - nom[:, 6:10]).max() < 1e-6           # identity rotation, not NaN
