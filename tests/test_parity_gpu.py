@@ -438,3 +438,41 @@ def test_long_run_stability_and_degenerate_inputs():
         s = flt.get_state()
         assert np.isfinite(s[0]).all() and np.isfinite(s[2]).all()
         assert np.abs(s[0][:, 6:10] - nom[:, 6:10]).max() < 1e-6           # identity rotation, not NaN
+
+
+def test_device_state_io_records_aliasing_and_checkpoint_resume():
+    """set/get_state with device arrays, records living in a caller-owned tensor (what the RCCL gather ships),
+    and checkpoint -> resume: copying the packed records into a fresh handle continues bit for bit."""
+    import torch
+    B = 777
+    prm, nom, rot, P, prev = _batch(B, 1, 18)
+    prev = (np.arange(B) % 3).astype(np.int32)
+    acc, gyr = _imu(0, B, 0, 4, nom)
+    dt = _r32(np.random.default_rng(1).uniform(0.002, 0.008, (4, B)))
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    with BatchedFilter(B, prm) as a, BatchedFilter(B, prm) as b:
+        a.set_state(f32(nom), f32(rot), f32(P), torch.from_numpy(prev).to(dev))      # device arrays in
+        a.sync()
+        s = a.get_state()
+        assert np.array_equal(s[0], nom.astype(np.float32)) and np.array_equal(s[3], prev)
+        _, bpf, total = a.records()
+        assert bpf == 800 and total == 800 * ((B + 63) // 64 * 64)
+        rec = torch.empty(total, dtype=torch.uint8, device=dev)
+        a.attach_records(rec)
+        a.predict_n(acc[:2], gyr[:2], dt[:2])                                          # per-filter dt, host arrays
+        snapshot = rec.clone()                                                         # checkpoint
+        a.predict_n(acc[2:], gyr[2:], dt[2:])
+        ref = a.get_state()
+        rec_b = torch.empty(total, dtype=torch.uint8, device=dev)
+        b.attach_records(rec_b)
+        rec_b.copy_(snapshot)                                                          # resume in another handle
+        torch.cuda.synchronize()
+        b.predict_n(acc[2:], gyr[2:], dt[2:])
+        got = b.get_state()
+        assert all(np.array_equal(x, y) for x, y in zip(ref, got))
+        eng = OracleEngine(B, 1, 18)
+        eng.set_state(nom, rot, P, prev)
+        for k in range(4):
+            eng.predict(acc[k], gyr[k], dt[k])
+        assert state_rel_err(got[0], eng.nominal, eng.P)[0] <= STATE_TOL and cov_rel_err(got[2], eng.P) <= COV_TOL
