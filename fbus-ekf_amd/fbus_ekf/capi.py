@@ -37,7 +37,8 @@ class FbusParams(C.Structure):
 
 
 def library_path():
-    return os.path.join(_ROOT, "lib", "libfbus_ekf.so")
+    """in-tree build; FBUS_EKF_LIB overrides it (A/B runs of differently built kernels)"""
+    return os.environ.get("FBUS_EKF_LIB") or os.path.join(_ROOT, "lib", "libfbus_ekf.so")
 
 
 def declared_symbols():
