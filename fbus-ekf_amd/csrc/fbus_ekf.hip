@@ -25,7 +25,12 @@ using namespace fbus;
 
 namespace {
 
-constexpr int BLOCK = 64;               // one wave per workgroup: B/64 workgroups spread over 256 CUs x 4 SIMDs
+#ifndef FBUS_BLOCK
+#define FBUS_BLOCK 64
+#endif
+constexpr int BLOCK = FBUS_BLOCK;       // 64 = one wave per workgroup: B/64 workgroups over 256 CUs x 4 SIMDs
+__device__ __forceinline__ unsigned my_tile() { return __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6); }
+__device__ __forceinline__ unsigned my_lane() { return threadIdx.x & 63u; }
 
 // ---------------------------------------------------------------------------------
 // record <-> registers
@@ -100,10 +105,10 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     if (b >= B) return;
     using RC = Rec<T, N>;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[Lay<N>::NNOM], P[RC::NCOVP];
-    load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, threadIdx.x, nom);
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, threadIdx.x, P);
+    load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, my_lane(), nom);
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
     if (MULTI) {
         for (int k = 0; k < K; ++k) {
             const size_t o = ((size_t)k * B + b) * 3;
@@ -120,8 +125,8 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
         predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
     }
     // ba, bg, g are not written by ImuUpdate: their chunks stay as they are in HBM
-    store_chunks<T, N, 0, RC::CH_KIN>(rs, threadIdx.x, nom);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
+    store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
 }
 
 template <typename T, int N, int DIALECT, int COV>
@@ -168,9 +173,9 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     }
 
     using RC = Rec<T, N>;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T P[RC::NCOVP];
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, threadIdx.x, P);
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
@@ -185,19 +190,19 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         // the linearisation point (p, q, R) is not modified until inject(): it is re-read per marker
         // (an L2 hit) instead of being held in registers across the seven rank-1 updates
         T pqr[L::NPQR];
-        load_chunks<T, N, 0, RC::CH_PQR>(rs, threadIdx.x, pqr);
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
         marker_update<T, N, DIALECT, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
         ++used;
     }
     if (used == 0) { applied[b] = 0; return; }
     T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, threadIdx.x, nom);
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     // the carried rotation is NOT refreshed by MeasureUpdate: chunks holding only R are left alone
-    store_chunks<T, N, 0, RC::CH_PQ>(rs, threadIdx.x, nom);
-    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, threadIdx.x, nom + L::NPQR);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
+    store_chunks<T, N, 0, RC::CH_PQ>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, my_lane(), nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
     applied[b] = 1;
 }
 
@@ -216,10 +221,10 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     using RC = Rec<T, N>;
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     if (b >= B) return;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, blockIdx.x);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
-    load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, threadIdx.x, nom);
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, threadIdx.x, P);
+    load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, my_lane(), nom);
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
     for (int k = 0; k < K; ++k) {
         const size_t o = ((size_t)k * B + b) * 3;
         const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
@@ -277,8 +282,8 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
         if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     }
     if (M > 0) applied[b] = used > 0 ? 1 : 0;
-    store_chunks<T, N, 0, RC::CH_NOM>(rs, threadIdx.x, nom);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, threadIdx.x, P);
+    store_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
 }
 
 // One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
