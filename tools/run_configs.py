@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Informational runs of the BASELINE.json configs 2, 3 and 5 on one MI355X (config 1 = CPU plumbing and
+config 4 = the multi-GPU bench are covered by tests/ and bench.py).  Prints one line per case; the contract
+line stays bench.py's.  Kernel times are HIP-event brackets (library timing API) around back-to-back launches."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
+import torch
+from fbus_ekf import BatchedFilter, capi, synth
+
+dev = torch.device("cuda:0")
+prm = capi.default_params(0)
+
+
+def tensors(a, tdt):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(tdt)
+
+
+def timed(flt, kind, fn, reps):
+    for _ in range(3):
+        fn()
+    flt.sync()
+    flt.timing_enable(True); flt.timing_reset()
+    for _ in range(reps):
+        fn()
+    ms, n = flt.timing_read(kind)
+    flt.timing_enable(False)
+    return ms / n * 1e3
+
+
+def run(B, dtype, M, what, K=1, mode=1, reps=200):
+    tdt = torch.float32 if dtype == 32 else torch.float64
+    es = 4 if dtype == 32 else 8
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18)
+    acc, gyr = synth.imu_samples(0, B, 0, max(K, 1), nom)
+    d_acc, d_gyr, d_dt = tensors(acc, tdt), tensors(gyr, tdt), tensors(np.full(max(K, 1), 0.005), tdt)
+    with BatchedFilter(B, prm, dtype=dtype) as flt:
+        flt.set_state(nom, rot, P, prev)
+        if what == "predict":
+            us = timed(flt, capi.KERNEL_PREDICT, lambda: flt.predict(d_acc[0], d_gyr[0], d_dt[:1]), reps)
+            steps, bytes_ = B, (2 * 199 * es + 7 * es) * B
+        elif what == "predict_n":
+            us = timed(flt, capi.KERNEL_PREDICT_N, lambda: flt.predict_n(d_acc, d_gyr, d_dt), reps)
+            steps, bytes_ = B * K, (2 * 199 * es + 7 * es) * B * K
+        else:
+            ids, pos, quat = synth.marker_frame(0, B, 0, min(M, 12), nom, prm)
+            if M > 12:
+                pad = M - 12
+                ids = np.concatenate([ids, np.full((B, pad), -1, np.int32)], axis=1)
+                pos = np.concatenate([pos, np.zeros((B, pad, 3))], axis=1)
+                quat = np.concatenate([quat, np.tile([1.0, 0, 0, 0], (B, pad, 1))], axis=1)
+            d = (torch.from_numpy(ids).to(dev), tensors(pos, tdt), tensors(quat, tdt))
+            us = timed(flt, capi.KERNEL_CORRECT, lambda: flt.correct(d[0], d[1], d[2], mode), reps)
+            steps, bytes_ = B, (2 * 199 * es + 8 * es * M) * B
+    return us, steps / us * 1e6, bytes_ / us * 1e-3
+
+
+print("config  case                                             us/launch     EKF steps/s   algorithmic GB/s")
+for name, args in (
+    ("2", dict(B=4096, dtype=32, M=0, what="predict")),
+    ("2", dict(B=4096, dtype=32, M=0, what="predict_n", K=8)),
+    ("3", dict(B=16384, dtype=32, M=4, what="correct", mode=0)),
+    ("3", dict(B=16384, dtype=32, M=4, what="correct", mode=1)),
+    ("5", dict(B=65536, dtype=32, M=16, what="correct", mode=1, reps=50)),
+    ("5", dict(B=65536, dtype=64, M=16, what="correct", mode=1, reps=20)),
+    ("5", dict(B=65536, dtype=64, M=0, what="predict", reps=50)),
+    ("-", dict(B=65536, dtype=32, M=1, what="correct", mode=0)),
+):
+    us, sps, gbs = run(**args)
+    desc = f"B={args['B']} fp{args['dtype']} {args['what']}" + (f" K={args['K']}" if "K" in args else "") + \
+           (f" M={args['M']} {'stacked' if args.get('mode', 1) else 'nearest'}" if args["what"] == "correct" else "")
+    print(f"{name:>4}    {desc:<48} {us:9.2f}   {sps:13.4g}   {gbs:10.0f}")
