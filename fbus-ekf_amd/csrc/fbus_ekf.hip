@@ -627,6 +627,22 @@ struct fbus_ekf {
 
 namespace {
 
+// Every entry point runs with the handle's device current (a process may hold handles on several GPUs) and
+// restores the caller's device on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const fbus_ekf* h) { if (h) enter(h->device); }
+    explicit DeviceGuard(int device) { enter(device); }
+    void enter(int device)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 int fail(fbus_ekf_t h, int code, const std::string& msg)
 {
     if (h) h->err = msg;
@@ -1013,7 +1029,9 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (prm->dialect != FBUS_DIALECT_MATLAB && prm->dialect != FBUS_DIALECT_CPP) return FBUS_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FBUS_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return FBUS_ERR_NO_DEVICE;
+    DeviceGuard guard_(device);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) return FBUS_ERR_NO_DEVICE;
 
     fbus_ekf* h = new (std::nothrow) fbus_ekf();
     if (!h) return FBUS_ERR_NOMEM;
@@ -1055,8 +1073,8 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
 
 int fbus_ekf_destroy(fbus_ekf_t h)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_OK;
-    (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& p : h->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (int i = 0; i < 6; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
@@ -1072,6 +1090,7 @@ int fbus_ekf_destroy(fbus_ekf_t h)
 
 int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
@@ -1080,6 +1099,7 @@ int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream)
 
 int fbus_ekf_sync(fbus_ekf_t h)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FBUS_OK;
@@ -1089,18 +1109,21 @@ const char* fbus_ekf_last_error(fbus_ekf_t h) { return h ? h->err.c_str() : "nul
 
 int fbus_ekf_set_state_dev(fbus_ekf_t h, const void* nominal, const void* rot, const void* P, const int32_t* prev_id)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     return do_pack(h, nominal, rot, P, prev_id);
 }
 
 int fbus_ekf_get_state_dev(fbus_ekf_t h, void* nominal, void* rot, void* P, int32_t* prev_id)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     return do_unpack(h, nominal, rot, P, prev_id);
 }
 
 int fbus_ekf_set_state(fbus_ekf_t h, const void* nominal, const void* rot, const void* P, const int32_t* prev_id)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     const size_t es = esize(h), B = (size_t)h->B, N = (size_t)h->N;
     const void *dn, *dr, *dP, *dp;
@@ -1116,6 +1139,7 @@ int fbus_ekf_set_state(fbus_ekf_t h, const void* nominal, const void* rot, const
 
 int fbus_ekf_get_state(fbus_ekf_t h, void* nominal, void* rot, void* P, int32_t* prev_id)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     const size_t es = esize(h), B = (size_t)h->B, N = (size_t)h->N;
     int rc;
@@ -1135,12 +1159,14 @@ int fbus_ekf_get_state(fbus_ekf_t h, void* nominal, void* rot, void* P, int32_t*
 
 int fbus_ekf_reset_cov(fbus_ekf_t h)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     return do_reset_cov(h);
 }
 
 int fbus_ekf_records(fbus_ekf_t h, void** dev_ptr, size_t* bytes_per_filter, size_t* total_bytes)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     if (dev_ptr) *dev_ptr = h->recs;
     if (bytes_per_filter) *bytes_per_filter = h->bytes_per_filter;
@@ -1150,6 +1176,7 @@ int fbus_ekf_records(fbus_ekf_t h, void** dev_ptr, size_t* bytes_per_filter, siz
 
 int fbus_ekf_attach_records(fbus_ekf_t h, void* dev_ptr, size_t total_bytes)
 {
+    DeviceGuard guard_(h);
     if (!h || !dev_ptr) return FBUS_ERR_INVALID;
     if (total_bytes != h->rec_bytes) return fail(h, FBUS_ERR_INVALID, "attach_records: size mismatch");
     if (((uintptr_t)dev_ptr & 15) != 0) return fail(h, FBUS_ERR_INVALID, "attach_records: pointer not 16-byte aligned");
@@ -1163,17 +1190,20 @@ int fbus_ekf_attach_records(fbus_ekf_t h, void* dev_ptr, size_t total_bytes)
 
 int fbus_ekf_predict_n_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
 {
+    DeviceGuard guard_(h);
     if (!h || !accel || !gyro || !dt || K < 1) return FBUS_ERR_INVALID;
     return launch_predict(h, K, accel, gyro, dt, dt_per_filter);
 }
 
 int fbus_ekf_predict_dev(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
 {
+    DeviceGuard guard_(h);
     return fbus_ekf_predict_n_dev(h, 1, accel, gyro, dt, dt_per_filter);
 }
 
 int fbus_ekf_predict_n(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
 {
+    DeviceGuard guard_(h);
     if (!h || !accel || !gyro || !dt || K < 1) return FBUS_ERR_INVALID;
     const size_t es = esize(h), B = (size_t)h->B;
     const void *da, *dg, *dd;
@@ -1188,12 +1218,14 @@ int fbus_ekf_predict_n(fbus_ekf_t h, int K, const void* accel, const void* gyro,
 
 int fbus_ekf_predict(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
 {
+    DeviceGuard guard_(h);
     return fbus_ekf_predict_n(h, 1, accel, gyro, dt, dt_per_filter);
 }
 
 int fbus_ekf_correct_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,
                          const uint8_t* skip)
 {
+    DeviceGuard guard_(h);
     if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
     if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     return launch_correct(h, M, ids, pos, quat, mode, skip);
@@ -1202,6 +1234,7 @@ int fbus_ekf_correct_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* po
 int fbus_ekf_correct(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,
                      const uint8_t* skip)
 {
+    DeviceGuard guard_(h);
     if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
     if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     const size_t es = esize(h), B = (size_t)h->B;
@@ -1218,6 +1251,7 @@ int fbus_ekf_correct(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
 
 int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host)
 {
+    DeviceGuard guard_(h);
     if (!h || !applied_host) return FBUS_ERR_INVALID;
     HIP_TRY(h, hipMemcpyAsync(applied_host, h->d_applied, (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1227,6 +1261,7 @@ int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host)
 int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                              int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
 {
+    DeviceGuard guard_(h);
     if (!h || K < 0 || M < 0 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
     if (K > 0 && (!accel || !gyro || !dt)) return FBUS_ERR_INVALID;
     if (M > 0 && (!ids || !pos || !quat)) return FBUS_ERR_INVALID;
@@ -1237,6 +1272,7 @@ int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void*
 int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                        int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
 {
+    DeviceGuard guard_(h);
     if (!h || K < 0) return FBUS_ERR_INVALID;
     const size_t es = esize(h), B = (size_t)h->B;
     // one event pair around the whole run of K back-to-back predict launches: a pair per launch
@@ -1262,6 +1298,7 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
 int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left, const void* right, void* pos,
                              void* quat, void* corners3d)
 {
+    DeviceGuard guard_(h);
     if (!h || n < 1 || !left || !pos || !quat) return FBUS_ERR_INVALID;
     if (geometry != FBUS_VIS_REFRACTIVE && geometry != FBUS_VIS_PINHOLE && geometry != FBUS_VIS_CORNERS3D)
         return FBUS_ERR_UNSUPPORTED;
@@ -1273,6 +1310,7 @@ int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left
 int fbus_ekf_marker_pose(fbus_ekf_t h, int n, int geometry, const void* left, const void* right, void* pos,
                          void* quat, void* corners3d)
 {
+    DeviceGuard guard_(h);
     if (!h || n < 1 || !left || !pos || !quat) return FBUS_ERR_INVALID;
     const size_t es = esize(h), nn = (size_t)n;
     const size_t in_w = geometry == FBUS_VIS_CORNERS3D ? 12 : 8;
@@ -1294,12 +1332,14 @@ int fbus_ekf_marker_pose(fbus_ekf_t h, int n, int geometry, const void* left, co
 
 int fbus_ekf_init_gravity_bias_dev(fbus_ekf_t h, int T, const void* accel, const void* gyro)
 {
+    DeviceGuard guard_(h);
     if (!h || T < 1 || !accel || !gyro) return FBUS_ERR_INVALID;
     return do_init_gb(h, T, accel, gyro);
 }
 
 int fbus_ekf_init_gravity_bias(fbus_ekf_t h, int T, const void* accel, const void* gyro)
 {
+    DeviceGuard guard_(h);
     if (!h || T < 1 || !accel || !gyro) return FBUS_ERR_INVALID;
     const size_t bytes = (size_t)T * h->B * 3 * esize(h);
     const void *da, *dg;
@@ -1314,6 +1354,7 @@ int fbus_ekf_init_gravity_bias(fbus_ekf_t h, int T, const void* accel, const voi
 int fbus_ekf_pose_init_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
                            const uint8_t* mask)
 {
+    DeviceGuard guard_(h);
     if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
     if (what != FBUS_POSE_INIT && what != FBUS_POSE_RESET) return FBUS_ERR_INVALID;
     return do_pose_init(h, M, ids, pos, quat, what, mask, nullptr);
@@ -1322,6 +1363,7 @@ int fbus_ekf_pose_init_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* 
 int fbus_ekf_vision_only_pose_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat,
                                   void* out_pose)
 {
+    DeviceGuard guard_(h);
     if (!h || !ids || !pos || !quat || !out_pose || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
     return do_pose_init(h, M, ids, pos, quat, 2, nullptr, out_pose);
 }
@@ -1348,6 +1390,7 @@ static int pose_host(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
 int fbus_ekf_pose_init(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int what,
                        const uint8_t* mask)
 {
+    DeviceGuard guard_(h);
     if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
     if (what != FBUS_POSE_INIT && what != FBUS_POSE_RESET) return FBUS_ERR_INVALID;
     return pose_host(h, M, ids, pos, quat, what, mask, nullptr);
@@ -1355,12 +1398,14 @@ int fbus_ekf_pose_init(fbus_ekf_t h, int M, const int32_t* ids, const void* pos,
 
 int fbus_ekf_vision_only_pose(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, void* out_pose)
 {
+    DeviceGuard guard_(h);
     if (!h || !ids || !pos || !quat || !out_pose || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
     return pose_host(h, M, ids, pos, quat, 2, nullptr, out_pose);
 }
 
 int fbus_ekf_imu_ema_dev(fbus_ekf_t h, int T, void* accel, void* gyro, int restart)
 {
+    DeviceGuard guard_(h);
     if (!h || T < 0 || (T > 0 && (!accel || !gyro))) return FBUS_ERR_INVALID;
     if (!h->d_ema_carry) HIP_TRY(h, hipMalloc(&h->d_ema_carry, (size_t)h->B * 6 * esize(h)));
     if (restart) h->ema_has_carry = false;
@@ -1379,6 +1424,7 @@ int fbus_ekf_imu_ema_dev(fbus_ekf_t h, int T, void* accel, void* gyro, int resta
 
 int fbus_ekf_imu_ema(fbus_ekf_t h, int T, void* accel, void* gyro, int restart)
 {
+    DeviceGuard guard_(h);
     if (!h || T < 0 || (T > 0 && (!accel || !gyro))) return FBUS_ERR_INVALID;
     if (T == 0) return fbus_ekf_imu_ema_dev(h, 0, nullptr, nullptr, restart);
     const size_t bytes = (size_t)T * h->B * 3 * esize(h);
@@ -1395,6 +1441,7 @@ int fbus_ekf_imu_ema(fbus_ekf_t h, int T, void* accel, void* gyro, int restart)
 
 int fbus_ekf_timing_enable(fbus_ekf_t h, int on)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     if (!on) { const int rc = flush_events(h); if (rc != FBUS_OK) return rc; }
     h->timing = on != 0;
@@ -1404,6 +1451,7 @@ int fbus_ekf_timing_enable(fbus_ekf_t h, int on)
 
 int fbus_ekf_timing_reset(fbus_ekf_t h)
 {
+    DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     const int rc = flush_events(h);
     if (rc != FBUS_OK) return rc;
@@ -1413,6 +1461,7 @@ int fbus_ekf_timing_reset(fbus_ekf_t h)
 
 int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* launches)
 {
+    DeviceGuard guard_(h);
     if (!h || kernel < 0 || kernel >= FBUS_KERNEL_COUNT) return FBUS_ERR_INVALID;
     const int rc = flush_events(h);
     if (rc != FBUS_OK) return rc;
