@@ -548,6 +548,59 @@ __device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const D
     }
 }
 
+// Corner-row measurement model (north-star extension, no reference counterpart): the four triangulated
+// corner positions C[12] of one marker as 12 scalar rows.  h_k = R_IL R'(P_m + R_m c_k - p - R P_IL) with
+// c_k = {(0,0,0),(0,s,0),(s,s,0),(s,0,0)} (marker frame of vision.cpp:736-759); Jacobian blocks as the
+// reference's position rows (MeasureUpdate.m:72-73) with the corner in place of the marker origin.
+template <typename T, int N, int COV>
+__device__ __forceinline__ void corner_update(T* P, T* dx, const T* pqr, const DevConst<T>& dc,
+                                              const T* __restrict__ mk, const T* C, T size)
+{
+    using L = Lay<N>;
+    const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
+    T Rm[9];
+    {
+        const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
+        quat_to_rotmat_m(Qm, Rm);
+    }
+    // H(:,1:3) = -R_IL R' is the same for every corner
+    T Hpp[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Hpp[3 * i + j] = -(dc.R_IL[3 * i] * R[3 * j] + dc.R_IL[3 * i + 1] * R[3 * j + 1] + dc.R_IL[3 * i + 2] * R[3 * j + 2]);
+    T RP[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) RP[i] = R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const T cx = (k >= 2) ? size : T(0), cy = (k == 1 || k == 2) ? size : T(0);
+        T u[3], d[3], ru[3], t[3], hp[3], Hpt[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            u[i] = mk[i] + Rm[3 * i] * cx + Rm[3 * i + 1] * cy - p[i];      // corner in the world, minus p
+            d[i] = u[i] - RP[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            t[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
+            ru[i] = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
+            hp[i] = l0 * t[0] + l1 * t[1] + l2 * t[2];
+            Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
+            Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
+            Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            scalar_update<T, N, true, COV>(P, dx, Hpp + 3 * a, Hpt + 3 * a, C[3 * k + a] - hp[a], dc.r_pos);
+    }
+}
+
 // State injection   MeasureUpdate.m:92-98 ; filter.cpp:726-733.  R is NOT refreshed.
 template <typename T, int N>
 __device__ __forceinline__ void inject(T* rec /* the 28 nominal + rotation elements */, const T* dx)

@@ -286,6 +286,82 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
 }
 
+// correct() from stereo corners: triangulation + 12 corner rows per marker (north-star extension).
+template <typename T, int N, int DIALECT, int COV>
+__global__ void __launch_bounds__(BLOCK)
+correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
+                       const T* __restrict__ right, int geometry, int mode, T size,
+                       const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied, DevConst<T> dc,
+                       VisConst<T> vc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    if (skip && skip[b]) { applied[b] = 0; return; }
+    const int* my_ids = ids + (size_t)b * M;
+    const int lw = (geometry == VIS_CORNERS3D) ? 12 : 8;
+    auto corner = [&](int i, int c, T* out) {          // corner c of marker slot i in the left camera frame
+        const T* l = left + ((size_t)b * M + i) * lw;
+        if (geometry == VIS_CORNERS3D) { out[0] = l[3 * c]; out[1] = l[3 * c + 1]; out[2] = l[3 * c + 2]; return; }
+        const T* r = right + ((size_t)b * M + i) * 8;
+        if (geometry == VIS_REFRACTIVE) refraction_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], out);
+        else pinhole_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], out);
+    };
+    int first = 0, last = M, new_prev = -1;
+    if (mode == MODE_NEAREST) {
+        int prev_id = 0;
+        if (DIALECT == DIALECT_CPP) prev_id = (int)recs[elem_index<T, N>(b, L::OFF_PREV)];
+        int min_i = -1, prev_i = -1;
+        T min_d = T(10), prev_d = T(0);
+        for (int i = 0; i < M; ++i) {
+            const int id = my_ids[i];
+            if (id < 0) continue;
+            T c0[3];
+            corner(i, 0, c0);
+            const T dist = fb_sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i < 0) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
+        const int id = my_ids[min_i];
+        const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+        if (slot < 0) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP) new_prev = id;
+        first = min_i; last = min_i + 1;
+    }
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T P[RC::NCOVP];
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    int used = 0;
+    for (int i = first; i < last; ++i) {
+        const int id = my_ids[i];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+        const int slot = dc.id2slot[id];
+        if (slot < 0) continue;
+        T C[12];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) corner(i, c, C + 3 * c);
+        T pqr[L::NPQR];
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
+        corner_update<T, N, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, C, size);
+        ++used;
+    }
+    if (used == 0) { applied[b] = 0; return; }
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    inject<T, N>(nom, dx);
+    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    store_chunks<T, N, 0, RC::CH_PQ>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, my_lane(), nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+    applied[b] = 1;
+}
+
 // One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -621,8 +697,8 @@ struct fbus_ekf {
     int64_t frame_count = 0;
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
-    double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0, 0 };
-    int64_t t_n[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0, 0 };
+    double t_ms[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0, 0, 0 };
+    int64_t t_n[FBUS_KERNEL_COUNT] = { 0, 0, 0, 0, 0, 0 };
 };
 
 namespace {
@@ -917,6 +993,31 @@ int do_pose_init(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const
     DISPATCH(h, pose_init_t, h, M, ids, pos, quat, what, mask, out7);
 }
 
+template <typename T, int N, int D>
+int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, int geometry,
+                             int mode, const uint8_t* skip)
+{
+    const int grid = (h->B + BLOCK - 1) / BLOCK;
+    const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
+    if (h->prm.cov_form == FBUS_COV_JOSEPH)
+        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, h->stream,
+                           (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
+                           (T)h->prm.marker_size, (const unsigned char*)skip, h->d_applied, make_dc<T>(h), make_vc<T>(h));
+    else
+        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, h->stream,
+                           (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
+                           (T)h->prm.marker_size, (const unsigned char*)skip, h->d_applied, make_dc<T>(h), make_vc<T>(h));
+    timing_end(h, ev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+int launch_correct_corners(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, int geometry,
+                           int mode, const uint8_t* skip)
+{
+    DISPATCH(h, launch_correct_corners_t, h, M, ids, left, right, geometry, mode, skip);
+}
+
 int ensure_stage(fbus_ekf_t h, int slot, size_t bytes)
 {
     if (bytes <= h->stage_cap[slot]) return FBUS_OK;
@@ -1017,6 +1118,7 @@ int fbus_params_default(fbus_params* prm, int dialect)
     prm->n_air = 1.00; prm->n_glass = 1.49; prm->n_water = 1.32;    // paramconfig.yml:31-42
     prm->d_air = 0.002; prm->d_glass = 0.02;
     prm->port_normal[0] = 0; prm->port_normal[1] = 0; prm->port_normal[2] = 1;
+    prm->marker_size = 0.28;    // vision.hpp:114
     return FBUS_OK;
 }
 
@@ -1245,6 +1347,37 @@ int fbus_ekf_correct(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
     if ((rc = stage_in(h, 2, quat, B * M * 4 * es, &dq)) != FBUS_OK) return rc;
     if ((rc = stage_in(h, 3, skip, B, &ds)) != FBUS_OK) return rc;
     if ((rc = launch_correct(h, M, (const int32_t*)di, dp, dq, mode, (const uint8_t*)ds)) != FBUS_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_correct_corners_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right,
+                                 int geometry, int mode, const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || !ids || !left || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (geometry != FBUS_VIS_REFRACTIVE && geometry != FBUS_VIS_PINHOLE && geometry != FBUS_VIS_CORNERS3D)
+        return FBUS_ERR_UNSUPPORTED;
+    if (geometry != FBUS_VIS_CORNERS3D && !right) return FBUS_ERR_INVALID;
+    if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    return launch_correct_corners(h, M, ids, left, right, geometry, mode, skip);
+}
+
+int fbus_ekf_correct_corners(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right,
+                             int geometry, int mode, const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || !ids || !left || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), B = (size_t)h->B;
+    const size_t lw = geometry == FBUS_VIS_CORNERS3D ? 12 : 8;
+    const void *di, *dl, *dr, *ds;
+    int rc;
+    if ((rc = stage_in(h, 0, ids, B * M * 4, &di)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, left, B * M * lw * es, &dl)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 2, geometry == FBUS_VIS_CORNERS3D ? nullptr : right, B * M * 8 * es, &dr)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 3, skip, B, &ds)) != FBUS_OK) return rc;
+    if ((rc = fbus_ekf_correct_corners_dev(h, M, (const int32_t*)di, dl, dr, geometry, mode, (const uint8_t*)ds)) != FBUS_OK)
+        return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FBUS_OK;
 }

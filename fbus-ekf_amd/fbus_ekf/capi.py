@@ -11,6 +11,7 @@ DIALECT_MATLAB, DIALECT_CPP = 0, 1
 MODE_NEAREST, MODE_STACKED = 0, 1
 COV_SIMPLE, COV_JOSEPH = 0, 1
 KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE, KERNEL_FRAME = 0, 1, 2, 3, 4
+KERNEL_CORRECT_CORNERS = 5
 VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D = 0, 1, 2
 POSE_INIT, POSE_RESET = 0, 1
 MAX_MARKERS, MAX_VISIBLE = 32, 16
@@ -33,6 +34,7 @@ class FbusParams(C.Structure):
         ("switch_thres", C.c_double), ("max_dist", C.c_double),
         ("n_air", C.c_double), ("n_glass", C.c_double), ("n_water", C.c_double),
         ("d_air", C.c_double), ("d_glass", C.c_double), ("port_normal", C.c_double * 3),
+        ("marker_size", C.c_double),
     ]
 
 
@@ -92,6 +94,8 @@ def load_library():
         "fbus_ekf_predict_n_dev": ([H, C.c_int, vp, vp, vp, C.c_int], C.c_int),
         "fbus_ekf_correct": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_correct_dev": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_correct_corners": ([H, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
+        "fbus_ekf_correct_corners_dev": ([H, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
         "fbus_ekf_get_applied": ([H, u8p], C.c_int),
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),

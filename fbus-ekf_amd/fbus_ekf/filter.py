@@ -175,6 +175,31 @@ class BatchedFilter:
         rc = self._lib.fbus_ekf_correct(self._h, M, self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
         self._check(rc, "correct")
 
+    def correct_corners(self, ids, left, right=None, geometry=capi.VIS_REFRACTIVE, mode=capi.MODE_NEAREST, skip=None):
+        """correct() from stereo corners (north-star extension, no reference counterpart): the corners are
+        triangulated on the device and each corner position is a 3-row measurement (12 rows per marker).
+        left/right: (B, M, 8) normalised corner coordinates, or left = (B, M, 12) with VIS_CORNERS3D."""
+        B = self.B
+        w = 12 if geometry == capi.VIS_CORNERS3D else 8
+        if _is_dev(ids):
+            M = ids.numel() // B
+            self._dev_checked(ids, B * M, "ids"); self._dev_checked(left, B * M * w, "left")
+            if right is not None:
+                self._dev_checked(right, B * M * 8, "right")
+            if skip is not None:
+                self._dev_checked(skip, B, "skip")
+            rc = self._lib.fbus_ekf_correct_corners_dev(self._h, M, self._p(ids), self._p(left), self._p(right),
+                                                        geometry, mode, self._p(skip))
+            return self._check(rc, "correct_corners_dev")
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        left = self._host(left, (B, M, w))
+        right = None if right is None else self._host(right, (B, M, 8))
+        skip = None if skip is None else self._host(skip, (B,), np.uint8)
+        rc = self._lib.fbus_ekf_correct_corners(self._h, M, self._p(ids), self._p(left), self._p(right), geometry, mode,
+                                                self._p(skip))
+        self._check(rc, "correct_corners")
+
     def applied(self):
         out = np.empty(self.B, np.uint8)
         self._check(self._lib.fbus_ekf_get_applied(self._h, self._p(out)), "get_applied")

@@ -57,6 +57,10 @@ enum { FBUS_DIALECT_MATLAB = 0,   /* matlab/ImuUpdate.m, MeasureUpdate.m        
 /* Measurement handling in correct(). */
 enum { FBUS_MODE_NEAREST = 0,     /* reference: nearest marker (C++: + hysteresis), 7 rows */
        FBUS_MODE_STACKED = 1 };   /* extension: all visible markers, 7M rows, one linearisation point */
+/* Stereo geometry of corner inputs (marker_pose, correct_corners). */
+enum { FBUS_VIS_REFRACTIVE = 0,   /* flat-port Snell ray trace (vision.cpp:472-618)      */
+       FBUS_VIS_PINHOLE = 1,      /* 6x4 DLT (vision.cpp:395-466)                        */
+       FBUS_VIS_CORNERS3D = 2 };  /* corner positions given, no triangulation            */
 /* Covariance correction form. */
 enum { FBUS_COV_SIMPLE = 0,       /* (I-KH)P then symmetrise (MeasureUpdate.m:101-102)  */
        FBUS_COV_JOSEPH = 1 };     /* (I-KH)P(I-KH)' + K R K'                            */
@@ -82,6 +86,7 @@ typedef struct fbus_params {
     double  n_air, n_glass, n_water;            /* flat-port refraction (paramconfig.yml:31-42) */
     double  d_air, d_glass;
     double  port_normal[3];
+    double  marker_size;        /* side of the square marker [m] (vision.hpp:114: 0.28); corner-row model only */
 } fbus_params;
 
 /* Fills prm with the reference's constants for the given dialect
@@ -144,6 +149,21 @@ int fbus_ekf_correct_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* po
 /* 1 where the last correct() applied an update, 0 where it returned early. */
 int fbus_ekf_get_applied(fbus_ekf_t h, uint8_t* applied_host);
 
+/* ---- correct from stereo corners (north-star extension; NO reference counterpart) ------------ */
+/* The per-corner measurement model BASELINE.json's north_star describes, in the form SURVEY.md section 0.1 (B2)
+ * fixes: the marker's four corners are triangulated on the device (flat-port refractive or pin-hole, the
+ * arithmetic of fbus_ekf_marker_pose: vision.cpp:472-618 / :395-466) and each corner position is a 3-row
+ * measurement h_k = R_IL R'(P_m + R_m c_k - p - R P_IL), c_k = corner k in the marker frame of
+ * VISION::ComputeMarkerPose (vision.cpp:736-759), noise r_pos per row: 12 rows per marker, Jacobians of the
+ * reference's position rows (MeasureUpdate.m:72-73), same gain / injection / covariance algebra as correct().
+ * left/right: B x M x 8 normalised corner coordinates (FBUS_VIS_REFRACTIVE / FBUS_VIS_PINHOLE), or
+ * left = B x M x 12 corner positions (FBUS_VIS_CORNERS3D).  mode as in correct() (nearest = by corner 0).
+ * The reference has nothing to compare this with: it is validated against the fp64 oracle only. */
+int fbus_ekf_correct_corners(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right,
+                             int geometry, int mode, const uint8_t* skip);
+int fbus_ekf_correct_corners_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right,
+                                 int geometry, int mode, const uint8_t* skip);
+
 /* ---- one camera frame: K predicts then one correct -------------------------- */
 /* Replaces one iteration of the frame loop (matlab/FBUS_EKF.m:175-196;
  * filter.cpp:232-235): enqueues K per-sample predict launches followed by one
@@ -201,7 +221,6 @@ int fbus_ekf_imu_ema_dev(fbus_ekf_t h, int T, void* accel, void* gyro, int resta
  * `right` is ignored.  Outputs: pos n x 3, quat n x 4 (wxyz) -- exactly the arrays
  * correct() takes -- and, if not NULL, corners3d n x 12.  Uses the handle's
  * T_SC_left/right and refraction constants, dtype and stream. */
-enum { FBUS_VIS_REFRACTIVE = 0, FBUS_VIS_PINHOLE = 1, FBUS_VIS_CORNERS3D = 2 };
 int fbus_ekf_marker_pose(fbus_ekf_t h, int n, int geometry, const void* left, const void* right,
                          void* pos, void* quat, void* corners3d);
 int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left, const void* right,
@@ -209,7 +228,7 @@ int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left
 
 /* ---- measurement support (bench / profiling) -------------------------------- */
 enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N = 2, FBUS_KERNEL_MARKER_POSE = 3,
-       FBUS_KERNEL_FRAME = 4, FBUS_KERNEL_COUNT = 5 };
+       FBUS_KERNEL_FRAME = 4, FBUS_KERNEL_CORRECT_CORNERS = 5, FBUS_KERNEL_COUNT = 6 };
 /* When enabled (on >= 1), launches of the listed kernels are bracketed by HIP events on
  * the handle's stream; read() synchronises and returns the summed device time and launch
  * count since the last reset.  fbus_ekf_frame_dev uses ONE pair around its run of K

@@ -508,49 +508,19 @@ static void marker_rows(const fbo_state* s, const fbo_params* prm, int slot,
         r[3 + i] = cpp ? (yq[i] - hq[i]) : 0.0;
 }
 
-int fbo_correct(fbo_state* s, const fbo_params* prm, int M,
-                const int* ids, const double* pos, const double* quat, int mode)
+/* Dense update shared by the pose-row and corner-row measurement models, exactly the reference's
+ * algebra: S = H P H' + R, K = P H' inv(S) (Matlab) / K' = ldlt(S).solve(H P) (C++), dx = K r,
+ * inject, P = (I - K H) P [Joseph option], symmetrise.  Rd = per-row measurement noise. */
+static void dense_update(fbo_state* s, const fbo_params* prm, int m, const double* H, const double* r,
+                         const double* Rd)
 {
     const int n = prm->nstate;
     const int cpp = (prm->dialect == FBO_DIALECT_CPP);
-    int sel[FBO_MAX_VISIBLE], slot[FBO_MAX_VISIBLE], nsel = 0;
-    if (M > FBO_MAX_VISIBLE) M = FBO_MAX_VISIBLE;
-
-    if (mode == FBO_MODE_NEAREST) {
-        /* MeasureUpdate.m:51-60 ; filter.cpp:639-664 */
-        int min_i = -1, prev_i = -1;
-        double min_d = 10.0, prev_d = 0.0;
-        for (int i = 0; i < M; ++i) {
-            if (ids[i] < 0) continue;       /* absent slot of the batched interface */
-            double dist = norm3(pos + 3 * i);
-            if (dist < min_d) { min_d = dist; min_i = i; }
-            if (cpp && ids[i] == s->prev_id) { prev_d = dist; prev_i = i; }
-        }
-        if (min_i < 0) return 0;
-        if (cpp && fabs(prev_d - min_d) < prm->switch_thres && prev_d != 0.0) min_i = prev_i;
-        int k = find_marker(prm, ids[min_i]);
-        if (k < 0) return 0;                /* filter.cpp:671-673 */
-        if (cpp) s->prev_id = ids[min_i];   /* filter.cpp:675 */
-        sel[0] = min_i; slot[0] = k; nsel = 1;
-    } else {
-        for (int i = 0; i < M; ++i) {
-            if (ids[i] < 0) continue;
-            int k = find_marker(prm, ids[i]);
-            if (k < 0) continue;
-            sel[nsel] = i; slot[nsel] = k; ++nsel;
-        }
-        if (nsel == 0) return 0;
-    }
-
-    const int m = 7 * nsel;
-    double H[FBO_MMAX * FBO_NMAX], r[FBO_MMAX], HP[FBO_MMAX * FBO_NMAX], S[FBO_MMAX * FBO_MMAX], K[FBO_NMAX * FBO_MMAX];
-    for (int j = 0; j < nsel; ++j)
-        marker_rows(s, prm, slot[j], pos + 3 * sel[j], quat + 4 * sel[j], H + 7 * j * n, r + 7 * j);
-
+    double HP[FBO_MMAX * FBO_NMAX], S[FBO_MMAX * FBO_MMAX], K[FBO_NMAX * FBO_MMAX];
     /* S = H P H' + Rm    MeasureUpdate.m:84 ; filter.cpp:709-710 */
     mat_mul(H, s->P, HP, m, n, n);
     mat_mul_bt(HP, H, S, m, n, m);
-    for (int j = 0; j < m; ++j) S[j * m + j] += ((j % 7) < 3) ? prm->r_pos : prm->r_quat;
+    for (int j = 0; j < m; ++j) S[j * m + j] += Rd[j];
     if (!cpp) {                             /* K = P H' inv(S) */
         double PHt[FBO_NMAX * FBO_MMAX];
         mat_mul_bt(s->P, H, PHt, n, n, m);
@@ -588,15 +558,156 @@ int fbo_correct(fbo_state* s, const fbo_params* prm, int M,
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) {
                 double acc = 0;
-                for (int k = 0; k < m; ++k)
-                    acc += K[i * m + k] * (((k % 7) < 3) ? prm->r_pos : prm->r_quat) * K[j * m + k];
+                for (int k = 0; k < m; ++k) acc += K[i * m + k] * Rd[k] * K[j * m + k];
                 Pn[i * n + j] = T[i * n + j] + acc;
             }
     }
     symmetrise(Pn, n);
     memcpy(s->P, Pn, sizeof(double) * n * n);
     /* rotateMat / rotmatI2G deliberately NOT refreshed (both dialects) */
+}
+
+int fbo_correct(fbo_state* s, const fbo_params* prm, int M,
+                const int* ids, const double* pos, const double* quat, int mode)
+{
+    const int n = prm->nstate;
+    const int cpp = (prm->dialect == FBO_DIALECT_CPP);
+    int sel[FBO_MAX_VISIBLE], slot[FBO_MAX_VISIBLE], nsel = 0;
+    if (M > FBO_MAX_VISIBLE) M = FBO_MAX_VISIBLE;
+
+    if (mode == FBO_MODE_NEAREST) {
+        /* MeasureUpdate.m:51-60 ; filter.cpp:639-664 */
+        int min_i = -1, prev_i = -1;
+        double min_d = 10.0, prev_d = 0.0;
+        for (int i = 0; i < M; ++i) {
+            if (ids[i] < 0) continue;       /* absent slot of the batched interface */
+            double dist = norm3(pos + 3 * i);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (cpp && ids[i] == s->prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i < 0) return 0;
+        if (cpp && fabs(prev_d - min_d) < prm->switch_thres && prev_d != 0.0) min_i = prev_i;
+        int k = find_marker(prm, ids[min_i]);
+        if (k < 0) return 0;                /* filter.cpp:671-673 */
+        if (cpp) s->prev_id = ids[min_i];   /* filter.cpp:675 */
+        sel[0] = min_i; slot[0] = k; nsel = 1;
+    } else {
+        for (int i = 0; i < M; ++i) {
+            if (ids[i] < 0) continue;
+            int k = find_marker(prm, ids[i]);
+            if (k < 0) continue;
+            sel[nsel] = i; slot[nsel] = k; ++nsel;
+        }
+        if (nsel == 0) return 0;
+    }
+
+    const int m = 7 * nsel;
+    double H[FBO_MMAX * FBO_NMAX], r[FBO_MMAX], Rd[FBO_MMAX];
+    for (int j = 0; j < nsel; ++j)
+        marker_rows(s, prm, slot[j], pos + 3 * sel[j], quat + 4 * sel[j], H + 7 * j * n, r + 7 * j);
+    for (int j = 0; j < m; ++j) Rd[j] = ((j % 7) < 3) ? prm->r_pos : prm->r_quat;
+    dense_update(s, prm, m, H, r, Rd);
     return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* corner-row measurement model (north-star extension, NO reference    */
+/* counterpart: parity unpinned by construction)                       */
+/* ------------------------------------------------------------------ */
+/* Measurement = the four triangulated corner positions of a marker in the left camera frame (3 rows per
+ * corner, 12 per marker).  Corner k sits at c_k = {(0,0,0),(0,s,0),(s,s,0),(s,0,0)} in the marker frame -- the
+ * frame VISION::ComputeMarkerPose builds (vision.cpp:736-759: origin = corner 0, axes along corner0->corner3 and
+ * corner0->corner1; verified on the recordings).  h_k = R_IL R' (P_m + R_m c_k - p - R P_IL), the Jacobian has
+ * the structure of the reference's position rows (MeasureUpdate.m:72-73) with the corner in place of the marker
+ * origin; noise r_pos per row.  corners: M x 12. */
+int fbo_correct_corners(fbo_state* s, const fbo_params* prm, int M, const int* ids, const double* corners,
+                        double size, int mode)
+{
+    const int n = prm->nstate;
+    const int cpp = (prm->dialect == FBO_DIALECT_CPP);
+    int sel[FBO_MAX_VISIBLE], slot[FBO_MAX_VISIBLE], nsel = 0;
+    if (M > FBO_MAX_VISIBLE) M = FBO_MAX_VISIBLE;
+    if (mode == FBO_MODE_NEAREST) {                 /* same selection rule as fbo_correct, on corner 0 */
+        int min_i = -1, prev_i = -1;
+        double min_d = 10.0, prev_d = 0.0;
+        for (int i = 0; i < M; ++i) {
+            if (ids[i] < 0) continue;
+            double dist = norm3(corners + 12 * i);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (cpp && ids[i] == s->prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i < 0) return 0;
+        if (cpp && fabs(prev_d - min_d) < prm->switch_thres && prev_d != 0.0) min_i = prev_i;
+        int k = find_marker(prm, ids[min_i]);
+        if (k < 0) return 0;
+        if (cpp) s->prev_id = ids[min_i];
+        sel[0] = min_i; slot[0] = k; nsel = 1;
+    } else {
+        for (int i = 0; i < M; ++i) {
+            if (ids[i] < 0) continue;
+            int k = find_marker(prm, ids[i]);
+            if (k < 0) continue;
+            sel[nsel] = i; slot[nsel] = k; ++nsel;
+        }
+        if (nsel == 0) return 0;
+    }
+    const int m = 12 * nsel;
+    double H[FBO_MMAX * FBO_NMAX], r[FBO_MMAX], Rd[FBO_MMAX];
+    memset(H, 0, sizeof(double) * m * n);
+    const double ck[4][3] = { { 0, 0, 0 }, { 0, size, 0 }, { size, size, 0 }, { size, 0, 0 } };
+    for (int j = 0; j < nsel; ++j) {
+        double Rm[9];
+        fbo_quat_to_rotmat(prm->marker_quat[slot[j]], Rm);
+        for (int k = 0; k < 4; ++k) {
+            double cw[3], RP[3], d[3], dm[3], t[3], hp[3], u[3], ux[9], Bm[9];
+            mat3_vec(Rm, ck[k], cw);
+            for (int i = 0; i < 3; ++i) cw[i] += prm->marker_pos[slot[j]][i];      /* corner in the world */
+            mat3_vec(s->R, prm->P_IL, RP);
+            for (int i = 0; i < 3; ++i) { dm[i] = cw[i] - s->p[i]; d[i] = dm[i] - RP[i]; }
+            mat3t_vec(s->R, d, t);
+            mat3_vec(prm->R_IL, t, hp);
+            mat3t_vec(s->R, dm, u);
+            fbo_skew(u, ux);
+            mat_mul(prm->R_IL, ux, Bm, 3, 3, 3);
+            double* Hk = H + (size_t)(12 * j + 3 * k) * n;
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) {
+                    double acc = 0;
+                    for (int c = 0; c < 3; ++c) acc += prm->R_IL[3 * a + c] * s->R[3 * b + c];
+                    Hk[a * n + b] = -acc;
+                    Hk[a * n + 6 + b] = Bm[3 * a + b];
+                }
+                r[12 * j + 3 * k + a] = corners[12 * sel[j] + 3 * k + a] - hp[a];
+                Rd[12 * j + 3 * k + a] = prm->r_pos;
+            }
+        }
+    }
+    dense_update(s, prm, m, H, r, Rd);
+    return 1;
+}
+
+void fbo_correct_corners_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                               int M, const int* ids, const double* corners, double size, int mode, int* applied)
+{
+    const int n = prm->nstate;
+    fbo_state s;
+    for (int b = 0; b < B; ++b) {
+        int pv = prev ? prev[b] : 0;
+        memset(&s, 0, sizeof(s));
+        memcpy(s.p, nominal + 19 * (size_t)b, 3 * sizeof(double));       memcpy(s.v, nominal + 19 * (size_t)b + 3, 3 * sizeof(double));
+        memcpy(s.q, nominal + 19 * (size_t)b + 6, 4 * sizeof(double));   memcpy(s.ba, nominal + 19 * (size_t)b + 10, 3 * sizeof(double));
+        memcpy(s.bg, nominal + 19 * (size_t)b + 13, 3 * sizeof(double)); memcpy(s.g, nominal + 19 * (size_t)b + 16, 3 * sizeof(double));
+        memcpy(s.R, rot + 9 * (size_t)b, 9 * sizeof(double));
+        memcpy(s.P, P + (size_t)n * n * b, sizeof(double) * n * n);
+        s.prev_id = pv;
+        int ok = fbo_correct_corners(&s, prm, M, ids + (size_t)M * b, corners + 12 * (size_t)M * b, size, mode);
+        if (applied) applied[b] = ok;
+        memcpy(nominal + 19 * (size_t)b, s.p, 3 * sizeof(double));       memcpy(nominal + 19 * (size_t)b + 3, s.v, 3 * sizeof(double));
+        memcpy(nominal + 19 * (size_t)b + 6, s.q, 4 * sizeof(double));   memcpy(nominal + 19 * (size_t)b + 10, s.ba, 3 * sizeof(double));
+        memcpy(nominal + 19 * (size_t)b + 13, s.bg, 3 * sizeof(double)); memcpy(nominal + 19 * (size_t)b + 16, s.g, 3 * sizeof(double));
+        memcpy(P + (size_t)n * n * b, s.P, sizeof(double) * n * n);
+        if (prev) prev[b] = s.prev_id;
+    }
 }
 
 /* ------------------------------------------------------------------ */

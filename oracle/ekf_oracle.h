@@ -37,7 +37,7 @@ extern "C" {
 #define FBO_NMAX 18
 #define FBO_MAX_MARKERS 32      /* map entries */
 #define FBO_MAX_VISIBLE 16      /* markers per frame */
-#define FBO_MMAX (7 * FBO_MAX_VISIBLE)   /* stacked measurement rows */
+#define FBO_MMAX (12 * FBO_MAX_VISIBLE)  /* stacked measurement rows (7 per marker pose, 12 per marker corners) */
 
 enum { FBO_DIALECT_MATLAB = 0, FBO_DIALECT_CPP = 1 };
 enum { FBO_MODE_NEAREST = 0,    /* reference behaviour: one 7-row update, nearest marker */
@@ -106,6 +106,12 @@ void fbo_predict_batch(int B, double* nominal, double* rot, double* P, int* prev
 void fbo_correct_batch(int B, double* nominal, double* rot, double* P, int* prev,
                        const fbo_params* prm, int M, const int* ids, const double* pos,
                        const double* quat, int mode, int* applied, int nthreads);
+
+/* ---- corner-row measurement model: north-star extension, no reference counterpart (parity unpinned) ---- */
+int  fbo_correct_corners(fbo_state* s, const fbo_params* prm, int M, const int* ids, const double* corners /*Mx12*/,
+                         double size, int mode);
+void fbo_correct_corners_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                               int M, const int* ids, const double* corners, double size, int mode, int* applied);
 
 /* ---- init / reset / front door ---- */
 void fbo_init_gravity_bias(int T, const double* accel, const double* gyro, double g[3], double bg[3]);

@@ -68,6 +68,8 @@ def load(native=False):
                                     ip, dp, dp, C.c_int, C.c_int]
     lib.fbo_schedule_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, ip, C.c_int, dp, dp, dp,
                                        C.c_int, ip, dp, dp, C.c_int, C.c_int]
+    lib.fbo_correct_corners_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, ip, dp,
+                                              C.c_double, C.c_int, ip]
     u8 = C.POINTER(C.c_ubyte)
     lib.fbo_init_gravity_bias.argtypes = [C.c_int, dp, dp, dp, dp]
     lib.fbo_pose_init_batch.argtypes = [C.c_int, dp, dp, C.POINTER(FboParams), C.c_int, ip, dp, dp, C.c_int, C.c_double,
@@ -144,6 +146,17 @@ class Oracle:
         self.lib.fbo_frame_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), K, _dp(accel),
                                  _dp(gyro), _dp(dt), M, _ip(ids), _dp(pos), _dp(quat), mode, self.nthreads)
 
+
+    def correct_corners(self, nominal, rot, P, prev, ids, corners, size, mode=NEAREST):
+        """corner-row model (no reference counterpart): corners (B, M, 4, 3) triangulated positions"""
+        B = nominal.shape[0]
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        corners = np.ascontiguousarray(corners, np.float64).reshape(B, M, 12)
+        applied = np.zeros(B, np.int32)
+        self.lib.fbo_correct_corners_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), M, _ip(ids),
+                                           _dp(corners), float(size), mode, _ip(applied))
+        return applied
 
     def schedule(self, nominal, rot, P, prev, Ks, reps, accel, gyro, dt, ids, pos, quat, mode=NEAREST):
         """reps x (frames of Ks[f] predicts + one correct) per filter inside ONE thread team (CPU baseline)."""

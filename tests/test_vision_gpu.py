@@ -142,3 +142,56 @@ def test_large_batch_properties():
     assert np.array_equal(pos[:4096], pos[-4096:])                    # deterministic across the batch
     side = np.linalg.norm(c3[:, 1] - c3[:, 0], axis=1)
     assert 0.1 < np.median(side) < 0.5                                # the 0.28 m marker, noisy corners
+
+
+@pytest.mark.parametrize("dtype,mult", [(64, 1e-4), (32, 10.0)])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_correct_from_stereo_corners_matches_oracle(dialect, mode, dtype, mult):
+    """correct_corners (north-star extension: triangulated corner positions as 3-row measurements, 12 rows per
+    marker).  The reference has no counterpart -> parity unpinned by construction; validated against the fp64
+    oracle chain (vision_oracle triangulation -> fbo_correct_corners).  fp32: the triangulated corners carry
+    ~2e-6 m of rounding, so the bound is 10x the single-step one; fp64 is tight."""
+    from fbus_ekf import synth
+    from replay_ref import OracleEngine
+    from util import COV_TOL, STATE_TOL, cov_rel_err, state_rel_err
+    B, M, size = 256, 3, 0.117
+    prm = capi.default_params(dialect)
+    prm.marker_size = size
+    rng = np.random.default_rng(7)
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    nom, rot, P, prev = synth.initial_state(300, 300 + B, list(prm.p0_diag), 18, mixed_cov=True)
+    nom, rot, P = r32(nom), r32(rot), r32(P)
+    ids, _, _ = synth.marker_frame(300, 300 + B, 0, M, nom, prm)
+    ids[0] = -1
+    ids[1, 0] = 9
+    d = np.load(os.path.join(GOLD, "vision_water.npz"))["corners"]
+    base = d[rng.integers(0, len(d), B * M)]
+    left = r32(base[:, 2:10] + rng.normal(0, 0.003, (B * M, 8))).reshape(B, M, 8)
+    right = r32(base[:, 10:18] + rng.normal(0, 0.003, (B * M, 8))).reshape(B, M, 8)
+    p = oc.vision_params()
+    corners = np.array([oc.refraction_triangulate(p, l, r) for l, r in zip(left.reshape(-1, 8), right.reshape(-1, 8))])
+    corners = corners.reshape(B, M, 4, 3)
+    # place every filter so that its first VALID marker is seen roughly where the corners are: modest innovations
+    from fbus_ekf import replay
+    for b in range(B):
+        m = next((k for k in range(M) if ids[b, k] >= 0 and ids[b, k] != 9), None)
+        if m is None:
+            continue
+        pos, quat, _ = oc.marker_pose(corners[b, m])
+        pp, qq, RR = replay.pose_from_marker(np.concatenate([[ids[b, m]], pos, quat]), prm)
+        nom[b, 0:3], nom[b, 6:10], rot[b] = pp + rng.normal(0, 0.005, 3), qq, RR.ravel()
+    nom, rot = r32(nom), r32(rot)
+    with BatchedFilter(B, prm, dtype=dtype) as flt:
+        flt.set_state(nom, rot, P, prev)
+        flt.correct_corners(ids, left, right, capi.VIS_REFRACTIVE, mode)
+        g = flt.get_state()
+        ap = flt.applied()
+    eng = OracleEngine(B, dialect, 18)
+    eng.set_state(nom, rot, P, prev)
+    ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids, corners, size, mode)
+    assert (ap == ok).all() and ok[0] == 0 and ok[2:].all()
+    assert (g[3] == eng.prev).all()
+    assert state_rel_err(g[0], eng.nominal, eng.P)[0] <= STATE_TOL * mult
+    assert cov_rel_err(g[2], eng.P) <= COV_TOL * min(mult, 1.0)
+    assert not np.array_equal(g[0][2:], nom[2:].astype(g[0].dtype))           # it did update
