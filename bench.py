@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay each bench step (23 launches) from a captured HIP graph (launch-bound small batches); "
+                         "the per-kernel HIP-event timing then comes from a short eager pass after the timed region")
     ap.add_argument("--kernel-timing", choices=["on", "off"], default="on",
                     help="bracket every launch with HIP events inside the timed region (feeds `roofline`)")
     return ap.parse_args()
@@ -188,6 +191,10 @@ def main():
             dist.barrier()
 
     flt.timing_enable(args.kernel_timing == "on", stride=TIMING_STRIDE)
+    if args.graphs:
+        graph_ids = [flt.graph_capture(lambda j=j: bench_step(j)) for j in range(POOL)]
+        eager_step = bench_step
+        bench_step = lambda i: flt.graph_launch(graph_ids[i % POOL])
     for i in range(args.warmup):
         bench_step(i)
     torch.cuda.synchronize()
@@ -205,6 +212,11 @@ def main():
     ctl_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev
     elapsed = shard.max_over_ranks(elapsed, dist, world, ctl_dev)
 
+    if args.graphs and args.kernel_timing == "on":          # events cannot live inside a graph: short eager pass
+        flt.timing_reset()
+        for i in range(4):
+            eager_step(i)
+        torch.cuda.synchronize()
     pred_ms, pred_n = flt.timing_read(capi.KERNEL_PREDICT)
     corr_ms, corr_n = flt.timing_read(capi.KERNEL_CORRECT)
     flt.timing_enable(False)
@@ -255,7 +267,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch {B} filters/GPU, 200 Hz IMU + 30 Hz stereo (7/7/6 predicts per correct), "
                                    f"{M} markers/frame, N=18, {args.dialect} dialect, correct mode {args.mode}, "
-                                   "per-call API (one launch per EKF step)",
+                                   "per-call API (one launch per EKF step)" + (", replayed from HIP graphs" if args.graphs else ""),
                        "batch_per_gpu": B, "markers": M, "ekf_steps_per_bench_step": STEPS_PER_BENCH_STEP,
                        "parallelism": f"independent filter shards x{world}, one RCCL gather at the end"},
             "roofline": {"bound": "hbm", "kernel": "predict_kernel<float,18>", "achieved": achieved,

@@ -694,6 +694,8 @@ struct fbus_ekf {
     struct EvPair { hipEvent_t a, b; int kind; int count; };
     bool timing_suspended = false;   // frame_dev brackets its run of predicts with ONE pair
     int timing_stride = 1;           // frame_dev: bracket every stride-th frame only
+    bool capturing = false;          // between graph_begin and graph_end: no events, no host syncs
+    std::vector<hipGraphExec_t> graphs;
     int64_t frame_count = 0;
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
@@ -768,7 +770,7 @@ int flush_events(fbus_ekf_t h)
 // returns the index of the event pair to close after the launch, or -1
 int timing_begin(fbus_ekf_t h, int kind, int count = 1)
 {
-    if (!h->timing || h->timing_suspended) return -1;
+    if (!h->timing || h->timing_suspended || h->capturing) return -1;
     if (h->ev_used == h->ev_pool.size()) {
         if (h->ev_pool.size() >= 8192) {
             if (flush_events(h) != FBUS_OK) return -1;
@@ -1179,6 +1181,7 @@ int fbus_ekf_destroy(fbus_ekf_t h)
     if (!h) return FBUS_OK;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& p : h->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto g : h->graphs) if (g) (void)hipGraphExecDestroy(g);
     for (int i = 0; i < 6; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     if (h->own_recs && h->recs) (void)hipFree(h->recs);
     if (h->d_applied) (void)hipFree(h->d_applied);
@@ -1569,6 +1572,53 @@ int fbus_ekf_imu_ema(fbus_ekf_t h, int T, void* accel, void* gyro, int restart)
     HIP_TRY(h, hipMemcpyAsync(accel, h->stage[0], bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(gyro, h->stage[1], bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_graph_begin(fbus_ekf_t h)
+{
+    DeviceGuard guard_(h);
+    if (!h) return FBUS_ERR_INVALID;
+    if (h->capturing) return fail(h, FBUS_ERR_INVALID, "graph_begin: already capturing");
+    const int rc = flush_events(h);
+    if (rc != FBUS_OK) return rc;
+    HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;
+    return FBUS_OK;
+}
+
+int fbus_ekf_graph_end(fbus_ekf_t h, int* graph_id)
+{
+    DeviceGuard guard_(h);
+    if (!h || !graph_id) return FBUS_ERR_INVALID;
+    if (!h->capturing) return fail(h, FBUS_ERR_INVALID, "graph_end: not capturing");
+    h->capturing = false;
+    hipGraph_t g = nullptr;
+    HIP_TRY(h, hipStreamEndCapture(h->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(h, FBUS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    h->graphs.push_back(ex);
+    *graph_id = (int)h->graphs.size() - 1;
+    return FBUS_OK;
+}
+
+int fbus_ekf_graph_launch(fbus_ekf_t h, int graph_id)
+{
+    DeviceGuard guard_(h);
+    if (!h || graph_id < 0 || graph_id >= (int)h->graphs.size() || !h->graphs[graph_id]) return FBUS_ERR_INVALID;
+    HIP_TRY(h, hipGraphLaunch(h->graphs[graph_id], h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_graph_destroy(fbus_ekf_t h, int graph_id)
+{
+    DeviceGuard guard_(h);
+    if (!h || graph_id < 0 || graph_id >= (int)h->graphs.size() || !h->graphs[graph_id]) return FBUS_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipGraphExecDestroy(h->graphs[graph_id]));
+    h->graphs[graph_id] = nullptr;
     return FBUS_OK;
 }
 

@@ -109,6 +109,10 @@ def load_library():
         "fbus_ekf_imu_ema_dev": ([H, C.c_int, vp, vp, C.c_int], C.c_int),
         "fbus_ekf_marker_pose": ([H, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "fbus_ekf_marker_pose_dev": ([H, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
+        "fbus_ekf_graph_begin": ([H], C.c_int),
+        "fbus_ekf_graph_end": ([H, C.POINTER(C.c_int)], C.c_int),
+        "fbus_ekf_graph_launch": ([H, C.c_int], C.c_int),
+        "fbus_ekf_graph_destroy": ([H, C.c_int], C.c_int),
         "fbus_ekf_timing_enable": ([H, C.c_int], C.c_int),
         "fbus_ekf_timing_reset": ([H], C.c_int),
         "fbus_ekf_timing_read": ([H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),

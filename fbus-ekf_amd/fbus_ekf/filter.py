@@ -284,6 +284,22 @@ class BatchedFilter:
         self._check(rc, "marker_pose")
         return (pos, quat, c3) if want_corners else (pos, quat)
 
+    # ---- HIP graphs ------------------------------------------------------------------------
+    def graph_capture(self, fn):
+        """Runs fn() (device-array calls on this filter only) under stream capture; returns a graph id."""
+        self._check(self._lib.fbus_ekf_graph_begin(self._h), "graph_begin")
+        try:
+            fn()
+        finally:
+            gid = C.c_int(-1)
+            rc = self._lib.fbus_ekf_graph_end(self._h, C.byref(gid))
+        self._check(rc, "graph_end")
+        self._graph_keep = getattr(self, "_graph_keep", []) + list(self._keep)   # captured pointers must stay alive
+        return gid.value
+
+    def graph_launch(self, gid):
+        self._check(self._lib.fbus_ekf_graph_launch(self._h, gid), "graph_launch")
+
     # ---- timing -------------------------------------------------------------------------
     def timing_enable(self, on=True, stride=1):
         """stride: frame() brackets only every stride-th frame with HIP events"""

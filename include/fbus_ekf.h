@@ -226,6 +226,17 @@ int fbus_ekf_marker_pose(fbus_ekf_t h, int n, int geometry, const void* left, co
 int fbus_ekf_marker_pose_dev(fbus_ekf_t h, int n, int geometry, const void* left, const void* right,
                              void* pos, void* quat, void* corners3d);
 
+/* ---- HIP graphs -------------------------------------------------------------- */
+/* Capture any sequence of *_dev calls on this handle once (between graph_begin and graph_end: the calls are
+ * recorded, not executed; no host-pointer entry points, no sync, no timing inside) and replay it with ONE
+ * launch.  The captured launches keep the device pointers they were given: replay reads the same input
+ * buffers (refill them in place between replays).  For launch-bound inner loops: small batches, long runs of
+ * per-step launches.  New: the reference runs one filter on one CPU thread and has nothing comparable. */
+int fbus_ekf_graph_begin(fbus_ekf_t h);
+int fbus_ekf_graph_end(fbus_ekf_t h, int* graph_id);
+int fbus_ekf_graph_launch(fbus_ekf_t h, int graph_id);
+int fbus_ekf_graph_destroy(fbus_ekf_t h, int graph_id);
+
 /* ---- measurement support (bench / profiling) -------------------------------- */
 enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N = 2, FBUS_KERNEL_MARKER_POSE = 3,
        FBUS_KERNEL_FRAME = 4, FBUS_KERNEL_CORRECT_CORNERS = 5, FBUS_KERNEL_COUNT = 6 };

@@ -476,3 +476,28 @@ def test_device_state_io_records_aliasing_and_checkpoint_resume():
         for k in range(4):
             eng.predict(acc[k], gyr[k], dt[k])
         assert state_rel_err(got[0], eng.nominal, eng.P)[0] <= STATE_TOL and cov_rel_err(got[2], eng.P) <= COV_TOL
+
+
+def test_hip_graph_replay_equals_eager_launches():
+    """a captured frame (7 predict launches + 1 correct launch) replayed from a HIP graph == the eager launches"""
+    import torch
+    B, M, K = 4096, 4, 7
+    prm, nom, rot, P, prev = _batch(B, 0, 18)
+    acc, gyr = _imu(0, B, 0, K, nom)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d = [f32(acc), f32(gyr), f32(np.full(K, DT[0])), torch.from_numpy(ids).to(dev), f32(pos), f32(quat)]
+    with BatchedFilter(B, prm) as a, BatchedFilter(B, prm) as b:
+        a.set_state(nom, rot, P, prev)
+        b.set_state(nom, rot, P, prev)
+        gid = b.graph_capture(lambda: b.frame(d[0], d[1], d[2], d[3], d[4], d[5], 1))
+        untouched = b.get_state()
+        assert np.array_equal(untouched[0], nom.astype(np.float32))          # capture records, it does not execute
+        for _ in range(3):
+            a.frame(d[0], d[1], d[2], d[3], d[4], d[5], 1)
+            b.graph_launch(gid)
+        a.sync(); b.sync()
+        sa, sb = a.get_state(), b.get_state()
+        assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
+        assert (a.applied() == b.applied()).all()
