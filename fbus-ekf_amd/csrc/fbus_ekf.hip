@@ -615,7 +615,7 @@ void rotmat_to_quat(const double R[9], double q[4])
 }
 
 struct HostConst {
-    double R_IL[9], P_IL[3], Q_IL[4];
+    double R_IL[9], P_IL[3], Q_IL[4], CL[16];
     std::vector<double> mk;             // n_markers x MK_STRIDE
     std::vector<short> id2slot;
 };
@@ -643,6 +643,7 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
                              x, -w,  z, -y,
                              y, -z, -w,  x,
                              z,  y, -x, -w };
+    std::memcpy(hc.CL, LL2, sizeof(LL2));
     for (int k = 0; k < prm.n_markers; ++k) {
         const int id = prm.marker_id[k];
         if (id < 0 || id > FBUS_MAX_MARKER_ID) { err = "marker id out of range"; return false; }
@@ -652,17 +653,6 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
         double q[4];
         rotmat_to_quat(prm.marker_rot[k], q);
         for (int i = 0; i < 4; ++i) m[3 + i] = q[i];
-        // C = Rq(Qm) * Lq(Q_IL) * L2   (MeasureUpdate.m:74)
-        const double Rq[16] = { q[0], -q[1], -q[2], -q[3],
-                                q[1],  q[0],  q[3], -q[2],
-                                q[2], -q[3],  q[0],  q[1],
-                                q[3],  q[2], -q[1],  q[0] };
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) {
-                double acc = 0;
-                for (int l = 0; l < 4; ++l) acc += Rq[4 * i + l] * LL2[4 * l + j];
-                m[7 + 4 * i + j] = acc;
-            }
     }
     return true;
 }
@@ -746,6 +736,7 @@ DevConst<T> make_dc(const fbus_ekf* h)
     for (int i = 0; i < 9; ++i) dc.R_IL[i] = (T)h->hc.R_IL[i];
     for (int i = 0; i < 3; ++i) dc.P_IL[i] = (T)h->hc.P_IL[i];
     for (int i = 0; i < 4; ++i) dc.Q_IL[i] = (T)h->hc.Q_IL[i];
+    for (int i = 0; i < 16; ++i) dc.CL[i] = (T)h->hc.CL[i];
     dc.switch_thres = (T)h->prm.switch_thres;
     dc.cov_form = h->prm.cov_form;
     dc.mk = (const T*)h->d_mk;
