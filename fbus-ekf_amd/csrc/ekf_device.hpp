@@ -47,6 +47,11 @@ struct Lay {
     static constexpr int NREC = OFF_PREV + 1;
 };
 
+// number of leading covariance elements predict may change (the rest is invariant under ImuUpdate; see the
+// storage order below)
+template <int N>
+__host__ __device__ constexpr int cov_variant_count() { return N == 18 ? 132 : N * (N + 1) / 2; }
+
 template <typename T, int N>
 struct Rec {
     static constexpr int EPC = 16 / (int)sizeof(T);                       // elements per 16-byte chunk
@@ -57,6 +62,9 @@ struct Rec {
     static constexpr int CH_KIN = (Lay<N>::NKIN + EPC - 1) / EPC;         // chunks predict must store back
     static constexpr int CH_PQ = (7 + EPC - 1) / EPC;                     // chunks holding p and q
     static constexpr int NCOVP = NRECP - Lay<N>::NNOM;                    // P + prev + padding
+    // chunks [CH_NOM, CH_VAR_END) hold every covariance element predict can change (all of them unless N = 18)
+    static constexpr int CH_VAR_END = (cov_variant_count<N>() % EPC == 0 && N == 18)
+                                          ? CH_NOM + cov_variant_count<N>() / EPC : NCH;
     static_assert(Lay<N>::NNOM % EPC == 0 && Lay<N>::NPQR % EPC == 0, "groups must end on chunk boundaries");
 };
 
@@ -65,11 +73,17 @@ template <> struct Vec16<float>  { using type = float4;  };
 template <> struct Vec16<double> { using type = double2; };
 
 // Packed storage order of the upper triangle.
-//  odd N : plain row-major upper triangle.
-//  even N: "pair-aligned rows" -- every row is stored from an EVEN column on, so that (P(i,c), P(i,c+1)),
-//          c even, are neighbours at an even offset and one v_pk_fma_f32 updates both: even rows start at
-//          their diagonal, odd rows at column i+1, and the N/2 diagonal elements of the odd rows are
-//          collected at the end.  Still exactly N(N+1)/2 elements, no duplicates.
+//  odd N  : plain row-major upper triangle.
+//  even N : "pair-aligned rows" -- every row is stored from an EVEN column on, so that (P(i,c), P(i,c+1)),
+//           c even, are neighbours at an even offset and one v_pk_fma_f32 updates both: even rows start at
+//           their diagonal, odd rows at column i+1, the diagonals of the odd rows are collected behind the rows.
+//  N = 18 : the same idea, plus: the elements ImuUpdate never changes come LAST.  F's rows for ba, bg, g are
+//           identity rows (ImuUpdate.m:63-69), so P(i,j) with 9 <= i < j and the gravity diagonals are
+//           invariant under predict (only the ba/bg diagonals get + Q): 39 of the 171 elements.  Order:
+//             [rows 0..8 pair-aligned (122)] [diagonals of rows 1,3,5,7 and 9..14 (10)]   <- 132 = 33 chunks, written by predict
+//             [rows 9..16 off-diagonal pairs, (16,16)] [(10,11) (12,13) (14,15) (15,15) (17,17)] <- 39, never written by predict
+//           predict therefore stores 33 of the 43 covariance chunks (-160 B per step, -10 % traffic).
+//  Always exactly N(N+1)/2 elements, no duplicates.
 template <int N>
 __host__ __device__ constexpr int pair_cols(int i) { return (i & 1) ? (N - i - 1) : (N - i); }
 template <int N>
@@ -79,15 +93,46 @@ __host__ __device__ constexpr int row_base(int i)
     for (int r = 0; r < i; ++r) s += pair_cols<N>(r);
     return s;
 }
+__host__ __device__ constexpr int pidx18(int i, int j)          // i <= j, N = 18
+{
+    if (i <= 8) return ((i & 1) && j == i) ? 122 + (i - 1) / 2 : row_base<18>(i) + (j - i - (i & 1));
+    if (j == i) return (i <= 14) ? 126 + (i - 9) : (i == 15 ? 169 : (i == 16 ? 164 : 170));
+    switch (i) {
+        case 9:  return 132 + (j - 10);
+        case 10: return (j == 11) ? 166 : 140 + (j - 12);
+        case 11: return 146 + (j - 12);
+        case 12: return (j == 13) ? 167 : 152 + (j - 14);
+        case 13: return 156 + (j - 14);
+        case 14: return (j == 15) ? 168 : 160 + (j - 16);
+        case 15: return 162 + (j - 16);
+        default: return 165;                                    // (16,17)
+    }
+}
 template <int N>
 __host__ __device__ constexpr int pidx_ord(int i, int j)        // i <= j
 {
+    if (N == 18) return pidx18(i, j);
     if (N % 2) return i * N - (i * (i - 1)) / 2 + (j - i);
     if ((i & 1) && j == i) return (N * (N + 1) / 2 - N / 2) + (i - 1) / 2;
     return row_base<N>(i) + (j - i - (i & 1));
 }
 template <int N>
 __host__ __device__ constexpr int pidx(int i, int j) { return (i <= j) ? pidx_ord<N>(i, j) : pidx_ord<N>(j, i); }
+// compile-time proof that the N = 18 order is a bijection onto 0..170 with the variant elements first
+__host__ __device__ constexpr bool pidx18_ok()
+{
+    bool seen[171] = {};
+    for (int i = 0; i < 18; ++i)
+        for (int j = i; j < 18; ++j) {
+            const int k = pidx18(i, j);
+            if (k < 0 || k >= 171 || seen[k]) return false;
+            seen[k] = true;
+            const bool invariant = (i >= 9) && !(i == j && i <= 14);
+            if (invariant != (k >= 132)) return false;
+        }
+    return true;
+}
+static_assert(pidx18_ok(), "N = 18 covariance order must be a bijection with the predict-invariant elements last");
 // (P(r,c), P(r,c+1)) with r <= c is an aligned storage pair
 template <int N>
 __host__ __device__ constexpr bool is_pair(int r, int c)
@@ -414,12 +459,16 @@ __device__ __forceinline__ void scalar_update_packed(float* P, float* dx, const 
     for (int i = 0; i < N; ++i) {
         const float ki = Ph[i] * is;
         dx[i] += ki * inn;
-        if (i & 1) PS(i, i) -= ki * Ph[i];
 #pragma unroll
-        for (int c = i + (i & 1); c < N; c += 2) {
-            const int o = pidx<N>(i, c);
-            const f32x2 v = f32x2{ P[o], P[o + 1] } - ki * f32x2{ Ph[c], Ph[c + 1] };
-            P[o] = v.x; P[o + 1] = v.y;
+        for (int c = i & ~1; c < N; c += 2) {          // even-aligned column pairs covering j >= i
+            if (c >= i && is_pair<N>(i, c)) {
+                const int o = pidx<N>(i, c);
+                const f32x2 v = f32x2{ P[o], P[o + 1] } - ki * f32x2{ Ph[c], Ph[c + 1] };
+                P[o] = v.x; P[o + 1] = v.y;
+            } else {
+                if (c >= i) PS(i, c) -= ki * Ph[c];
+                if (c + 1 >= i && c + 1 < N) PS(i, c + 1) -= ki * Ph[c + 1];
+            }
         }
     }
 #undef LD2

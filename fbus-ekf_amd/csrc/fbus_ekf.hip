@@ -124,9 +124,10 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
         const T h = dt_stride ? dt[b] : dt[0];
         predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
     }
-    // ba, bg, g are not written by ImuUpdate: their chunks stay as they are in HBM
+    // ba, bg, g and the covariance elements among ba, bg, g (off-diagonal) are not written by ImuUpdate: their
+    // chunks stay as they are in HBM (N = 18: 33 of the 43 covariance chunks are stored)
     store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+    store_chunks<T, N, RC::CH_NOM, RC::CH_VAR_END>(rs, my_lane(), P);
 }
 
 template <typename T, int N, int DIALECT, int COV>
