@@ -205,25 +205,42 @@ struct DevConst {
 // ================================================================================
 // predict
 // ================================================================================
-// Covariance propagation P <- F P F' + Fi Q Fi', packed symmetric, in place.
-// R = carried rotation, a = accel - ba, Th = F(theta,theta) block.
-template <typename T, int N>
-__device__ __forceinline__ void cov_propagate(T* P, const T* R, const T* a, const T (&Th)[9], T dt, const T* qd)
-{
-#define PS(i, j) P[pidx<N>((i), (j))]
-    constexpr bool G = (N == 18);
-    // A = -R [a]x dt (v,theta) ; Bm = -R dt (v,ba)      ImuUpdate.m:65-66 ; filter.cpp:600-601
-    T A[9], Bm[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const T r0 = R[3 * i], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
-        A[3 * i + 0] = -dt * (r1 * a[2] - r2 * a[1]);
-        A[3 * i + 1] = -dt * (r2 * a[0] - r0 * a[2]);
-        A[3 * i + 2] = -dt * (r0 * a[1] - r1 * a[0]);
-        Bm[3 * i + 0] = -dt * r0; Bm[3 * i + 1] = -dt * r1; Bm[3 * i + 2] = -dt * r2;
-    }
+// ImuUpdate is written as four stages so that a kernel can chase its own loads and store results as soon as they
+// are final (the per-call kernel does; predict_n and the fused frame kernel just run them back to back):
+//   predict_nominal   kinematics + the coefficient blocks of F            needs the nominal state and the IMU sample
+//   cov_stage_p       rows p of  F P F'                                    needs covariance rows p, v
+//   cov_stage_v       rows v                                               needs rows theta, ba, g (and P(bg,g))
+//   cov_stage_th      rows theta, + Fi Q Fi' on the theta/ba/bg diagonals  needs rows bg
+// F = E_theta * E_v * E_p (three elementary block-row operations: p += dt v ; v += A th + Bm ba + dt g ;
+// th = Th th - dt bg, each reading not-yet-updated rows), so F P F' is three in-place symmetric congruences;
+// the column part of E_v and E_theta on rows p (rows v) only reads rows p (rows v), which is why rows p are
+// final after cov_stage_p and rows v after cov_stage_v.
+template <typename T>
+struct PredictCoef {
+    T A[9];     // F(v,theta)  = -R [a]x dt      ImuUpdate.m:65 ; filter.cpp:600
+    T Bm[9];    // F(v,ba)     = -R dt           ImuUpdate.m:66 ; filter.cpp:601
+    T Th[9];    // F(theta,theta)                ImuUpdate.m:68 ; filter.cpp:603
+    T dt;
+};
 
-    // ---- E_p : rows p += dt * rows v ---------------------------------------------
+// lowest storage index used by any covariance element of rows >= r: everything below it is final once rows < r are
+template <int N>
+__host__ __device__ constexpr int cov_final_before_row(int r)
+{
+    int m = N * (N + 1) / 2;
+    for (int i = r; i < N; ++i)
+        for (int j = i; j < N; ++j)
+            if (pidx<N>(i, j) < m) m = pidx<N>(i, j);
+    return m;
+}
+
+#define PS(i, j) P[pidx<N>((i), (j))]
+// rows p:  E_p, then the v- and theta-columns of rows p
+template <typename T, int N>
+__device__ __forceinline__ void cov_stage_p(T* P, const PredictCoef<T>& k)
+{
+    constexpr bool G = (N == 18);
+    const T dt = k.dt;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -233,20 +250,51 @@ __device__ __forceinline__ void cov_propagate(T* P, const T* R, const T* a, cons
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int c = 3; c < N; ++c) PS(i, c) += dt * PS(3 + i, c);
+    // E_v, column v of rows p: P(p,v) += P(p,theta) A' + P(p,ba) Bm' + dt P(p,g)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            PS(c, 3 + i) += k.A[3 * i] * PS(c, 6) + k.A[3 * i + 1] * PS(c, 7) + k.A[3 * i + 2] * PS(c, 8)
+                          + k.Bm[3 * i] * PS(c, 9) + k.Bm[3 * i + 1] * PS(c, 10) + k.Bm[3 * i + 2] * PS(c, 11)
+                          + (G ? dt * PS(c, 15 + i) : T(0));
+    // E_theta, column theta of rows p: P(p,theta) = P(p,theta) Th' - dt P(p,bg)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const T o0 = PS(c, 6), o1 = PS(c, 7), o2 = PS(c, 8);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            PS(c, 6 + i) = k.Th[3 * i] * o0 + k.Th[3 * i + 1] * o1 + k.Th[3 * i + 2] * o2 - dt * PS(c, 12 + i);
+    }
+}
 
-    // ---- E_v : rows v += A * rows theta + Bm * rows ba + dt * rows g ----------------
-#define INC(i, c) (A[3 * (i)] * PS(6, (c)) + A[3 * (i) + 1] * PS(7, (c)) + A[3 * (i) + 2] * PS(8, (c)) \
-                 + Bm[3 * (i)] * PS(9, (c)) + Bm[3 * (i) + 1] * PS(10, (c)) + Bm[3 * (i) + 2] * PS(11, (c)) \
-                 + (G ? dt * PS(15 + (i), (c)) : T(0)))
-    T Ut[9], Ua[9], Ug[9];
+// rows v:  E_v (row part and the symmetric v,v block), then the theta-column of rows v, + Q on the v diagonal
+template <typename T, int N>
+__device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const T* qd)
+{
+    constexpr bool G = (N == 18);
+    constexpr int NC = N - 6;                       // columns theta .. end
+    const T dt = k.dt;
+    // U(i, c) = A_i . P(theta, c) + Bm_i . P(ba, c) + dt P(g_i, c), c = 6 .. N-1, accumulated source by source in
+    // the order the rows arrive (theta rows, ba rows, then the g/bg bits)
+    T U[3 * NC];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Ut[3 * i + j] = INC(i, 6 + j);
-            Ua[3 * i + j] = INC(i, 9 + j);
-            Ug[3 * i + j] = G ? INC(i, 15 + j) : T(0);
-        }
+        for (int c = 0; c < NC; ++c)
+            U[NC * i + c] = k.A[3 * i] * PS(6, 6 + c) + k.A[3 * i + 1] * PS(7, 6 + c) + k.A[3 * i + 2] * PS(8, 6 + c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            U[NC * i + c] += k.Bm[3 * i] * PS(9, 6 + c) + k.Bm[3 * i + 1] * PS(10, 6 + c) + k.Bm[3 * i + 2] * PS(11, 6 + c);
+    if (G) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) U[NC * i + c] += dt * PS(15 + i, 6 + c);
+    }
+    // v,v block: P(v,v) += D + D',  D = (P(v,theta) + U_theta/2) A' + (P(v,ba) + U_ba/2) Bm' + dt (P(v,g) + U_g/2)
     T D[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -254,11 +302,11 @@ __device__ __forceinline__ void cov_propagate(T* P, const T* R, const T* a, cons
         for (int j = 0; j < 3; ++j) {
             T acc = T(0);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                acc += (PS(3 + i, 6 + k) + T(0.5) * Ut[3 * i + k]) * A[3 * j + k];
-                acc += (PS(3 + i, 9 + k) + T(0.5) * Ua[3 * i + k]) * Bm[3 * j + k];
+            for (int m = 0; m < 3; ++m) {
+                acc += (PS(3 + i, 6 + m) + T(0.5) * U[NC * i + m]) * k.A[3 * j + m];
+                acc += (PS(3 + i, 9 + m) + T(0.5) * U[NC * i + 3 + m]) * k.Bm[3 * j + m];
             }
-            if (G) acc += dt * (PS(3 + i, 15 + j) + T(0.5) * Ug[3 * i + j]);
+            if (G) acc += dt * (PS(3 + i, 15 + j) + T(0.5) * U[NC * i + 9 + j]);
             D[3 * i + j] = acc;
         }
 #pragma unroll
@@ -266,40 +314,47 @@ __device__ __forceinline__ void cov_propagate(T* P, const T* R, const T* a, cons
 #pragma unroll
         for (int j = i; j < 3; ++j) PS(3 + i, 3 + j) += D[3 * i + j] + D[3 * j + i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int c = 12; c < 15; ++c) PS(3 + i, c) += INC(i, c);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) PS(c, 3 + i) += INC(i, c);
-    }
-#pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            PS(3 + i, 6 + j) += Ut[3 * i + j];
-            PS(3 + i, 9 + j) += Ua[3 * i + j];
-            if (G) PS(3 + i, 15 + j) += Ug[3 * i + j];
-        }
-#undef INC
+        for (int c = 0; c < NC; ++c) PS(3 + i, 6 + c) += U[NC * i + c];
+    // E_theta, column theta of rows v: P(v,theta) = P(v,theta) Th' - dt P(v,bg)
+#pragma unroll
+    for (int c = 3; c < 6; ++c) {
+        const T o0 = PS(c, 6), o1 = PS(c, 7), o2 = PS(c, 8);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            PS(c, 6 + i) = k.Th[3 * i] * o0 + k.Th[3 * i + 1] * o1 + k.Th[3 * i + 2] * o2 - dt * PS(c, 12 + i);
+    }
+#pragma unroll
+    for (int i = 3; i < 6; ++i) PS(i, i) += qd[0];
+}
 
-    // ---- E_th : rows theta = Th * rows theta - dt * rows bg --------------------------
+// rows theta:  E_theta on the remaining columns, + Fi Q Fi' (not scaled by dt; ImuUpdate.m:70-73 ; filter.cpp:609-610)
+template <typename T, int N>
+__device__ __forceinline__ void cov_stage_th(T* P, const PredictCoef<T>& k, const T* qd)
+{
+    const T dt = k.dt;
+    const T (&Th)[9] = k.Th;
     T Xn[9], Gm[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Xn[3 * i + j] = Th[3 * i] * PS(6, 12 + j) + Th[3 * i + 1] * PS(7, 12 + j) + Th[3 * i + 2] * PS(8, 12 + j)
-                          - dt * PS(12 + i, 12 + j);
+        for (int j = 0; j < 3; ++j)
             Gm[3 * i + j] = Th[3 * i] * PS(6, 6 + j) + Th[3 * i + 1] * PS(7, 6 + j) + Th[3 * i + 2] * PS(8, 6 + j);
-        }
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
-        if ((c >= 6 && c < 9) || (c >= 12 && c < 15)) continue;
+    for (int c = 9; c < N; ++c) {
+        if (c >= 12 && c < 15) continue;
         const T o0 = PS(6, c), o1 = PS(7, c), o2 = PS(8, c);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             PS(6 + i, c) = Th[3 * i] * o0 + Th[3 * i + 1] * o1 + Th[3 * i + 2] * o2 - dt * PS(12 + i, c);
     }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Xn[3 * i + j] = Th[3 * i] * PS(6, 12 + j) + Th[3 * i + 1] * PS(7, 12 + j) + Th[3 * i + 2] * PS(8, 12 + j)
+                          - dt * PS(12 + i, 12 + j);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -311,28 +366,38 @@ __device__ __forceinline__ void cov_propagate(T* P, const T* R, const T* a, cons
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) PS(6 + i, 12 + j) = Xn[3 * i + j];
-
-    // ---- + Fi Q Fi' (not scaled by dt)              ImuUpdate.m:70-73 ; filter.cpp:609-610
 #pragma unroll
-    for (int i = 3; i < 15; ++i) PS(i, i) += qd[(i - 3) / 3];
-#undef PS
+    for (int i = 6; i < 15; ++i) PS(i, i) += qd[(i - 3) / 3];
 }
+#undef PS
 
-// One ImuUpdate: nom = the 28 nominal + rotation elements (record order), P = packed covariance.
+// Nominal part of one ImuUpdate: nom = the 28 nominal + rotation elements (record order).  Fills the coefficient
+// blocks from the PRE-step (carried) rotation (filter.cpp:510 runs UpdateCovariance before UpdateNominalState).
 template <typename T, int N, int DIALECT>
-__device__ __forceinline__ void predict_step(T* nom, T* P, const T* accel, const T* gyro, T dt, const T* qd)
+__device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T* gyro, T dt, PredictCoef<T>& k)
 {
     using L = Lay<N>;
     T* p = nom + L::OFF_P3; T* v = nom + L::OFF_V; T* q = nom + L::OFF_Q;
     const T* ba = nom + L::OFF_BA; const T* bg = nom + L::OFF_BG; const T* g = nom + L::OFF_G;
     T* R = nom + L::OFF_R;
+    T (&Th)[9] = k.Th;
+    k.dt = dt;
 
     const T a[3] = { accel[0] - ba[0], accel[1] - ba[1], accel[2] - ba[2] };   // ImuUpdate.m:37-38
     const T w[3] = { gyro[0] - bg[0], gyro[1] - bg[1], gyro[2] - bg[2] };
     const T wn = fb_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
 
-    // ---- phase 1: rotation increments (kept small: n, sin/cos) and F(theta,theta) ----------
-    T Th[9], n[3], s2, c2, s4, c4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T r0 = R[3 * i], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
+        k.A[3 * i + 0] = -dt * (r1 * a[2] - r2 * a[1]);
+        k.A[3 * i + 1] = -dt * (r2 * a[0] - r0 * a[2]);
+        k.A[3 * i + 2] = -dt * (r0 * a[1] - r1 * a[0]);
+        k.Bm[3 * i + 0] = -dt * r0; k.Bm[3 * i + 1] = -dt * r1; k.Bm[3 * i + 2] = -dt * r2;
+    }
+
+    // ---- rotation increments (kept small: n, sin/cos) and F(theta,theta) ----------
+    T n[3], s2, c2, s4, c4;
     bool small_rate = false;
     if (DIALECT == DIALECT_MATLAB) {
         // ImuUpdate.m:41-43,68.  axis/|axis| is NaN at w == 0 in the reference; guarded here
@@ -360,10 +425,7 @@ __device__ __forceinline__ void predict_step(T* nom, T* P, const T* accel, const
         Th[6] = w[1] * dt;   Th[7] = -w[0] * dt;  Th[8] = T(1);
     }
 
-    // ---- phase 2: covariance; reads the pre-step (carried) rotation (filter.cpp:510) -----------
-    cov_propagate<T, N>(P, R, a, Th, dt, qd);
-
-    // ---- phase 3: quaternion, velocity, position   ImuUpdate.m:42-60 ; filter.cpp:539-581 -----
+    // ---- quaternion, velocity, position   ImuUpdate.m:42-60 ; filter.cpp:539-581 -----
     T qT[4], qH[4], R0[9], RH[9], RT[9];
     if (DIALECT == DIALECT_MATLAB) {
         const T dqT[4] = { c2, n[0] * s2, n[1] * s2, n[2] * s2 };
@@ -408,6 +470,17 @@ __device__ __forceinline__ void predict_step(T* nom, T* P, const T* accel, const
     for (int i = 0; i < 4; ++i) q[i] = qT[i];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = RT[i];                        // ImuUpdate.m:77 ; filter.cpp:564
+}
+
+// One ImuUpdate with everything resident: nom = the 28 nominal + rotation elements, P = packed covariance.
+template <typename T, int N, int DIALECT>
+__device__ __forceinline__ void predict_step(T* nom, T* P, const T* accel, const T* gyro, T dt, const T* qd)
+{
+    PredictCoef<T> k;
+    predict_nominal<T, N, DIALECT>(nom, accel, gyro, dt, k);
+    cov_stage_p<T, N>(P, k);
+    cov_stage_v<T, N>(P, k, qd);
+    cov_stage_th<T, N>(P, k, qd);
 }
 
 // ================================================================================

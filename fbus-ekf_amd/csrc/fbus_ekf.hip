@@ -97,6 +97,15 @@ __device__ __forceinline__ size_t elem_index(size_t b, int e)
 // ---------------------------------------------------------------------------------
 // K consecutive ImuUpdates per launch (K = 1 is the per-call API).
 // accel/gyro: [K][B][3]; dt: [K] (dt_stride 0) or [K][B] (dt_stride 1).
+//
+// K = 1 (MULTI = false) is written as a stream: at one wave per SIMD nothing else hides this wave's latency, and
+// all waves of a launch run in lock step, so a load-everything / compute / store-everything body leaves HBM idle
+// while the chip computes and the VALUs idle while it loads.  Here every load is issued up front in the order the
+// stages need the data (IMU sample, nominal state, the separately stored diagonals, covariance rows p and v, rows
+// theta, then the predict-invariant ba/bg/g part), the arithmetic follows in that order (s_waitcnt vmcnt(n) lets a
+// stage start when ITS chunks have landed), and each stage's chunks are stored as soon as they are final.
+// ba, bg, g and the covariance elements among ba, bg, g (off-diagonal) are not written by ImuUpdate: their chunks
+// stay as they are in HBM (N = 18: 33 of the 43 covariance chunks are stored).
 template <typename T, int N, int DIALECT, bool MULTI>
 __global__ void __launch_bounds__(BLOCK)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
@@ -105,11 +114,12 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     if (b >= B) return;
     using RC = Rec<T, N>;
+    constexpr int EPC = RC::EPC, CN = RC::CH_NOM;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[Lay<N>::NNOM], P[RC::NCOVP];
-    load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, my_lane(), nom);
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
     if (MULTI) {
+        load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
         for (int k = 0; k < K; ++k) {
             const size_t o = ((size_t)k * B + b) * 3;
             const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
@@ -117,17 +127,38 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
             const T h = dt_stride ? dt[(size_t)k * B + b] : dt[k];
             predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
         }
+        store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
+        store_chunks<T, N, CN, RC::CH_VAR_END>(rs, my_lane(), P);
     } else {
+        // chunk boundaries of the stages (whole chunks whose elements all belong to finished rows)
+        constexpr int C_P = CN + cov_final_before_row<N>(3) / EPC;       // rows p final
+        constexpr int C_V = CN + cov_final_before_row<N>(6) / EPC;       // rows p, v final
+        constexpr int C_PV_IN = CN + (cov_final_before_row<N>(6) + EPC - 1) / EPC;   // chunks holding rows p, v
+        // N = 18 keeps the odd-row and ba/bg diagonals behind rows 0..8: bring them in first
+        constexpr int C_DG0 = (N == 18) ? CN + 122 / EPC : RC::CH_VAR_END;
+        constexpr int C_DG1 = RC::CH_VAR_END;
+        static_assert(C_PV_IN <= C_DG0, "rows p, v must precede the collected diagonals");
+
         const size_t o = (size_t)b * 3;
         const T a[3] = { accel[o], accel[o + 1], accel[o + 2] };
         const T w[3] = { gyro[o], gyro[o + 1], gyro[o + 2] };
         const T h = dt_stride ? dt[b] : dt[0];
-        predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
+        load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, C_DG0, C_DG1, AUX_NT>(rs, my_lane(), P + (C_DG0 - CN) * EPC);
+        load_chunks<T, N, CN, C_PV_IN, AUX_NT>(rs, my_lane(), P);
+        load_chunks<T, N, C_PV_IN, C_DG0, AUX_NT>(rs, my_lane(), P + (C_PV_IN - CN) * EPC);
+        load_chunks<T, N, C_DG1, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_DG1 - CN) * EPC);
+
+        PredictCoef<T> k;
+        predict_nominal<T, N, DIALECT>(nom, a, w, h, k);
+        store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
+        cov_stage_p<T, N>(P, k);
+        store_chunks<T, N, CN, C_P>(rs, my_lane(), P);
+        cov_stage_v<T, N>(P, k, dc.qd);
+        store_chunks<T, N, C_P, C_V>(rs, my_lane(), P + (C_P - CN) * EPC);
+        cov_stage_th<T, N>(P, k, dc.qd);
+        store_chunks<T, N, C_V, RC::CH_VAR_END>(rs, my_lane(), P + (C_V - CN) * EPC);
     }
-    // ba, bg, g and the covariance elements among ba, bg, g (off-diagonal) are not written by ImuUpdate: their
-    // chunks stay as they are in HBM (N = 18: 33 of the 43 covariance chunks are stored)
-    store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
-    store_chunks<T, N, RC::CH_NOM, RC::CH_VAR_END>(rs, my_lane(), P);
 }
 
 template <typename T, int N, int DIALECT, int COV>
