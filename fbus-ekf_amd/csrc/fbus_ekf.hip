@@ -69,7 +69,7 @@ __device__ __forceinline__ void load_chunks(__amdgpu_buffer_rsrc_t rs, unsigned 
     }
 }
 
-template <typename T, int N, int C0, int C1>
+template <typename T, int N, int C0, int C1, int AUX = AUX_DEFAULT>
 __device__ __forceinline__ void store_chunks(__amdgpu_buffer_rsrc_t rs, unsigned lane, const T* src)
 {
     constexpr int EPC = Rec<T, N>::EPC;
@@ -80,7 +80,7 @@ __device__ __forceinline__ void store_chunks(__amdgpu_buffer_rsrc_t rs, unsigned
         T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
         for (int k = 0; k < EPC; ++k) e[k] = src[(c - C0) * EPC + k];
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c & 3) * 1024u, (c >> 2) * 4096, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c & 3) * 1024u, (c >> 2) * 4096, AUX);
     }
 }
 
@@ -149,15 +149,21 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
         load_chunks<T, N, C_PV_IN, C_DG0, AUX_NT>(rs, my_lane(), P + (C_PV_IN - CN) * EPC);
         load_chunks<T, N, C_DG1, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_DG1 - CN) * EPC);
 
+        // stores are non-temporal: the lines leave the XCD's L2 while the launch is still reading (reads and writes
+        // overlap) instead of piling up dirty until the end-of-kernel write-back; the sched_barriers keep the
+        // compiler from sinking a stage's stores behind the next stage's arithmetic
         PredictCoef<T> k;
         predict_nominal<T, N, DIALECT>(nom, a, w, h, k);
-        store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
+        store_chunks<T, N, 0, RC::CH_KIN, AUX_NT>(rs, my_lane(), nom);
+        __builtin_amdgcn_sched_barrier(0);
         cov_stage_p<T, N>(P, k);
-        store_chunks<T, N, CN, C_P>(rs, my_lane(), P);
+        store_chunks<T, N, CN, C_P, AUX_NT>(rs, my_lane(), P);
+        __builtin_amdgcn_sched_barrier(0);
         cov_stage_v<T, N>(P, k, dc.qd);
-        store_chunks<T, N, C_P, C_V>(rs, my_lane(), P + (C_P - CN) * EPC);
+        store_chunks<T, N, C_P, C_V, AUX_NT>(rs, my_lane(), P + (C_P - CN) * EPC);
+        __builtin_amdgcn_sched_barrier(0);
         cov_stage_th<T, N>(P, k, dc.qd);
-        store_chunks<T, N, C_V, RC::CH_VAR_END>(rs, my_lane(), P + (C_V - CN) * EPC);
+        store_chunks<T, N, C_V, RC::CH_VAR_END, AUX_NT>(rs, my_lane(), P + (C_V - CN) * EPC);
     }
 }
 
