@@ -6,9 +6,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "fbus_ekf.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "csrc", "vision_device.hpp"),
+DEPS = SRC + [os.path.join(HERE, "csrc", "ekf_kernels.hpp"), os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "csrc", "vision_device.hpp"),
               os.path.join(HERE, "..", "include", "fbus_ekf.h")]
-OUT = os.path.join(HERE, "lib", "libfbus_ekf.so")
+OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so")   # FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds
 
 
 def hipcc():
@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     srcs = [s for s in SRC if os.path.exists(s)]
     # -fno-slp-vectorize: the SLP pass packs the unrolled scalar FMAs into v_pk_fma_f32 and pays for it with
     # ~1.9x more instructions (v_mov / v_accvgpr shuffles to form register pairs) -- measured on the .s
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", OUT] + srcs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", OUT] + os.environ.get("FBUS_EXTRA_FLAGS", "").split() + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,0 +1,631 @@
+// ekf_kernels.hpp -- the __global__ kernels of libfbus_ekf.so and their record <-> register helpers.
+// Included by fbus_ekf.hip (launchers + C ABI) and by the single-kernel experiments under tools/ (which
+// instantiate one kernel and read its ISA / time it in isolation).  gfx950 only.
+#pragma once
+#include "../../include/fbus_ekf.h"
+#include "ekf_device.hpp"
+#include "vision_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+using namespace fbus;
+
+namespace {
+
+#ifndef FBUS_BLOCK
+#define FBUS_BLOCK 64
+#endif
+constexpr int BLOCK = FBUS_BLOCK;       // 64 = one wave per workgroup: B/64 workgroups over 256 CUs x 4 SIMDs
+__device__ __forceinline__ unsigned my_tile() { return __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6); }
+__device__ __forceinline__ unsigned my_lane() { return threadIdx.x & 63u; }
+
+// ---------------------------------------------------------------------------------
+// record <-> registers
+// ---------------------------------------------------------------------------------
+// A tile = the records of 64 consecutive filters = NCH pieces of 1 KiB; piece c holds
+// chunk c (16 bytes) of each of the 64 filters, so one wave moves a piece with one
+// buffer_load_dwordx4 / buffer_store_dwordx4.  The descriptor covers exactly one tile
+// (wave-uniform base), the lane contributes a 32-bit offset, the piece index goes
+// into soffset/imm -- no per-piece 64-bit address lives in VGPRs.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+// cache policy (aux) of a record load: 0 = default, 2 = nt (non-temporal).  Measured at B = 65 536: nt on the
+// once-read record stream of predict 18.05 -> 17.30 us; nt on lines that are re-read (the linearisation point in
+// correct) +9 %; nt on the stores +3..7 % -- so: nt for once-read loads only.
+constexpr int AUX_DEFAULT = 0, AUX_NT = 2;
+// Per-step inputs (IMU samples, marker measurements) are read once: nt as well.  Measured: with default-policy
+// loads of 1.5 MB of fresh IMU data per launch the nt-streamed records lose their Infinity Cache residency and a
+// predict launch takes 13.8 us instead of 11.8 us (tools/exp_predict_timeline.hip).
+template <typename T>
+__device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_load(p); }
+// experiment knobs (tools/ab_bench.sh builds variants with -D...)
+#ifndef FBUS_X_CORRECT_ST
+#define FBUS_X_CORRECT_ST AUX_DEFAULT
+#endif
+#ifndef FBUS_X_MEAS_NT
+#define FBUS_X_MEAS_NT 0
+#endif
+template <typename T>
+__device__ __forceinline__ T ld_meas(const T* p) { return FBUS_X_MEAS_NT ? __builtin_nontemporal_load(p) : *p; }
+
+template <typename T, int N>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const T* recs, unsigned tile)
+{
+    constexpr unsigned TILE_BYTES = Rec<T, N>::NCH * 1024u;
+    char* tb = const_cast<char*>(reinterpret_cast<const char*>(recs)) + (size_t)tile * TILE_BYTES;
+    return __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)TILE_BYTES, 0x00020000);
+}
+
+// chunks [C0, C1) of the lane's record -> dst[0 .. (C1-C0)*EPC)
+template <typename T, int N, int C0, int C1, int AUX = AUX_DEFAULT>
+__device__ __forceinline__ void load_chunks(__amdgpu_buffer_rsrc_t rs, unsigned lane, T* dst)
+{
+    constexpr int EPC = Rec<T, N>::EPC;
+    const unsigned off = lane * 16u;
+#pragma unroll
+    for (int c = C0; c < C1; ++c) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (c & 3) * 1024u, (c >> 2) * 4096, AUX);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) dst[(c - C0) * EPC + k] = e[k];
+    }
+}
+
+template <typename T, int N, int C0, int C1, int AUX = AUX_DEFAULT>
+__device__ __forceinline__ void store_chunks(__amdgpu_buffer_rsrc_t rs, unsigned lane, const T* src)
+{
+    constexpr int EPC = Rec<T, N>::EPC;
+    const unsigned off = lane * 16u;
+#pragma unroll
+    for (int c = C0; c < C1; ++c) {
+        u32x4 v;
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) e[k] = src[(c - C0) * EPC + k];
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c & 3) * 1024u, (c >> 2) * 4096, AUX);
+    }
+}
+
+// element e of filter b inside the tiled record storage (pack/unpack helpers)
+template <typename T, int N>
+__device__ __forceinline__ size_t elem_index(size_t b, int e)
+{
+    constexpr int EPC = Rec<T, N>::EPC;
+    return ((b >> 6) * Rec<T, N>::NCH + (size_t)(e / EPC)) * (64 * EPC) + (b & 63) * EPC + (e % EPC);
+}
+
+// ---------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------
+// K consecutive ImuUpdates per launch (K = 1 is the per-call API).
+// accel/gyro: [K][B][3]; dt: [K] (dt_stride 0) or [K][B] (dt_stride 1).
+//
+// K = 1 (MULTI = false) is written as a stream: at one wave per SIMD nothing else hides this wave's latency, and
+// all waves of a launch run in lock step, so a load-everything / compute / store-everything body leaves HBM idle
+// while the chip computes and the VALUs idle while it loads.  Here every load is issued up front in the order the
+// stages need the data (IMU sample, nominal state, the separately stored diagonals, covariance rows p and v, rows
+// theta, then the predict-invariant ba/bg/g part), the arithmetic follows in that order (s_waitcnt vmcnt(n) lets a
+// stage start when ITS chunks have landed), and each stage's chunks are stored as soon as they are final.
+// ba, bg, g and the covariance elements among ba, bg, g (off-diagonal) are not written by ImuUpdate: their chunks
+// stay as they are in HBM (N = 18: 33 of the 43 covariance chunks are stored).
+template <typename T, int N, int DIALECT, bool MULTI>
+__global__ void __launch_bounds__(BLOCK)
+predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
+               const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
+{
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    using RC = Rec<T, N>;
+    constexpr int EPC = RC::EPC, CN = RC::CH_NOM;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T nom[Lay<N>::NNOM], P[RC::NCOVP];
+    if (MULTI) {
+        load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        for (int k = 0; k < K; ++k) {
+            const size_t o = ((size_t)k * B + b) * 3;
+            const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
+            const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
+            const T h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
+            predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
+        }
+        store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
+        store_chunks<T, N, CN, RC::CH_VAR_END>(rs, my_lane(), P);
+    } else {
+        // chunk boundaries of the stages (whole chunks whose elements all belong to finished rows)
+        constexpr int C_P = CN + cov_final_before_row<N>(3) / EPC;       // rows p final
+        constexpr int C_V = CN + cov_final_before_row<N>(6) / EPC;       // rows p, v final
+        constexpr int C_PV_IN = CN + (cov_final_before_row<N>(6) + EPC - 1) / EPC;   // chunks holding rows p, v
+        // N = 18 keeps the odd-row and ba/bg diagonals behind rows 0..8: bring them in first
+        constexpr int C_DG0 = (N == 18) ? CN + 122 / EPC : RC::CH_VAR_END;
+        constexpr int C_DG1 = RC::CH_VAR_END;
+        static_assert(C_PV_IN <= C_DG0, "rows p, v must precede the collected diagonals");
+
+        const size_t o = (size_t)b * 3;
+        const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
+        const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
+        const T h = dt_stride ? ld_once(dt + b) : dt[0];
+        load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, C_DG0, C_DG1, AUX_NT>(rs, my_lane(), P + (C_DG0 - CN) * EPC);
+        load_chunks<T, N, CN, C_PV_IN, AUX_NT>(rs, my_lane(), P);
+        load_chunks<T, N, C_PV_IN, C_DG0, AUX_NT>(rs, my_lane(), P + (C_PV_IN - CN) * EPC);
+        load_chunks<T, N, C_DG1, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_DG1 - CN) * EPC);
+
+        // stores are non-temporal: the lines leave the XCD's L2 while the launch is still reading (reads and writes
+        // overlap) instead of piling up dirty until the end-of-kernel write-back; the sched_barriers keep the
+        // compiler from sinking a stage's stores behind the next stage's arithmetic
+        PredictCoef<T> k;
+        predict_nominal<T, N, DIALECT>(nom, a, w, h, k);
+        store_chunks<T, N, 0, RC::CH_KIN, AUX_NT>(rs, my_lane(), nom);
+        __builtin_amdgcn_sched_barrier(0);
+        cov_stage_p<T, N>(P, k);
+        store_chunks<T, N, CN, C_P, AUX_NT>(rs, my_lane(), P);
+        __builtin_amdgcn_sched_barrier(0);
+        cov_stage_v<T, N>(P, k, dc.qd);
+        store_chunks<T, N, C_P, C_V, AUX_NT>(rs, my_lane(), P + (C_P - CN) * EPC);
+        __builtin_amdgcn_sched_barrier(0);
+        cov_stage_th<T, N>(P, k, dc.qd);
+        store_chunks<T, N, C_V, RC::CH_VAR_END, AUX_NT>(rs, my_lane(), P + (C_V - CN) * EPC);
+    }
+}
+
+template <typename T, int N, int DIALECT, int COV>
+__global__ void __launch_bounds__(BLOCK)
+correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+               const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
+               unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    if (skip && skip[b]) { applied[b] = 0; return; }
+
+    const int* my_ids = ids + (size_t)b * M;
+    const T* my_pos = pos + (size_t)b * M * 3;
+    const T* my_quat = quat + (size_t)b * M * 4;
+
+    int first = 0, last = M;            // marker slots [first, last) to apply
+    int new_prev = -1;
+    if (mode == MODE_NEAREST) {
+        // recs is re-read below; only the previous-marker id is needed for the selection
+        int prev_id = 0;
+        if (DIALECT == DIALECT_CPP) {
+            prev_id = (int)recs[elem_index<T, N>(b, L::OFF_PREV)];
+        }
+        // nearest visible marker, start threshold 10   MeasureUpdate.m:51-60 ; filter.cpp:639-664
+        int min_i = -1, prev_i = -1;
+        T min_d = T(10), prev_d = T(0);
+        for (int i = 0; i < M; ++i) {
+            const int id = my_ids[i];
+            if (id < 0) continue;
+            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
+            const T dist = fb_sqrt(x * x + y * y + z * z);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i < 0) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
+        const int id = my_ids[min_i];
+        const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+        if (slot < 0) { applied[b] = 0; return; }              // filter.cpp:671-673
+        if (DIALECT == DIALECT_CPP) new_prev = id;              // filter.cpp:675
+        first = min_i; last = min_i + 1;
+    }
+
+    using RC = Rec<T, N>;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T P[RC::NCOVP];
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    int used = 0;
+    for (int i = first; i < last; ++i) {
+        const int id = my_ids[i];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+        const int slot = dc.id2slot[id];
+        if (slot < 0) continue;
+        const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
+        const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
+        // the linearisation point (p, q, R) is not modified until inject(): it is re-read per marker
+        // (an L2 hit) instead of being held in registers across the seven rank-1 updates
+        T pqr[L::NPQR];
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
+        marker_update<T, N, DIALECT, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
+        ++used;
+    }
+    if (used == 0) { applied[b] = 0; return; }
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    inject<T, N>(nom, dx);
+    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    // the carried rotation is NOT refreshed by MeasureUpdate: chunks holding only R are left alone
+    store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, my_lane(), nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, my_lane(), P);
+    applied[b] = 1;
+}
+
+// One camera frame in ONE launch: K ImuUpdates then one MeasureUpdate with the record resident in
+// registers in between (the reference's BatchImuProcessing + ObservationUpdate, filter.cpp:232-235).
+// Same device functions, same arithmetic as K predict launches + one correct launch; the record makes
+// one HBM round trip per frame instead of one per EKF step.
+template <typename T, int N, int DIALECT, int COV>
+__global__ void __launch_bounds__(BLOCK)
+frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
+             const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+             const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
+             unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T nom[L::NNOM], P[RC::NCOVP];
+    load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, my_lane(), nom);
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+    for (int k = 0; k < K; ++k) {
+        const size_t o = ((size_t)k * B + b) * 3;
+        const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
+        const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
+        const T h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
+        predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
+    }
+
+    int first = 0, last = (M > 0 && !(skip && skip[b])) ? M : 0;
+    int new_prev = -1;
+    const int* my_ids = ids + (size_t)b * M;
+    const T* my_pos = pos + (size_t)b * M * 3;
+    const T* my_quat = quat + (size_t)b * M * 4;
+    if (last > 0 && mode == MODE_NEAREST) {
+        const int prev_id = (DIALECT == DIALECT_CPP) ? (int)P[L::OFF_PREV - L::OFF_COV] : 0;
+        int min_i = -1, prev_i = -1;
+        T min_d = T(10), prev_d = T(0);
+        for (int i = 0; i < M; ++i) {
+            const int id = my_ids[i];
+            if (id < 0) continue;
+            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
+            const T dist = fb_sqrt(x * x + y * y + z * z);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i >= 0 && DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0))
+            min_i = prev_i;
+        int slot = -1, id = -1;
+        if (min_i >= 0) {
+            id = my_ids[min_i];
+            slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+        }
+        if (slot < 0) { first = last = 0; }
+        else {
+            if (DIALECT == DIALECT_CPP) new_prev = id;
+            first = min_i; last = min_i + 1;
+        }
+    }
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    int used = 0;
+    for (int i = first; i < last; ++i) {
+        const int id = my_ids[i];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+        const int slot = dc.id2slot[id];
+        if (slot < 0) continue;
+        const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
+        const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
+        marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
+        ++used;
+    }
+    if (used > 0) {
+        inject<T, N>(nom, dx);
+        if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    }
+    if (M > 0) applied[b] = used > 0 ? 1 : 0;
+    store_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+}
+
+// correct() from stereo corners: triangulation + 12 corner rows per marker (north-star extension).
+template <typename T, int N, int DIALECT, int COV>
+__global__ void __launch_bounds__(BLOCK)
+correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
+                       const T* __restrict__ right, int geometry, int mode, T size,
+                       const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied, DevConst<T> dc,
+                       VisConst<T> vc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    if (skip && skip[b]) { applied[b] = 0; return; }
+    const int* my_ids = ids + (size_t)b * M;
+    const int lw = (geometry == VIS_CORNERS3D) ? 12 : 8;
+    auto corner = [&](int i, int c, T* out) {          // corner c of marker slot i in the left camera frame
+        const T* l = left + ((size_t)b * M + i) * lw;
+        if (geometry == VIS_CORNERS3D) { out[0] = l[3 * c]; out[1] = l[3 * c + 1]; out[2] = l[3 * c + 2]; return; }
+        const T* r = right + ((size_t)b * M + i) * 8;
+        if (geometry == VIS_REFRACTIVE) refraction_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], out);
+        else pinhole_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], out);
+    };
+    int first = 0, last = M, new_prev = -1;
+    if (mode == MODE_NEAREST) {
+        int prev_id = 0;
+        if (DIALECT == DIALECT_CPP) prev_id = (int)recs[elem_index<T, N>(b, L::OFF_PREV)];
+        int min_i = -1, prev_i = -1;
+        T min_d = T(10), prev_d = T(0);
+        for (int i = 0; i < M; ++i) {
+            const int id = my_ids[i];
+            if (id < 0) continue;
+            T c0[3];
+            corner(i, 0, c0);
+            const T dist = fb_sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+            if (dist < min_d) { min_d = dist; min_i = i; }
+            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+        }
+        if (min_i < 0) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
+        const int id = my_ids[min_i];
+        const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+        if (slot < 0) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP) new_prev = id;
+        first = min_i; last = min_i + 1;
+    }
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T P[RC::NCOVP];
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    int used = 0;
+    for (int i = first; i < last; ++i) {
+        const int id = my_ids[i];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+        const int slot = dc.id2slot[id];
+        if (slot < 0) continue;
+        T C[12];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) corner(i, c, C + 3 * c);
+        T pqr[L::NPQR];
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
+        corner_update<T, N, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, C, size);
+        ++used;
+    }
+    if (used == 0) { applied[b] = 0; return; }
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    inject<T, N>(nom, dx);
+    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    store_chunks<T, N, 0, RC::CH_PQ>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, my_lane(), nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+    applied[b] = 1;
+}
+
+// One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
+template <typename T>
+__global__ void __launch_bounds__(256)
+marker_pose_kernel(int n, int geometry, const T* __restrict__ left, const T* __restrict__ right,
+                   T* __restrict__ pos, T* __restrict__ quat, T* __restrict__ corners3d, VisConst<T> vc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T C[12];
+    if (geometry == VIS_CORNERS3D) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) C[k] = left[(size_t)i * 12 + k];
+    } else {
+        T l[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { l[k] = left[(size_t)i * 8 + k]; r[k] = right[(size_t)i * 8 + k]; }
+        if (geometry == VIS_REFRACTIVE) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) refraction_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], C + 3 * c);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pinhole_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], C + 3 * c);
+        }
+    }
+    T p[3], q[4];
+    marker_pose(C, p, q);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pos[(size_t)i * 3 + k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) quat[(size_t)i * 4 + k] = q[k];
+    if (corners3d) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) corners3d[(size_t)i * 12 + k] = C[k];
+    }
+}
+
+// ---- init / reset / front door (rows f-2, f-4): one filter per lane, element-wise record access -------
+// gravity = (0, 0, -|mean accel|), gyro bias = mean gyro over T samples (accel/gyro T x B x 3).
+// InitGravityAndGyrobias.m:36-40 ; FILTER::InitializeGravityAndBias filter.cpp:256-285
+template <typename T, int N>
+__global__ void init_gravity_bias_kernel(T* __restrict__ recs, int B, int Tn, const T* __restrict__ accel,
+                                         const T* __restrict__ gyro)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    T ma[3] = { T(0), T(0), T(0) }, mg[3] = { T(0), T(0), T(0) };
+    for (int t = 0; t < Tn; ++t) {
+        const size_t o = ((size_t)t * B + b) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ma[i] += accel[o + i]; mg[i] += gyro[o + i]; }
+    }
+    const T inv = T(1) / T(Tn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ma[i] *= inv; recs[elem_index<T, N>(b, L::OFF_BG + i)] = mg[i] * inv; }
+    recs[elem_index<T, N>(b, L::OFF_G + 0)] = T(0);
+    recs[elem_index<T, N>(b, L::OFF_G + 1)] = T(0);
+    recs[elem_index<T, N>(b, L::OFF_G + 2)] = -fb_sqrt(ma[0] * ma[0] + ma[1] * ma[1] + ma[2] * ma[2]);
+}
+
+// IMU pose from the nearest marker: init / reset / vision-only (what = 0 / 1 / 2).
+// InitPositionAndQuaternion.m:38-80, ResetState.m:37-80, ComputeVisionOnlyResults.m:39-79 ;
+// FILTER::InitializePose filter.cpp:291-399, FILTER::ResetSystemState filter.cpp:405-477
+template <typename T, int N, int DIALECT>
+__global__ void pose_init_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids,
+                                 const T* __restrict__ pos, const T* __restrict__ quat, int what, T max_dist,
+                                 const unsigned char* __restrict__ mask, T* __restrict__ out7,
+                                 unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    applied[b] = 0;
+    if (mask && !mask[b]) return;
+    int mi = -1;
+    T md = T(10);
+    for (int i = 0; i < M; ++i) {
+        if (ids[(size_t)b * M + i] < 0) continue;
+        const T* y = pos + ((size_t)b * M + i) * 3;
+        const T d = fb_sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+        if (d < md) { md = d; mi = i; }
+    }
+    if (mi < 0) return;
+    if (DIALECT == DIALECT_CPP && max_dist > T(0) && md > max_dist) return;     // filter.cpp:343-347,432-436
+    const int id = ids[(size_t)b * M + mi];
+    const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
+    if (slot < 0) return;                                                        // filter.cpp:355-359,444-448
+    const T* mk = dc.mk + (size_t)slot * MK_STRIDE;
+    const T* yp = pos + ((size_t)b * M + mi) * 3;
+    const T* yq = quat + ((size_t)b * M + mi) * 4;
+    const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
+    const T qc[4] = { yq[0], -yq[1], -yq[2], -yq[3] };
+    T t4[4], q[4], R[9];
+    quat_mul(Qm, qc, t4);
+    quat_mul(t4, dc.Q_IL, q);                       // Q_IG = Q_MG (x) Q_ML* (x) Q_IL
+    if (what == 2) quat_normalize(q);               // ComputeVisionOnlyResults.m:67
+    if (DIALECT == DIALECT_CPP) quat_to_rotmat_e(q, R); else quat_to_rotmat_m(q, R);
+    T a[3], p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = dc.R_IL[i] * yp[0] + dc.R_IL[3 + i] * yp[1] + dc.R_IL[6 + i] * yp[2];   // R_IL' P_ML
+#pragma unroll
+    for (int i = 0; i < 3; ++i)                     // P_IG = -R_IG R_IL' P_ML + P_MG - R_IG P_IL
+        p[i] = -(R[3 * i] * a[0] + R[3 * i + 1] * a[1] + R[3 * i + 2] * a[2]) + mk[i]
+               - (R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2]);
+    applied[b] = 1;
+    if (what == 2) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out7[(size_t)b * 7 + i] = p[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out7[(size_t)b * 7 + 3 + i] = q[i];
+        return;
+    }
+    auto put = [&](int e, T v) { recs[elem_index<T, N>(b, e)] = v; };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) put(L::OFF_P3 + i, p[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(L::OFF_Q + i, q[i]);
+    if (what == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) put(L::OFF_R + i, R[i]);
+        put(L::OFF_G, T(9.8)); put(L::OFF_G + 1, T(0)); put(L::OFF_G + 2, T(0));   // InitPositionAndQuaternion.m:79
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { put(L::OFF_V + i, T(0)); put(L::OFF_BA + i, T(0)); }
+        if (DIALECT == DIALECT_CPP) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) put(L::OFF_BG + i, T(0));                    // filter.cpp:470 ; rotmatI2G stays stale
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) put(L::OFF_R + i, R[i]);                     // ResetState.m:77
+        }
+    }
+}
+
+// y[t] = 0.9 y[t-1] + 0.1 x[t] per filter over T samples, in place (FILTER::SetImuData filter.cpp:36-47).
+// accel/gyro: T x B x 3; carry: B x 6 previous filtered sample (read if have_carry, always written).
+template <typename T>
+__global__ void imu_ema_kernel(int B, int Tn, T* __restrict__ accel, T* __restrict__ gyro, T* __restrict__ carry,
+                               int have_carry)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const T c = T(0.1);
+    T prev[6];
+    if (have_carry) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) prev[i] = carry[(size_t)b * 6 + i];
+    }
+    for (int t = 0; t < Tn; ++t) {
+        const size_t o = ((size_t)t * B + b) * 3;
+        T x[6] = { accel[o], accel[o + 1], accel[o + 2], gyro[o], gyro[o + 1], gyro[o + 2] };
+        if (t > 0 || have_carry) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = prev[i] * (T(1) - c) + x[i] * c;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { accel[o + i] = x[i]; gyro[o + i] = x[3 + i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) prev[i] = x[i];
+    }
+    if (Tn > 0 && carry) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) carry[(size_t)b * 6 + i] = prev[i];
+    }
+}
+
+// AoS (API arrays) <-> records.  Not on the hot path.
+template <typename T, int N>
+__global__ void pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ nominal,
+                            const T* __restrict__ rot, const T* __restrict__ P, const int* __restrict__ prev)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    auto put = [&](int e, T v) { recs[elem_index<T, N>(b, e)] = v; };
+    // API order p v q ba bg g -> record order
+    const int map[19] = { L::OFF_P3, L::OFF_P3 + 1, L::OFF_P3 + 2, L::OFF_V, L::OFF_V + 1, L::OFF_V + 2,
+                          L::OFF_Q, L::OFF_Q + 1, L::OFF_Q + 2, L::OFF_Q + 3, L::OFF_BA, L::OFF_BA + 1, L::OFF_BA + 2,
+                          L::OFF_BG, L::OFF_BG + 1, L::OFF_BG + 2, L::OFF_G, L::OFF_G + 1, L::OFF_G + 2 };
+    if (nominal) for (int i = 0; i < 19; ++i) put(map[i], nominal[(size_t)b * 19 + i]);
+    if (rot) for (int i = 0; i < 9; ++i) put(L::OFF_R + i, rot[(size_t)b * 9 + i]);
+    if (prev) put(L::OFF_PREV, (T)prev[b]);
+    if (P)
+        for (int i = 0; i < N; ++i)
+            for (int j = i; j < N; ++j) {   // the reference symmetrises every step; store the mean of the two halves
+                const T u = P[((size_t)b * N + i) * N + j], l = P[((size_t)b * N + j) * N + i];
+                put(L::OFF_COV + pidx<N>(i, j), (u + l) / 2);
+            }
+}
+
+template <typename T, int N>
+__global__ void unpack_kernel(const T* __restrict__ recs, int B, T* __restrict__ nominal,
+                              T* __restrict__ rot, T* __restrict__ P, int* __restrict__ prev)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    auto get = [&](int e) { return recs[elem_index<T, N>(b, e)]; };
+    const int map[19] = { L::OFF_P3, L::OFF_P3 + 1, L::OFF_P3 + 2, L::OFF_V, L::OFF_V + 1, L::OFF_V + 2,
+                          L::OFF_Q, L::OFF_Q + 1, L::OFF_Q + 2, L::OFF_Q + 3, L::OFF_BA, L::OFF_BA + 1, L::OFF_BA + 2,
+                          L::OFF_BG, L::OFF_BG + 1, L::OFF_BG + 2, L::OFF_G, L::OFF_G + 1, L::OFF_G + 2 };
+    if (nominal) for (int i = 0; i < 19; ++i) nominal[(size_t)b * 19 + i] = get(map[i]);
+    if (rot) for (int i = 0; i < 9; ++i) rot[(size_t)b * 9 + i] = get(L::OFF_R + i);
+    if (prev) prev[b] = (int)get(L::OFF_PREV);
+    if (P)
+        for (int i = 0; i < N; ++i)
+            for (int j = i; j < N; ++j) {
+                const T v = get(L::OFF_COV + pidx<N>(i, j));
+                P[((size_t)b * N + i) * N + j] = v;
+                P[((size_t)b * N + j) * N + i] = v;
+            }
+}
+
+template <typename T, int N>
+__global__ void reset_cov_kernel(T* __restrict__ recs, int B, T d0, T d1, T d2, T d3, T d4, T d5)
+{
+    using L = Lay<N>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const T d[6] = { d0, d1, d2, d3, d4, d5 };
+    for (int i = 0; i < N; ++i)
+        for (int j = i; j < N; ++j) {
+            const int e = L::OFF_COV + pidx<N>(i, j);
+            recs[elem_index<T, N>(b, e)] = (i == j) ? d[i / 3] : T(0);
+        }
+}
+
+}  // namespace
