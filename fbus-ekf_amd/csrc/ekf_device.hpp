@@ -595,11 +595,12 @@ __device__ __forceinline__ void scalar_update(T* P, T* dx, const T* hA, const T*
 #undef PS
 }
 
-// The 7 rows of one marker (map slot constants mk), linearised at the record's
-// nominal state (which is not modified until inject()).
-template <typename T, int N, int DIALECT, int COV>
-__device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const DevConst<T>& dc,
-                                              const T* __restrict__ mk, const T* yp, const T* yq)
+// The 7 rows of one marker (map slot constants mk), linearised at the record's nominal state (which is not
+// modified until inject()): Jacobian blocks Hpp = H(1:3, p), Hpt = H(1:3, theta), Hq = H(4:7, theta) (all other
+// columns are zero) and the residuals rp (position rows), rq (quaternion rows).
+template <typename T, int N, int DIALECT>
+__device__ __forceinline__ void marker_rows(const T* pqr, const DevConst<T>& dc, const T* __restrict__ mk, const T* yp,
+                                            const T* yq, T (&Hpp)[9], T (&Hpt)[9], T (&rp)[3], T (&Hq)[12], T (&rq)[4])
 {
     using L = Lay<N>;
     const T* p = pqr + L::OFF_P3; const T* q = pqr + L::OFF_Q; const T* R = pqr + L::OFF_R;
@@ -631,7 +632,6 @@ __device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const D
     quat_mul(tmp, Qm, hq);
 
     // H(1:3,1:3) = -R_IL R' ; H(1:3,7:9) = R_IL [R'(Pm-p)]x      MeasureUpdate.m:72-73 ; filter.cpp:691-692
-    T Hpp[9], Hpt[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
@@ -642,8 +642,7 @@ __device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const D
         Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        scalar_update<T, N, true, COV>(P, dx, Hpp + 3 * k, Hpt + 3 * k, yp[k] - hp[k], dc.r_pos);
+    for (int k = 0; k < 3; ++k) rp[k] = yp[k] - hp[k];
 
     // H(4:7,7:9) = Rq(Qm) [Lq(Q_IL) L2] [Lq(q) L1]   MeasureUpdate.m:74-75 ; filter.cpp:693-694
     // evaluated right to left: M1 = CL * Lq(q)(:,2:4) with the wave-uniform constant CL, then Rq(Qm) * M1 -- only
@@ -666,19 +665,222 @@ __device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const D
         k2 += (yq[i] + hq[i]) * (yq[i] + hq[i]);
     }
     const T sg = (k1 > k2) ? T(-0.5) : T(0.5);                    // 0.5 = L1
-    T Hq[12];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             Hq[3 * i + j] = sg * (RqM[4 * i] * M1[j] + RqM[4 * i + 1] * M1[3 + j] + RqM[4 * i + 2] * M1[6 + j] + RqM[4 * i + 3] * M1[9 + j]);
     const T sq = (k1 > k2) ? T(-1) : T(1);
+    // Matlab zeroes the quaternion residual (MeasureUpdate.m:88); C++ uses it (filter.cpp:718-721)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        // Matlab zeroes the quaternion residual (MeasureUpdate.m:88); C++ uses it (filter.cpp:718-721)
-        const T rk = (DIALECT == DIALECT_CPP) ? (yq[k] - sq * hq[k]) : T(0);
-        scalar_update<T, N, false, COV>(P, dx, Hq + 3 * k, Hq + 3 * k, rk, dc.r_quat);
+    for (int k = 0; k < 4; ++k) rq[k] = (DIALECT == DIALECT_CPP) ? (yq[k] - sq * hq[k]) : T(0);
+}
+
+// One marker applied row by row (the reference's 7-row update, algebraically K = P H'(H P H' + R)^-1 with the
+// diagonal R): 7 sequential scalar updates at one linearisation point.
+template <typename T, int N, int DIALECT, int COV>
+__device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const DevConst<T>& dc,
+                                              const T* __restrict__ mk, const T* yp, const T* yq)
+{
+    T Hpp[9], Hpt[9], rp[3], Hq[12], rq[4];
+    marker_rows<T, N, DIALECT>(pqr, dc, mk, yp, yq, Hpp, Hpt, rp, Hq, rq);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        scalar_update<T, N, true, COV>(P, dx, Hpp + 3 * k, Hpt + 3 * k, rp[k], dc.r_pos);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        scalar_update<T, N, false, COV>(P, dx, Hq + 3 * k, Hq + 3 * k, rq[k], dc.r_quat);
+}
+
+// --------------------------------------------------------------------------------
+// Stacked mode: the information-compressed joint update.
+// Every row of every marker has its non-zeros in the same six columns J = (p, theta), so the stacked 7M-row
+// measurement enters the Kalman update only through the 6x6 information matrix Lam = sum h_J h_J' / r and the
+// 6-vector b = sum h_J res / r  (K = P H'(H P H' + R)^-1 depends on H, R, res through them alone).  Lam = L D L'
+// gives six equivalent scalar measurements -- row a = column a of the unit lower-triangular L (non-zeros in J-positions
+// a..5), information d_a, residual-times-information beta_a = (L^-1 b)_a -- which are applied as six sequential
+// scalar updates: 6 rank-1 passes over P instead of 7M, the same posterior.  A direction without information
+// (d_a = 0) is a no-op, nothing divides by d.
+// --------------------------------------------------------------------------------
+__host__ __device__ constexpr int jcol(int k) { return k < 3 ? k : k + 3; }            // J-position -> state column
+__host__ __device__ constexpr int lidx(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   // i <= j < 6
+
+template <typename T>
+struct InfoAcc {
+    T Lam[21];      // upper triangle of the 6x6 information matrix, lidx order
+    T b[6];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < 21; ++i) Lam[i] = T(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b[i] = T(0);
     }
+    // a row with non-zeros hA (columns p) and hB (columns theta), residual res, weight w = 1 / noise
+    __device__ __forceinline__ void add6(const T* hA, const T* hB, T res, T w)
+    {
+        const T h[6] = { hA[0], hA[1], hA[2], hB[0], hB[1], hB[2] };
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const T wi = w * h[i];
+            b[i] += wi * res;
+#pragma unroll
+            for (int j = i; j < 6; ++j) Lam[lidx(i, j)] += wi * h[j];
+        }
+    }
+    // a row with non-zeros hB in the theta columns only
+    __device__ __forceinline__ void add3(const T* hB, T res, T w)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T wi = w * hB[i];
+            b[3 + i] += wi * res;
+#pragma unroll
+            for (int j = i; j < 3; ++j) Lam[lidx(3 + i, 3 + j)] += wi * hB[j];
+        }
+    }
+};
+
+// the 7 rows of one marker into the accumulator
+template <typename T, int N, int DIALECT>
+__device__ __forceinline__ void marker_info(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc,
+                                            const T* __restrict__ mk, const T* yp, const T* yq, T w_pos, T w_quat)
+{
+    T Hpp[9], Hpt[9], rp[3], Hq[12], rq[4];
+    marker_rows<T, N, DIALECT>(pqr, dc, mk, yp, yq, Hpp, Hpt, rp, Hq, rq);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc.add6(Hpp + 3 * k, Hpt + 3 * k, rp[k], w_pos);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc.add3(Hq + 3 * k, rq[k], w_quat);
+}
+
+// One equivalent scalar measurement: row = (0,..,0, 1, l[A+1..5]) in the J columns, information d, beta.
+//   s' = 1 + d h P h' ; dx += P h' (beta - d h dx) / s' ; P -= (d / s') (P h')(P h')'
+template <typename T, int N, int A, int COV>
+__device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d, T beta)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+    T Ph[N];
+    if constexpr (PackedMath<T, N>::on && COV == COV_SIMPLE) {
+#define LD2(r, c) f32x2{ P[pidx<N>((r), (c))], P[pidx<N>((r), (c)) + 1] }
+#pragma unroll
+        for (int c = 0; c < N; c += 2) {
+            f32x2 v = { 0.f, 0.f };
+            float lo = 0.f, hi = 0.f;
+            bool vset = false, sset = false;
+#pragma unroll
+            for (int k = A; k < 6; ++k) {
+                const int r = jcol(k);
+                if (is_pair<N>(r, c)) {
+                    const f32x2 t = LD2(r, c);
+                    v = !vset ? ((k == A) ? t : l[k] * t) : ((k == A) ? v + t : v + l[k] * t);
+                    vset = true;
+                } else {
+                    const float t0 = PS(c, r), t1 = PS(c + 1, r);
+                    lo = !sset ? ((k == A) ? t0 : l[k] * t0) : ((k == A) ? lo + t0 : lo + l[k] * t0);
+                    hi = !sset ? ((k == A) ? t1 : l[k] * t1) : ((k == A) ? hi + t1 : hi + l[k] * t1);
+                    sset = true;
+                }
+            }
+            Ph[c] = vset ? (sset ? v.x + lo : v.x) : lo;
+            Ph[c + 1] = vset ? (sset ? v.y + hi : v.y) : hi;
+        }
+#undef LD2
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = PS(i, jcol(A));
+#pragma unroll
+            for (int k = A + 1; k < 6; ++k) acc += l[k] * PS(i, jcol(k));
+            Ph[i] = acc;
+        }
+    }
+    T hPh = Ph[jcol(A)], hdx = dx[jcol(A)];
+#pragma unroll
+    for (int k = A + 1; k < 6; ++k) { hPh += l[k] * Ph[jcol(k)]; hdx += l[k] * dx[jcol(k)]; }
+    const T sp = T(1) + d * hPh;                 // >= 1
+    T is;
+    if constexpr (sizeof(T) == 4) {
+        is = __builtin_amdgcn_rcpf(sp);
+        is = is * (2.0f - sp * is);
+    } else {
+        is = T(1) / sp;
+    }
+    const T g = (beta - d * hdx) * is, dk = d * is;
+    if constexpr (PackedMath<T, N>::on && COV == COV_SIMPLE) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float ki = Ph[i] * dk;
+            dx[i] += Ph[i] * g;
+#pragma unroll
+            for (int c = i & ~1; c < N; c += 2) {
+                if (c >= i && is_pair<N>(i, c)) {
+                    const int o = pidx<N>(i, c);
+                    const f32x2 v = f32x2{ P[o], P[o + 1] } - ki * f32x2{ Ph[c], Ph[c + 1] };
+                    P[o] = v.x; P[o + 1] = v.y;
+                } else {
+                    if (c >= i) PS(i, c) -= ki * Ph[c];
+                    if (c + 1 >= i && c + 1 < N) PS(i, c + 1) -= ki * Ph[c + 1];
+                }
+            }
+        }
+    } else if (COV == COV_JOSEPH) {
+        // P - K Ph' - Ph K' + s K K' with s K_i K_j = Ph_i Ph_j d / s' (finite for d -> 0)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const T ki = Ph[i] * dk;
+            dx[i] += Ph[i] * g;
+#pragma unroll
+            for (int j = i; j < N; ++j) {
+                const T kj = Ph[j] * dk;
+                PS(i, j) += (Ph[i] * Ph[j]) * dk - ki * Ph[j] - Ph[i] * kj;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const T ki = Ph[i] * dk;
+            dx[i] += Ph[i] * g;
+#pragma unroll
+            for (int j = i; j < N; ++j) PS(i, j) -= ki * Ph[j];
+        }
+    }
+#undef PS
+}
+
+// Lam = L D L' in place (no pivoting: Lam is positive semi-definite; a pivot that is not clearly positive relative
+// to its original diagonal carries no information and is dropped), beta = L^-1 b, then the six scalar updates.
+template <typename T, int N, int COV>
+__device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc)
+{
+    T (&A)[21] = acc.Lam;
+    T (&bt)[6] = acc.b;
+    T d[6], l[6][6], dg0[6];
+    const T tiny = (sizeof(T) == 4) ? T(2e-6) : T(4e-15);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) dg0[a] = A[lidx(a, a)];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const T piv = A[lidx(a, a)];
+        const bool ok = piv > tiny * dg0[a];
+        const T inv = ok ? T(1) / piv : T(0);
+        d[a] = ok ? piv : T(0);
+        if (!ok) bt[a] = T(0);
+#pragma unroll
+        for (int i = a + 1; i < 6; ++i) l[a][i] = A[lidx(a, i)] * inv;
+#pragma unroll
+        for (int i = a + 1; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) A[lidx(i, j)] -= l[a][i] * A[lidx(a, j)];
+            bt[i] -= l[a][i] * bt[a];
+        }
+    }
+    scalar_update_info<T, N, 0, COV>(P, dx, l[0], d[0], bt[0]);
+    scalar_update_info<T, N, 1, COV>(P, dx, l[1], d[1], bt[1]);
+    scalar_update_info<T, N, 2, COV>(P, dx, l[2], d[2], bt[2]);
+    scalar_update_info<T, N, 3, COV>(P, dx, l[3], d[3], bt[3]);
+    scalar_update_info<T, N, 4, COV>(P, dx, l[4], d[4], bt[4]);
+    scalar_update_info<T, N, 5, COV>(P, dx, l[5], d[5], bt[5]);
 }
 
 // Corner-row measurement model (north-star extension, no reference counterpart): the four triangulated

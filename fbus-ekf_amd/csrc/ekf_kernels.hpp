@@ -168,7 +168,9 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     }
 }
 
-template <typename T, int N, int DIALECT, int COV>
+// JOINT = stacked mode (all visible markers at one linearisation point) through the information-compressed joint
+// update; !JOINT = the reference's behaviour, one (nearest) marker applied row by row.
+template <typename T, int N, int DIALECT, int COV, bool JOINT>
 __global__ void __launch_bounds__(BLOCK)
 correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
                const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
@@ -214,24 +216,46 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     using RC = Rec<T, N>;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T P[RC::NCOVP];
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0;
-    for (int i = first; i < last; ++i) {
-        const int id = my_ids[i];
-        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
-        const int slot = dc.id2slot[id];
-        if (slot < 0) continue;
-        const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
-        const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
-        // the linearisation point (p, q, R) is not modified until inject(): it is re-read per marker
-        // (an L2 hit) instead of being held in registers across the seven rank-1 updates
+    if constexpr (JOINT) {
+        // all visible markers at one linearisation point: their rows are folded into the 6x6 information matrix
+        // while the covariance is still on its way in, then applied as six scalar updates (joint_update)
         T pqr[L::NPQR];
         load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
-        marker_update<T, N, DIALECT, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
-        ++used;
+        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        InfoAcc<T> acc;
+        acc.clear();
+        const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+        for (int i = first; i < last; ++i) {
+            const int id = my_ids[i];
+            if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+            const int slot = dc.id2slot[id];
+            if (slot < 0) continue;
+            const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
+            const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
+            marker_info<T, N, DIALECT>(acc, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq, w_pos, w_quat);
+            ++used;
+        }
+        if (used > 0) joint_update<T, N, COV>(P, dx, acc);
+    } else {
+        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        for (int i = first; i < last; ++i) {
+            const int id = my_ids[i];
+            if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+            const int slot = dc.id2slot[id];
+            if (slot < 0) continue;
+            const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
+            const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
+            // the linearisation point (p, q, R) is not modified until inject(): it is re-read per marker
+            // (an L2 hit) instead of being held in registers across the seven rank-1 updates
+            T pqr[L::NPQR];
+            load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
+            marker_update<T, N, DIALECT, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
+            ++used;
+        }
     }
     if (used == 0) { applied[b] = 0; return; }
     T nom[L::NNOM];
@@ -249,7 +273,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
 // registers in between (the reference's BatchImuProcessing + ObservationUpdate, filter.cpp:232-235).
 // Same device functions, same arithmetic as K predict launches + one correct launch; the record makes
 // one HBM round trip per frame instead of one per EKF step.
-template <typename T, int N, int DIALECT, int COV>
+template <typename T, int N, int DIALECT, int COV, bool JOINT>
 __global__ void __launch_bounds__(BLOCK)
 frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
              const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
@@ -306,6 +330,10 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0;
+    InfoAcc<T> acc;
+    constexpr bool joint = JOINT;
+    const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+    if (joint) acc.clear();
     for (int i = first; i < last; ++i) {
         const int id = my_ids[i];
         if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
@@ -313,9 +341,11 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
         if (slot < 0) continue;
         const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
         const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
-        marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
+        if constexpr (joint) marker_info<T, N, DIALECT>(acc, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq, w_pos, w_quat);
+        else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
         ++used;
     }
+    if constexpr (joint) { if (used > 0) joint_update<T, N, COV>(P, dx, acc); }
     if (used > 0) {
         inject<T, N>(nom, dx);
         if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;

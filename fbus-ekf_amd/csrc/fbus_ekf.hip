@@ -240,14 +240,14 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
 {
     const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
-    if (h->prm.cov_form == FBUS_COV_JOSEPH)
-        hipLaunchKernelGGL((correct_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs,
-                           h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip,
-                           h->d_applied, make_dc<T>(h));
-    else
-        hipLaunchKernelGGL((correct_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs,
-                           h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip,
-                           h->d_applied, make_dc<T>(h));
+    const bool joseph = h->prm.cov_form == FBUS_COV_JOSEPH, joint = mode == MODE_STACKED;
+#define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                            \
+    hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs,  \
+                       h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip,  \
+                       h->d_applied, make_dc<T>(h))
+    if (joseph) { if (joint) FBUS_LAUNCH_CORRECT(COV_JOSEPH, true); else FBUS_LAUNCH_CORRECT(COV_JOSEPH, false); }
+    else        { if (joint) FBUS_LAUNCH_CORRECT(COV_SIMPLE, true); else FBUS_LAUNCH_CORRECT(COV_SIMPLE, false); }
+#undef FBUS_LAUNCH_CORRECT
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -285,14 +285,14 @@ int launch_frame_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, con
 {
     const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
-    if (h->prm.cov_form == FBUS_COV_JOSEPH)
-        hipLaunchKernelGGL((frame_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,
-                           K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, M, (const int*)ids,
-                           (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
-    else
-        hipLaunchKernelGGL((frame_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,
-                           K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, M, (const int*)ids,
-                           (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+    const bool joseph = h->prm.cov_form == FBUS_COV_JOSEPH, joint = mode == MODE_STACKED;
+#define FBUS_LAUNCH_FRAME(COV, JOINT)                                                                                  \
+    hipLaunchKernelGGL((frame_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,  \
+                       K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, M, (const int*)ids,    \
+                       (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied, make_dc<T>(h))
+    if (joseph) { if (joint) FBUS_LAUNCH_FRAME(COV_JOSEPH, true); else FBUS_LAUNCH_FRAME(COV_JOSEPH, false); }
+    else        { if (joint) FBUS_LAUNCH_FRAME(COV_SIMPLE, true); else FBUS_LAUNCH_FRAME(COV_SIMPLE, false); }
+#undef FBUS_LAUNCH_FRAME
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;

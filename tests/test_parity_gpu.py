@@ -235,7 +235,10 @@ def test_one_stacked_marker_is_the_nearest_marker_update():
         a.correct(ids, pos, quat, 0)
         b.correct(ids, pos, quat, 1)
         sa, sb = a.get_state(), b.get_state()
-        assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[2], sb[2])
+        # nearest applies the 7 rows one by one, stacked folds them into the 6x6 information matrix first: the same
+        # posterior, not the same rounding
+        assert state_rel_err(sa[0], sb[0], sb[2], nom)[0] < STATE_TOL
+        assert cov_rel_err(sa[2], sb[2]) < COV_TOL
 
 
 @pytest.mark.parametrize("dialect", [0, 1])

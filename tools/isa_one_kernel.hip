@@ -5,13 +5,16 @@
 #ifndef KERNEL
 #define KERNEL 1
 #endif
+#ifndef KJOINT
+#define KJOINT true
+#endif
 const void* fbus_isa_keep()
 {
 #if KERNEL == 1
     return (const void*)predict_kernel<float, 18, 0, false>;
 #elif KERNEL == 2
-    return (const void*)correct_kernel<float, 18, 0, 0>;
+    return (const void*)correct_kernel<float, 18, 0, 0, KJOINT>;
 #elif KERNEL == 3
-    return (const void*)frame_kernel<float, 18, 0, 0>;
+    return (const void*)frame_kernel<float, 18, 0, 0, KJOINT>;
 #endif
 }
