@@ -887,9 +887,11 @@ __device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc)
 // corner positions C[12] of one marker as 12 scalar rows.  h_k = R_IL R'(P_m + R_m c_k - p - R P_IL) with
 // c_k = {(0,0,0),(0,s,0),(s,s,0),(s,0,0)} (marker frame of vision.cpp:736-759); Jacobian blocks as the
 // reference's position rows (MeasureUpdate.m:72-73) with the corner in place of the marker origin.
-template <typename T, int N, int COV>
-__device__ __forceinline__ void corner_update(T* P, T* dx, const T* pqr, const DevConst<T>& dc,
-                                              const T* __restrict__ mk, const T* C, T size)
+// The 12 rows go into the information accumulator (same column support as the marker rows), so any number of
+// markers is again six scalar updates (joint_update).
+template <typename T, int N>
+__device__ __forceinline__ void corner_info(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc,
+                                            const T* __restrict__ mk, const T* C, T size, T w_pos)
 {
     using L = Lay<N>;
     const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
@@ -931,8 +933,7 @@ __device__ __forceinline__ void corner_update(T* P, T* dx, const T* pqr, const D
             Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-            scalar_update<T, N, true, COV>(P, dx, Hpp + 3 * a, Hpt + 3 * a, C[3 * k + a] - hp[a], dc.r_pos);
+        for (int a = 0; a < 3; ++a) acc.add6(Hpp + 3 * a, Hpt + 3 * a, C[3 * k + a] - hp[a], w_pos);
     }
 }
 

@@ -215,7 +215,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
 
     using RC = Rec<T, N>;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
-    T P[RC::NCOVP];
+    T P[RC::NCOVP], nom[L::NNOM];
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
@@ -223,8 +223,9 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     if constexpr (JOINT) {
         // all visible markers at one linearisation point: their rows are folded into the 6x6 information matrix
         // while the covariance is still on its way in, then applied as six scalar updates (joint_update)
-        T pqr[L::NPQR];
-        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
+        // the whole nominal state comes in up front (p, q, R for the rows; v, ba, bg, g only for the injection --
+        // 12 registers that save a dependent reload between the last update and the stores)
+        load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
         load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
         InfoAcc<T> acc;
         acc.clear();
@@ -236,7 +237,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             if (slot < 0) continue;
             const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
             const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
-            marker_info<T, N, DIALECT>(acc, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq, w_pos, w_quat);
+            marker_info<T, N, DIALECT>(acc, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq, w_pos, w_quat);
             ++used;
         }
         if (used > 0) joint_update<T, N, COV>(P, dx, acc);
@@ -258,8 +259,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         }
     }
     if (used == 0) { applied[b] = 0; return; }
-    T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    if constexpr (!JOINT) load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     // the carried rotation is NOT refreshed by MeasureUpdate: chunks holding only R are left alone
@@ -401,12 +401,16 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         first = min_i; last = min_i + 1;
     }
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
-    T P[RC::NCOVP];
+    T P[RC::NCOVP], pqr[L::NPQR];
+    load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
     load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0;
+    InfoAcc<T> acc;
+    acc.clear();
+    const T w_pos = T(1) / dc.r_pos;
     for (int i = first; i < last; ++i) {
         const int id = my_ids[i];
         if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
@@ -415,11 +419,10 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         T C[12];
 #pragma unroll
         for (int c = 0; c < 4; ++c) corner(i, c, C + 3 * c);
-        T pqr[L::NPQR];
-        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
-        corner_update<T, N, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, C, size);
+        corner_info<T, N>(acc, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, C, size, w_pos);
         ++used;
     }
+    if (used > 0) joint_update<T, N, COV>(P, dx, acc);
     if (used == 0) { applied[b] = 0; return; }
     T nom[L::NNOM];
     load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
