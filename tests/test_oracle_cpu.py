@@ -201,3 +201,79 @@ def test_predict_keeps_covariance_symmetric_psd_and_biases_constant():
     for Pk in P:
         assert np.abs(Pk - Pk.T).max() == 0
         assert np.linalg.eigvalsh(Pk).min() > 0
+
+
+# ---------------------------------------------------------------- the stacked kernel's algebra
+def _info_compressed_update(P, H, res, Rdiag, drop_tol=4e-15):
+    """numpy restatement of what the stacked correct kernel does (ekf_device.hpp: InfoAcc / joint_update /
+    scalar_update_info): fold the rows into the 6x6 information matrix of the (p, theta) columns, L D L', six scalar
+    updates in information form.  Returns dx, P'."""
+    J = [0, 1, 2, 6, 7, 8]
+    assert not np.any(np.delete(H, J, axis=1)), "rows must live in the p / theta columns"
+    n = P.shape[0]
+    Lam = np.zeros((6, 6)); b = np.zeros(6)
+    for h, r, Rk in zip(H, res, Rdiag):
+        Lam += np.outer(h[J], h[J]) / Rk
+        b += h[J] * r / Rk
+    A, beta, d, L = Lam.copy(), b.copy(), np.zeros(6), np.eye(6)
+    dg0 = np.diag(Lam).copy()
+    for a in range(6):
+        ok = A[a, a] > drop_tol * dg0[a]
+        d[a] = A[a, a] if ok else 0.0
+        if not ok:
+            beta[a] = 0.0
+        L[a + 1:, a] = A[a, a + 1:] / A[a, a] if ok else 0.0
+        for i in range(a + 1, 6):
+            A[i, i:] -= L[i, a] * A[a, i:]
+            A[i:, i] = A[i, i:]
+            beta[i] -= L[i, a] * beta[a]
+    P = P.copy(); dx = np.zeros(n)
+    for a in range(6):
+        h = np.zeros(n); h[J] = L[:, a]
+        Ph = P @ h
+        is_ = 1.0 / (1.0 + d[a] * (h @ Ph))
+        dx = dx + Ph * (is_ * (beta[a] - d[a] * (h @ dx)))
+        P = P - np.outer(Ph * (d[a] * is_), Ph)
+    return dx, P
+
+
+@pytest.mark.parametrize("dialect", [0, 1])
+@pytest.mark.parametrize("M", [1, 3, 12])
+def test_information_compressed_update_is_the_dense_stacked_update(dialect, M):
+    """K = P H'(H P H' + R)^-1 (MeasureUpdate.m:84-90 with all visible markers stacked) against the 6-update form."""
+    rng = np.random.default_rng(11 + M)
+    prm = onp.Params(dialect, 18)
+    g = np.load(os.path.join(GOLD, "ekf_random.npz"))
+    t = f"d{dialect}_n18"
+    nom, rot, P, prev = [g[t + k][:8].copy() for k in ("_nom", "_rot", "_P", "_prev")]
+    for s in _np_states(nom, rot, P, prev, 18):
+        mids = rng.choice(sorted(prm.markers), M, replace=False)
+        rows, res = [], []
+        for mid in mids:
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            H, r = onp._rows(s, prm, int(mid), rng.normal(0, 0.5, 3), q)
+            rows.append(H); res.append(r)
+        H, r = np.vstack(rows), np.concatenate(res)
+        Rd = np.tile([prm.r_pos] * 3 + [prm.r_quat] * 4, M)
+        K = s.P @ H.T @ np.linalg.inv(H @ s.P @ H.T + np.diag(Rd))
+        dx_ref, P_ref = K @ r, (np.eye(18) - K @ H) @ s.P
+        dx, Pn = _info_compressed_update(s.P, H, r, Rd)
+        assert np.abs(dx - dx_ref).max() <= 1e-9 * max(1.0, np.abs(dx_ref).max())
+        assert np.abs(Pn - P_ref).max() <= 1e-9 * np.abs(P_ref).max()
+
+
+def test_information_compressed_update_drops_directions_without_information():
+    """rows that span only part of the (p, theta) space: the L D L' pivots of the missing directions are zero and must
+    be no-ops (position rows of one marker only: rank 3 of 6)"""
+    prm = onp.Params(0, 18)
+    g = np.load(os.path.join(GOLD, "ekf_random.npz"))
+    nom, rot, P, prev = [g["d0_n18" + k][:4].copy() for k in ("_nom", "_rot", "_P", "_prev")]
+    for s in _np_states(nom, rot, P, prev, 18):
+        H, r = onp._rows(s, prm, 16, np.array([0.1, -0.2, 0.8]), np.array([1.0, 0, 0, 0]))
+        H, r = np.vstack([H[:3], H[:3]]), np.concatenate([r[:3], r[:3] + 0.01])      # duplicated rows: still rank 3
+        Rd = np.full(6, prm.r_pos)
+        K = s.P @ H.T @ np.linalg.inv(H @ s.P @ H.T + np.diag(Rd))
+        dx, Pn = _info_compressed_update(s.P, H, r, Rd)
+        assert np.isfinite(dx).all() and np.isfinite(Pn).all()
+        assert np.abs(dx - K @ r).max() <= 1e-9 * max(1.0, np.abs(K @ r).max())
+        assert np.abs(Pn - (np.eye(18) - K @ H) @ s.P).max() <= 1e-9 * np.abs(s.P).max()
