@@ -233,27 +233,16 @@ int main()
         return 0;
     }
     if (getenv("SEQ")) {
-        for (int pool : {1, 8, 32, 96, 96, 1, 1}) run_lib(recs, acc, gyr, dt, B, pool);
-        for (int pool : {1, 1, 8, 8, 32, 96, 1, 1}) run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, false, pool);
-        run<1, 0>(recs, acc, gyr, dt, d_st, B, "staged stream, plain stores", 1, 0, false, 8);
-        for (int pool : {8, 8, 1, 1}) run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, false, pool);
-        return 0;
-        run_lib(recs, acc, gyr, dt, B, 8);
-        run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, false, 1);
-        run_lib(recs, acc, gyr, dt, B, 1);
-        run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, false, 8);
-        run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, false, 1);
-        run_lib(recs, acc, gyr, dt, B, 1);
+        // Infinity Cache residency: the same launches with the IMU sample taken from a pool of 1 .. 96 slices
+        // (build with -DIMU_NT for non-temporal IMU loads: the times then stay at the pool-1 level)
+        for (int pool : {1, 1, 8, 32, 96, 1, 1}) run_lib(recs, acc, gyr, dt, B, pool);
         return 0;
     }
-    run_lib(recs, acc, gyr, dt, B, 1);
     run_lib(recs, acc, gyr, dt, B, 8);
-    run<0, 0>(recs, acc, gyr, dt, d_st, B, "load / compute / store, plain stores");
-    run<0, 2>(recs, acc, gyr, dt, d_st, B, "load / compute / store, nt stores");
-    run<1, 0>(recs, acc, gyr, dt, d_st, B, "staged stream, plain stores");
-    run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores");
-    run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores, IMU pool 8", 1, 0, true, 8);
-    run<0, 2>(recs, acc, gyr, dt, d_st, B, "load / compute / store, nt stores, IMU pool 8", 1, 0, true, 8);
-    run_lib(recs, acc, gyr, dt, B, 1);
+    run<0, 0>(recs, acc, gyr, dt, d_st, B, "load / compute / store, plain stores", 1, 0, true, 8);
+    run<0, 2>(recs, acc, gyr, dt, d_st, B, "load / compute / store, nt stores", 1, 0, true, 8);
+    run<1, 0>(recs, acc, gyr, dt, d_st, B, "staged stream, plain stores", 1, 0, true, 8);
+    run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, true, 8);
+    run_lib(recs, acc, gyr, dt, B, 8);
     return 0;
 }

@@ -8,6 +8,7 @@
 //                 compute phase of predict; all waves of a launch run load -> compute -> store together)
 //   split S       the batch split over S streams (S launches of B/S filters issued round-robin), so that the
 //                 compute phase of one part can overlap the memory phases of another
+//   nt stores     the same with non-temporal stores (what the library kernel uses)
 // Build: hipcc --offload-arch=gfx950 -O3 tools/exp_stream_floor.hip -o tools/_build/exp_floor
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,7 +20,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int NCH = 50;
 
-template <int L>
+template <int L, int SAUX>
 __global__ __launch_bounds__(64) void stream_kernel(float* rec, int tile0)
 {
     const int tile = tile0 + blockIdx.x;
@@ -50,10 +51,10 @@ __global__ __launch_bounds__(64) void stream_kernel(float* rec, int tile0)
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
         if (c < 5 || (c >= 7 && c < 40))
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v[c]), rs, vo, c * 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v[c]), rs, vo, c * 1024, SAUX);
 }
 
-template <int L>
+template <int L, int SAUX = 0>
 static double run(float* d, int B, int S, int reps, hipStream_t* st)
 {
     const int tiles = B / 64, per = tiles / S;
@@ -62,7 +63,7 @@ static double run(float* d, int B, int S, int reps, hipStream_t* st)
     for (int s = 0; s < S; ++s) CK(hipEventCreateWithFlags(&join[s], hipEventDisableTiming));
     auto body = [&](int n) {
         for (int r = 0; r < n; ++r)
-            for (int s = 0; s < S; ++s) stream_kernel<L><<<per, 64, 0, st[s]>>>(d, s * per);
+            for (int s = 0; s < S; ++s) stream_kernel<L, SAUX><<<per, 64, 0, st[s]>>>(d, s * per);
     };
     body(20);
     for (int s = 0; s < S; ++s) CK(hipStreamSynchronize(st[s]));
@@ -86,7 +87,13 @@ int main()
         const double mb = B * (NCH + 38) * 16 / 1e6;
         const int reps = B > 65536 ? 50 : 200;
         printf("B=%d  (%.1f MB moved per pass)\n", B, mb);
-        for (int S : {1, 2, 4}) {
+        {
+            double t;
+            t = run<0, 2>(d, B, 1, reps, st);    printf("  nt stores  copy      %7.2f us  %6.0f GB/s\n", t, mb / t * 1e3);
+            t = run<800, 2>(d, B, 1, reps, st);  printf("  nt stores  fma 800   %7.2f us  %6.0f GB/s\n", t, mb / t * 1e3);
+            t = run<1600, 2>(d, B, 1, reps, st); printf("  nt stores  fma 1600  %7.2f us  %6.0f GB/s\n", t, mb / t * 1e3);
+        }
+        for (int S : {1, 2}) {
             double t;
             t = run<0>(d, B, S, reps, st);    printf("  split %d  copy      %7.2f us  %6.0f GB/s\n", S, t, mb / t * 1e3);
             t = run<800>(d, B, S, reps, st);  printf("  split %d  fma 800   %7.2f us  %6.0f GB/s\n", S, t, mb / t * 1e3);
