@@ -41,6 +41,9 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_CORRECT_ST
 #define FBUS_X_CORRECT_ST AUX_DEFAULT
 #endif
+#ifndef FBUS_X_SPLIT
+#define FBUS_X_SPLIT RC::CH_VAR_END
+#endif
 #ifndef FBUS_X_MEAS_NT
 #define FBUS_X_MEAS_NT 0
 #endif
@@ -92,6 +95,93 @@ __device__ __forceinline__ size_t elem_index(size_t b, int e)
     constexpr int EPC = Rec<T, N>::EPC;
     return ((b >> 6) * Rec<T, N>::NCH + (size_t)(e / EPC)) * (64 * EPC) + (b & 63) * EPC + (e % EPC);
 }
+
+// Keeps memory instructions in source order: an empty asm with a memory clobber for the IR passes (sched_barrier is
+// not a memory operation for them) and a sched_barrier for the machine scheduler.
+__device__ __forceinline__ void order_fence()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Marker map in LDS.  A measurement names its marker by ArUco id: id -> map slot -> map constants are two dependent
+// lookups.  As vector loads they queue behind the 50 KiB of record loads the wave already has in flight (vector loads
+// return in issue order), so the rows of the first marker could not be built before the whole covariance had landed
+// plus two more round trips (tools/exp_correct_timeline.hip: rows folded 10.9 us after entry).  The tables are small
+// (2 KiB + 1 KiB), so every workgroup copies them to LDS with its first loads and looks them up there: LDS reads
+// count on lgkmcnt and do not wait for the record stream.
+template <typename T>
+struct alignas(16) MarkerLDS {
+    short id2slot[FBUS_MAX_MARKER_ID + 1];
+    T mk[FBUS_MAX_MARKERS * MK_STRIDE];
+};
+template <typename T>
+struct MarkerTableRegs {            // the global -> register half of the copy (issued before the record loads)
+    static constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(T) * FBUS_MAX_MARKERS * MK_STRIDE / 16;
+    static constexpr int PI = (NI + BLOCK - 1) / BLOCK, PM = (NM + BLOCK - 1) / BLOCK;
+    u32x4 vi[PI], vm[PM];
+    __device__ __forceinline__ void load(const DevConst<T>& dc)
+    {
+        const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
+        const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
+#pragma unroll
+        for (int k = 0; k < PI; ++k) { const int i = threadIdx.x + k * BLOCK; vi[k] = si[(NI % BLOCK == 0 || i < NI) ? i : 0]; }
+#pragma unroll
+        for (int k = 0; k < PM; ++k) { const int i = threadIdx.x + k * BLOCK; vm[k] = sm[(NM % BLOCK == 0 || i < NM) ? i : 0]; }
+    }
+    __device__ __forceinline__ void to_lds(MarkerLDS<T>& t) const
+    {
+        u32x4* di = reinterpret_cast<u32x4*>(t.id2slot);
+        u32x4* dm = reinterpret_cast<u32x4*>(t.mk);
+        // no branches here (straight-line code keeps the compiler's s_waitcnt bookkeeping exact: the writes must wait
+        // for the map pieces only, not for the record loads issued behind them)
+#pragma unroll
+        for (int k = 0; k < PI; ++k) { const int i = threadIdx.x + k * BLOCK; if (NI % BLOCK == 0 || i < NI) di[i] = vi[k]; }
+#pragma unroll
+        for (int k = 0; k < PM; ++k) { const int i = threadIdx.x + k * BLOCK; if (NM % BLOCK == 0 || i < NM) dm[i] = vm[k]; }
+        if constexpr (BLOCK > 64) __syncthreads();      // one wave per workgroup needs no barrier: LDS ops are in order
+    }
+};
+
+// The measurements of up to G marker slots [i0, i0 + G) of one filter: ids and poses in ONE round of loads (fetch),
+// the map lookups from LDS (resolve).  Slots past `last` and markers that are invisible / not in the map come back
+// with slot = -1.
+#ifndef FBUS_MARKER_GROUP
+#define FBUS_MARKER_GROUP 4
+#endif
+template <typename T, int G>
+struct MarkerGroup {
+    int id[G], slot[G], n;          // n = slots of this group that exist (the loaded values are not touched in fetch)
+    T yp[G][3], yq[G][4], mk[G][MK_STRIDE];
+    __device__ __forceinline__ void fetch(const int* my_ids, const T* my_pos, const T* my_quat, int i0, int last)
+    {
+        n = last - i0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = (i0 + g < last) ? i0 + g : last - 1;
+            id[g] = my_ids[i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) yp[g][k] = ld_meas(my_pos + 3 * i + k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yq[g][k] = ld_meas(my_quat + 4 * i + k);
+        }
+    }
+    __device__ __forceinline__ void resolve(const MarkerLDS<T>& t)
+    {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool ok = g < n && id[g] >= 0 && id[g] <= FBUS_MAX_MARKER_ID;
+            const int s_ = t.id2slot[ok ? id[g] : 0];
+            slot[g] = ok ? s_ : -1;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const T* m = t.mk + (slot[g] < 0 ? 0 : slot[g]) * MK_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) mk[g][k] = m[k];
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------
 // kernels
@@ -177,17 +267,44 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
                unsigned char* __restrict__ applied, DevConst<T> dc)
 {
     using L = Lay<N>;
+    using RC = Rec<T, N>;
     const int b = blockIdx.x * BLOCK + threadIdx.x;
-    if (b >= B) return;
-    if (skip && skip[b]) { applied[b] = 0; return; }
+    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
+    const int* my_ids = ids + (size_t)(live ? b : 0) * M;
+    const T* my_pos = pos + (size_t)(live ? b : 0) * M * 3;
+    const T* my_quat = quat + (size_t)(live ? b : 0) * M * 4;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T P[RC::NCOVP], nom[L::NNOM];
+    __shared__ MarkerLDS<T> tbl;
+    MarkerGroup<T, FBUS_MARKER_GROUP> mg;
+    if constexpr (JOINT) {
+        // load order = need order: the marker map (every lane carries a piece of it to LDS, live or not), the first
+        // group's measurements, the nominal state, then the covariance; the LDS copy only waits for the map pieces
+        MarkerTableRegs<T> treg;
+        // (issued by every lane, skipped or past B: their addresses are clamped / their tile exists -- straight-line code)
+        // The sched_barriers pin this order: left alone the scheduler moved two nominal chunks behind the covariance
+        // loads and the LDS writes in front of them, and vector loads return in issue order.
+        treg.load(dc);
+        order_fence();
+        if (M > 0) mg.fetch(my_ids, my_pos, my_quat, 0, M);
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+        order_fence();
+        load_chunks<T, N, RC::CH_NOM, FBUS_X_SPLIT, AUX_NT>(rs, my_lane(), P);
+        order_fence();
+        treg.to_lds(tbl);
+        order_fence();
+    }
+    // JOINT: lanes that are skipped or past B keep running (no markers: last = 0) and leave at "used == 0" -- an early
+    // exit here would let the compiler sink some of the loads above into the live branch, behind the covariance loads
+    if constexpr (!JOINT) {
+        if (b >= B) return;
+        if (!live) { applied[b] = 0; return; }
+    }
 
-    const int* my_ids = ids + (size_t)b * M;
-    const T* my_pos = pos + (size_t)b * M * 3;
-    const T* my_quat = quat + (size_t)b * M * 4;
-
-    int first = 0, last = M;            // marker slots [first, last) to apply
+    int first = 0, last = (!JOINT || live) ? M : 0;            // marker slots [first, last) to apply
     int new_prev = -1;
-    if (mode == MODE_NEAREST) {
+    if (!JOINT && mode == MODE_NEAREST) {
         // recs is re-read below; only the previous-marker id is needed for the selection
         int prev_id = 0;
         if (DIALECT == DIALECT_CPP) {
@@ -213,33 +330,37 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         first = min_i; last = min_i + 1;
     }
 
-    using RC = Rec<T, N>;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
-    T P[RC::NCOVP], nom[L::NNOM];
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0;
     if constexpr (JOINT) {
         // all visible markers at one linearisation point: their rows are folded into the 6x6 information matrix
-        // while the covariance is still on its way in, then applied as six scalar updates (joint_update)
-        // the whole nominal state comes in up front (p, q, R for the rows; v, ba, bg, g only for the injection --
+        // while the covariance is still on its way in, then applied as six scalar updates (joint_update).
+        // The whole nominal state came in up front (p, q, R for the rows; v, ba, bg, g only for the injection --
         // 12 registers that save a dependent reload between the last update and the stores)
-        load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
-        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
         InfoAcc<T> acc;
         acc.clear();
         const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
-        for (int i = first; i < last; ++i) {
-            const int id = my_ids[i];
-            if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
-            const int slot = dc.id2slot[id];
-            if (slot < 0) continue;
-            const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
-            const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
-            marker_info<T, N, DIALECT>(acc, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq, w_pos, w_quat);
-            ++used;
+        auto fold_group = [&]() {
+            mg.resolve(tbl);
+#pragma unroll
+            for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
+                if (mg.slot[g] < 0) continue;
+                marker_info<T, N, DIALECT>(acc, nom, dc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                ++used;
+            }
+        };
+        // the first group (fetched in the prologue) unconditionally -- a lane without markers has n = 0 and folds
+        // nothing -- so that the nominal loads it needs stay where they were issued; further groups in a loop
+        if (last == 0) mg.n = 0;
+        fold_group();
+        for (int i0 = FBUS_MARKER_GROUP; i0 < last; i0 += FBUS_MARKER_GROUP) {
+            mg.fetch(my_ids, my_pos, my_quat, i0, last);
+            fold_group();
         }
+        order_fence();
+        load_chunks<T, N, FBUS_X_SPLIT, RC::NCH, AUX_NT>(rs, my_lane(), P + (FBUS_X_SPLIT - RC::CH_NOM) * RC::EPC);
         if (used > 0) joint_update<T, N, COV>(P, dx, acc);
     } else {
         load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
@@ -258,7 +379,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             ++used;
         }
     }
-    if (used == 0) { applied[b] = 0; return; }
+    if (used == 0) { if (b < B) applied[b] = 0; return; }
     if constexpr (!JOINT) load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
@@ -283,6 +404,12 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     using L = Lay<N>;
     using RC = Rec<T, N>;
     const int b = blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ MarkerLDS<T> tbl;                      // the marker map, looked up from LDS (see MarkerLDS)
+    {
+        MarkerTableRegs<T> treg;
+        treg.load(dc);
+        treg.to_lds(tbl);
+    }
     if (b >= B) return;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
@@ -334,16 +461,17 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     constexpr bool joint = JOINT;
     const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
     if (joint) acc.clear();
-    for (int i = first; i < last; ++i) {
-        const int id = my_ids[i];
-        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
-        const int slot = dc.id2slot[id];
-        if (slot < 0) continue;
-        const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
-        const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
-        if constexpr (joint) marker_info<T, N, DIALECT>(acc, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq, w_pos, w_quat);
-        else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
-        ++used;
+    for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
+        MarkerGroup<T, FBUS_MARKER_GROUP> mg;
+        mg.fetch(my_ids, my_pos, my_quat, i0, last);
+        mg.resolve(tbl);
+#pragma unroll
+        for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
+            if (mg.slot[g] < 0) continue;
+            if constexpr (joint) marker_info<T, N, DIALECT>(acc, nom, dc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+            else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mg.mk[g], mg.yp[g], mg.yq[g]);
+            ++used;
+        }
     }
     if constexpr (joint) { if (used > 0) joint_update<T, N, COV>(P, dx, acc); }
     if (used > 0) {

@@ -71,7 +71,7 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
     rotmat_to_quat(hc.R_IL, hc.Q_IL);
     if (prm.n_markers < 0 || prm.n_markers > FBUS_MAX_MARKERS) { err = "n_markers out of range"; return false; }
     hc.id2slot.assign(FBUS_MAX_MARKER_ID + 1, (short)-1);
-    hc.mk.assign((size_t)std::max(prm.n_markers, 1) * MK_STRIDE, 0.0);
+    hc.mk.assign((size_t)FBUS_MAX_MARKERS * MK_STRIDE, 0.0);        // always the full table: kernels copy it to LDS whole
     const double w = hc.Q_IL[0], x = hc.Q_IL[1], y = hc.Q_IL[2], z = hc.Q_IL[3];
     // Lq(Q_IL) * L2, L2 = diag(1,-1,-1,-1)   MeasureUpdate.m:39-44
     const double LL2[16] = { w,  x,  y,  z,
