@@ -259,7 +259,14 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
 }
 
 // JOINT = stacked mode (all visible markers at one linearisation point) through the information-compressed joint
-// update; !JOINT = the reference's behaviour, one (nearest) marker applied row by row.
+// update; !JOINT = the reference's behaviour, the nearest marker (C++ dialect: with hysteresis) applied row by row.
+//
+// Both paths share the prologue.  Vector loads return in issue order, so it issues them in need order -- the marker map
+// (every lane carries a piece of it to LDS), the first group's measurements, the nominal state, then the covariance
+// -- and keeps that order with order_fence(); the arithmetic that needs only the early loads (the rows of the markers)
+// then runs while the covariance is still on its way in.  Lanes that are skipped or past B run along with no markers
+// and leave before the stores: an early exit in front of the loads would let the compiler sink loads into the live
+// branch, behind the covariance stream.
 template <typename T, int N, int DIALECT, int COV, bool JOINT>
 __global__ void __launch_bounds__(BLOCK)
 correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
@@ -268,84 +275,54 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
 {
     using L = Lay<N>;
     using RC = Rec<T, N>;
+    constexpr int G = FBUS_MARKER_GROUP;
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     const bool live = b < B && !(skip && skip[b < B ? b : 0]);
-    const int* my_ids = ids + (size_t)(live ? b : 0) * M;
-    const T* my_pos = pos + (size_t)(live ? b : 0) * M * 3;
-    const T* my_quat = quat + (size_t)(live ? b : 0) * M * 4;
+    const int bc = live ? b : 0;
+    const int* my_ids = ids + (size_t)bc * M;
+    const T* my_pos = pos + (size_t)bc * M * 3;
+    const T* my_quat = quat + (size_t)bc * M * 4;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T P[RC::NCOVP], nom[L::NNOM];
     __shared__ MarkerLDS<T> tbl;
-    MarkerGroup<T, FBUS_MARKER_GROUP> mg;
-    if constexpr (JOINT) {
-        // load order = need order: the marker map (every lane carries a piece of it to LDS, live or not), the first
-        // group's measurements, the nominal state, then the covariance; the LDS copy only waits for the map pieces
+    MarkerGroup<T, G> mg;
+    // the stacked path asks for the predict-invariant covariance tail behind the fold: fewer registers are tied up
+    // while the rows are built, and the first scalar update only needs it for its last rows
+    constexpr int C_SPLIT = JOINT ? FBUS_X_SPLIT : RC::NCH;
+    T prev_raw = T(0);
+    {
         MarkerTableRegs<T> treg;
-        // (issued by every lane, skipped or past B: their addresses are clamped / their tile exists -- straight-line code)
-        // The sched_barriers pin this order: left alone the scheduler moved two nominal chunks behind the covariance
-        // loads and the LDS writes in front of them, and vector loads return in issue order.
         treg.load(dc);
         order_fence();
+        if (!JOINT && DIALECT == DIALECT_CPP) prev_raw = recs[elem_index<T, N>(bc, L::OFF_PREV)];
         if (M > 0) mg.fetch(my_ids, my_pos, my_quat, 0, M);
         order_fence();
+        // the whole nominal state up front (p, q, R for the rows; v, ba, bg, g only for the injection -- 12 registers
+        // that save a dependent reload between the last update and the stores)
         load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
         order_fence();
-        load_chunks<T, N, RC::CH_NOM, FBUS_X_SPLIT, AUX_NT>(rs, my_lane(), P);
+        load_chunks<T, N, RC::CH_NOM, C_SPLIT, AUX_NT>(rs, my_lane(), P);
         order_fence();
         treg.to_lds(tbl);
         order_fence();
     }
-    // JOINT: lanes that are skipped or past B keep running (no markers: last = 0) and leave at "used == 0" -- an early
-    // exit here would let the compiler sink some of the loads above into the live branch, behind the covariance loads
-    if constexpr (!JOINT) {
-        if (b >= B) return;
-        if (!live) { applied[b] = 0; return; }
-    }
-
-    int first = 0, last = (!JOINT || live) ? M : 0;            // marker slots [first, last) to apply
-    int new_prev = -1;
-    if (!JOINT && mode == MODE_NEAREST) {
-        // recs is re-read below; only the previous-marker id is needed for the selection
-        int prev_id = 0;
-        if (DIALECT == DIALECT_CPP) {
-            prev_id = (int)recs[elem_index<T, N>(b, L::OFF_PREV)];
-        }
-        // nearest visible marker, start threshold 10   MeasureUpdate.m:51-60 ; filter.cpp:639-664
-        int min_i = -1, prev_i = -1;
-        T min_d = T(10), prev_d = T(0);
-        for (int i = 0; i < M; ++i) {
-            const int id = my_ids[i];
-            if (id < 0) continue;
-            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
-            const T dist = fb_sqrt(x * x + y * y + z * z);
-            if (dist < min_d) { min_d = dist; min_i = i; }
-            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
-        }
-        if (min_i < 0) { applied[b] = 0; return; }
-        if (DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
-        const int id = my_ids[min_i];
-        const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
-        if (slot < 0) { applied[b] = 0; return; }              // filter.cpp:671-673
-        if (DIALECT == DIALECT_CPP) new_prev = id;              // filter.cpp:675
-        first = min_i; last = min_i + 1;
-    }
-
+    const int last = live ? M : 0;
+    if (last == 0) mg.n = 0;
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
-    int used = 0;
+    int used = 0, new_prev = -1;
+
     if constexpr (JOINT) {
-        // all visible markers at one linearisation point: their rows are folded into the 6x6 information matrix
-        // while the covariance is still on its way in, then applied as six scalar updates (joint_update).
-        // The whole nominal state came in up front (p, q, R for the rows; v, ba, bg, g only for the injection --
-        // 12 registers that save a dependent reload between the last update and the stores)
+        // all visible markers: their rows are folded into the 6x6 information matrix while the covariance is still
+        // on its way in, then applied as six scalar updates (joint_update)
         InfoAcc<T> acc;
         acc.clear();
         const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
         auto fold_group = [&]() {
             mg.resolve(tbl);
 #pragma unroll
-            for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
+            for (int g = 0; g < G; ++g) {
                 if (mg.slot[g] < 0) continue;
                 marker_info<T, N, DIALECT>(acc, nom, dc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
                 ++used;
@@ -353,34 +330,68 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         };
         // the first group (fetched in the prologue) unconditionally -- a lane without markers has n = 0 and folds
         // nothing -- so that the nominal loads it needs stay where they were issued; further groups in a loop
-        if (last == 0) mg.n = 0;
         fold_group();
-        for (int i0 = FBUS_MARKER_GROUP; i0 < last; i0 += FBUS_MARKER_GROUP) {
+        for (int i0 = G; i0 < last; i0 += G) {
             mg.fetch(my_ids, my_pos, my_quat, i0, last);
             fold_group();
         }
         order_fence();
-        load_chunks<T, N, FBUS_X_SPLIT, RC::NCH, AUX_NT>(rs, my_lane(), P + (FBUS_X_SPLIT - RC::CH_NOM) * RC::EPC);
+        load_chunks<T, N, C_SPLIT, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_SPLIT - RC::CH_NOM) * RC::EPC);
         if (used > 0) joint_update<T, N, COV>(P, dx, acc);
     } else {
-        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
-        for (int i = first; i < last; ++i) {
-            const int id = my_ids[i];
-            if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
-            const int slot = dc.id2slot[id];
-            if (slot < 0) continue;
-            const T yp[3] = { ld_meas(my_pos + 3 * i), ld_meas(my_pos + 3 * i + 1), ld_meas(my_pos + 3 * i + 2) };
-            const T yq[4] = { ld_meas(my_quat + 4 * i), ld_meas(my_quat + 4 * i + 1), ld_meas(my_quat + 4 * i + 2), ld_meas(my_quat + 4 * i + 3) };
-            // the linearisation point (p, q, R) is not modified until inject(): it is re-read per marker
-            // (an L2 hit) instead of being held in registers across the seven rank-1 updates
-            T pqr[L::NPQR];
-            load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
-            marker_update<T, N, DIALECT, COV>(P, dx, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, yp, yq);
-            ++used;
+        // nearest visible marker, start threshold 10   MeasureUpdate.m:51-60 ; filter.cpp:639-664.
+        // The candidates keep their measurement with them: no reload behind the covariance stream.
+        const int prev_id = (int)prev_raw;
+        int min_id = -1, pv_id = -1;
+        T min_d = T(10), prev_d = T(0);
+        T min_y[7], pv_y[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { min_y[k] = T(0); pv_y[k] = T(0); }
+        auto scan_group = [&]() {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int id = mg.id[g];
+                if (g >= mg.n || id < 0) continue;
+                const T x = mg.yp[g][0], y = mg.yp[g][1], z = mg.yp[g][2];
+                const T dist = fb_sqrt(x * x + y * y + z * z);
+                if (dist < min_d) {
+                    min_d = dist; min_id = id;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) min_y[k] = mg.yp[g][k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) min_y[3 + k] = mg.yq[g][k];
+                }
+                if (DIALECT == DIALECT_CPP && id == prev_id) {
+                    prev_d = dist; pv_id = id;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) pv_y[k] = mg.yp[g][k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pv_y[3 + k] = mg.yq[g][k];
+                }
+            }
+        };
+        scan_group();
+        for (int i0 = G; i0 < last; i0 += G) {
+            mg.fetch(my_ids, my_pos, my_quat, i0, last);
+            scan_group();
+        }
+        if (min_id >= 0 && DIALECT == DIALECT_CPP && pv_id >= 0 && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) {
+            min_id = pv_id;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) min_y[k] = pv_y[k];
+        }
+        const bool ok = min_id >= 0 && min_id <= FBUS_MAX_MARKER_ID;
+        const int slot = ok ? (int)tbl.id2slot[ok ? min_id : 0] : -1;              // filter.cpp:671-673
+        if (slot >= 0) {
+            if (DIALECT == DIALECT_CPP) new_prev = min_id;                           // filter.cpp:675
+            T mk[MK_STRIDE];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
+            marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mk, min_y, min_y + 3);
+            used = 1;
         }
     }
     if (used == 0) { if (b < B) applied[b] = 0; return; }
-    if constexpr (!JOINT) load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     // the carried rotation is NOT refreshed by MeasureUpdate: chunks holding only R are left alone
