@@ -284,6 +284,62 @@ def test_skip_mask_and_state_roundtrip():
         assert np.allclose(P0, np.diag(np.repeat(np.array(list(prm.p0_diag)), 3))[None])
 
 
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_nearest_marker_among_many_slots(dialect):
+    """reference mode with more slots than one fetch group (12 markers spread over 16 slots): the nearest-marker scan
+    runs over four groups; in the C++ dialect the previously used marker sits in a late group (hysteresis,
+    filter.cpp:652-664) for half of the filters"""
+    B = 96                                          # not a multiple of 64: a ragged last tile
+    prm, nom, rot, P, prev = _batch(B, dialect, 18)
+    ids, pos, quat = _markers(0, B, 3, 12, nom, prm)
+    ids16 = np.full((B, 16), -1, np.int32); ids16[:, [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 14, 15]] = ids
+    pos16 = np.zeros((B, 16, 3)); quat16 = np.zeros((B, 16, 4)); quat16[:, :, 0] = 1
+    pos16[:, [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 14, 15]] = pos
+    quat16[:, [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 14, 15]] = quat
+    prev = np.where(np.arange(B) % 2 == 0, ids16[:, 14], prev).astype(np.int32)
+    for dtype in (32, 64):
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            eng = OracleEngine(B, dialect, 18)
+            flt.set_state(nom, rot, P, prev)
+            eng.set_state(nom, rot, P, prev)
+            flt.correct(ids16, pos16, quat16, 0)
+            ok = eng.correct(ids16, pos16, quat16, 0)
+            assert (flt.applied() == ok).all() and ok.all()
+            _check(flt, eng, dtype, f"nearest of 16 slots, dialect {dialect}")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_skip_mask_ragged_batch_and_invisible_markers(mode):
+    """lanes that are skipped, lanes past the batch end and filters without any visible marker run through the same
+    prologue as live lanes: nothing of theirs may be written"""
+    B, M = 100, 4
+    prm, nom, rot, P, prev = _batch(B, 1, 18)
+    ids, pos, quat = _markers(0, B, 1, M, nom, prm)
+    ids = ids.copy()
+    ids[5::10] = -1                                 # no visible marker at all
+    ids[3::10, 1:] = -1                             # one visible marker
+    ids[7::10, 0] = 999                             # an id that is not in the map (dropped; others still apply)
+    skip = (np.arange(B) % 4 == 1).astype(np.uint8)
+    with BatchedFilter(B, prm) as flt:
+        eng = OracleEngine(B, 1, 18)
+        flt.set_state(nom, rot, P, prev)
+        eng.set_state(nom, rot, P, prev)
+        flt.correct(ids, pos, quat, mode, skip)
+        keep = [x.copy() for x in eng.get_state()]
+        ok = eng.correct(ids, pos, quat, mode)
+        now = eng.get_state()
+        for x, y in zip(now, keep):
+            x[skip == 1] = y[skip == 1]
+        eng.set_state(*now)
+        ok[skip == 1] = 0
+        assert (flt.applied() == ok).all()
+        assert not ok[5::10].any()
+        _check(flt, eng, 32, f"skip + ragged, mode {mode}")
+        got = flt.get_state()
+        untouched = (ok == 0)
+        assert np.array_equal(got[0][untouched], nom[untouched].astype(np.float32).astype(np.float64))
+
+
 # ------------------------------------------------------------------ full size (BASELINE.json batch)
 def test_full_batch_properties_and_shard_equality():
     """B = 65 536 (the headline batch): size-independent properties instead of an oracle run --
