@@ -416,16 +416,21 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     using RC = Rec<T, N>;
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     __shared__ MarkerLDS<T> tbl;                      // the marker map, looked up from LDS (see MarkerLDS)
-    {
-        MarkerTableRegs<T> treg;
-        treg.load(dc);
-        treg.to_lds(tbl);
-    }
-    if (b >= B) return;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
-    load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, my_lane(), nom);
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+    {
+        // map pieces first, the record behind them, the LDS copy after both are on their way (lanes past B load
+        // their existing tile too: no branch in front of the loads)
+        MarkerTableRegs<T> treg;
+        treg.load(dc);
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        order_fence();
+        treg.to_lds(tbl);
+        order_fence();
+    }
+    if (b >= B) return;
     for (int k = 0; k < K; ++k) {
         const size_t o = ((size_t)k * B + b) * 3;
         const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
