@@ -88,6 +88,27 @@ def test_predict_single_step(dialect, n, dtype):
         _check(flt, eng, dtype, "predict scalar dt")
 
 
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_predict_large_rotation_increments(dialect):
+    """rotation increments on both sides of the 0.5 rad switch between the polynomial and the library sin/cos
+    (|w| dt / 2 from 0.05 to 1.5 rad: fast tumbling / long gaps between IMU samples), mixed inside one wave"""
+    B = 256
+    prm, nom, rot, P, prev = _batch(B, dialect, 18)
+    acc, gyr = _imu(0, B, 0, 1, nom)
+    rng = np.random.default_rng(5)
+    axis = rng.normal(size=(B, 3)); axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    half_angle = rng.uniform(0.05, 1.5, B)
+    dt = _r32(rng.uniform(0.02, 0.2, B))
+    gyr0 = _r32(axis * (2 * half_angle / dt)[:, None] + nom[:, 13:16])
+    with BatchedFilter(B, prm) as flt:
+        eng = OracleEngine(B, dialect, 18)
+        flt.set_state(nom, rot, P, prev)
+        eng.set_state(nom, rot, P, prev)
+        flt.predict(acc[0], gyr0, dt)
+        eng.predict(acc[0], gyr0, dt)
+        _check(flt, eng, 32, "predict, large rotation increments")
+
+
 @pytest.mark.parametrize("dtype", [32, 64])
 @pytest.mark.parametrize("n", [18, 15])
 @pytest.mark.parametrize("mode", [0, 1])
