@@ -43,6 +43,18 @@ def run(B, dtype, M, what, K=1, mode=1, reps=200):
         elif what == "predict_n":
             us = timed(flt, capi.KERNEL_PREDICT_N, lambda: flt.predict_n(d_acc, d_gyr, d_dt), reps)
             steps, bytes_ = B * K, (2 * 199 * es + 7 * es) * B * K
+        elif what == "correct_corners":
+            # north-star B2: stereo corner pixels -> refractive triangulation -> 12 rows per marker, on the device
+            ids, _, _ = synth.marker_frame(0, B, 0, min(M, 12), nom, prm)
+            if M > 12:
+                ids = np.concatenate([ids, np.full((B, M - 12), -1, np.int32)], axis=1)
+            c = np.load(os.path.join(ROOT, "tests", "golden", "vision_water.npz"))["corners"]
+            base = c[np.random.default_rng(1).integers(0, len(c), B * M)]
+            left, right = base[:, 2:10].reshape(B, M, 8), base[:, 10:18].reshape(B, M, 8)
+            d = (torch.from_numpy(ids).to(dev), tensors(left, tdt), tensors(right, tdt))
+            us = timed(flt, capi.KERNEL_CORRECT_CORNERS,
+                       lambda: flt.correct_corners(d[0], d[1], d[2], capi.VIS_REFRACTIVE, mode), reps)
+            steps, bytes_ = B, (2 * 199 * es + 17 * es * M) * B
         else:
             ids, pos, quat = synth.marker_frame(0, B, 0, min(M, 12), nom, prm)
             if M > 12:
@@ -62,12 +74,14 @@ for name, args in (
     ("2", dict(B=4096, dtype=32, M=0, what="predict_n", K=8)),
     ("3", dict(B=16384, dtype=32, M=4, what="correct", mode=0)),
     ("3", dict(B=16384, dtype=32, M=4, what="correct", mode=1)),
+    ("3", dict(B=16384, dtype=32, M=4, what="correct_corners", mode=1)),
     ("5", dict(B=65536, dtype=32, M=16, what="correct", mode=1, reps=50)),
+    ("5", dict(B=65536, dtype=32, M=16, what="correct_corners", mode=1, reps=30)),
     ("5", dict(B=65536, dtype=64, M=16, what="correct", mode=1, reps=20)),
     ("5", dict(B=65536, dtype=64, M=0, what="predict", reps=50)),
     ("-", dict(B=65536, dtype=32, M=1, what="correct", mode=0)),
 ):
     us, sps, gbs = run(**args)
     desc = f"B={args['B']} fp{args['dtype']} {args['what']}" + (f" K={args['K']}" if "K" in args else "") + \
-           (f" M={args['M']} {'stacked' if args.get('mode', 1) else 'nearest'}" if args["what"] == "correct" else "")
+           (f" M={args['M']} {'stacked' if args.get('mode', 1) else 'nearest'}" if args["what"].startswith("correct") else "")
     print(f"{name:>4}    {desc:<48} {us:9.2f}   {sps:13.4g}   {gbs:10.0f}")
