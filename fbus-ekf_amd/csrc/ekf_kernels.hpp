@@ -28,9 +28,10 @@ __device__ __forceinline__ unsigned my_lane() { return threadIdx.x & 63u; }
 // (wave-uniform base), the lane contributes a 32-bit offset, the piece index goes
 // into soffset/imm -- no per-piece 64-bit address lives in VGPRs.
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-// cache policy (aux) of a record load: 0 = default, 2 = nt (non-temporal).  Measured at B = 65 536: nt on the
-// once-read record stream of predict 18.05 -> 17.30 us; nt on lines that are re-read (the linearisation point in
-// correct) +9 %; nt on the stores +3..7 % -- so: nt for once-read loads only.
+// cache policy (aux) of a record access: 0 = default, 2 = nt (non-temporal).  Measured at B = 65 536:
+// nt on the once-read record stream of predict 18.05 -> 17.30 us; nt on lines that are re-read +9 %; nt STORES win in
+// the streamed predict kernel (the lines leave L2 while the launch still reads: 14.9 -> 14.0 us) and lose in correct
+// (its default-policy stores are what puts the records back into the Infinity Cache for the predicts that follow).
 constexpr int AUX_DEFAULT = 0, AUX_NT = 2;
 // Per-step inputs (IMU samples, marker measurements) are read once: nt as well.  Measured: with default-policy
 // loads of 1.5 MB of fresh IMU data per launch the nt-streamed records lose their Infinity Cache residency and a
@@ -96,8 +97,10 @@ __device__ __forceinline__ size_t elem_index(size_t b, int e)
     return ((b >> 6) * Rec<T, N>::NCH + (size_t)(e / EPC)) * (64 * EPC) + (b & 63) * EPC + (e % EPC);
 }
 
-// Keeps memory instructions in source order: an empty asm with a memory clobber for the IR passes (sched_barrier is
-// not a memory operation for them) and a sched_barrier for the machine scheduler.
+// Keeps memory instructions in source order within a block: an empty asm with a memory clobber plus a sched_barrier
+// for the machine scheduler.  It does NOT stop LLVM from sinking a buffer load into a later block that is its only
+// user -- the correct kernels avoid that structurally (no early exit in front of the loads, first marker group folded
+// unconditionally).
 __device__ __forceinline__ void order_fence()
 {
     asm volatile("" ::: "memory");
