@@ -200,7 +200,14 @@ struct MarkerGroup {
 // stage start when ITS chunks have landed), and each stage's chunks are stored as soon as they are final.
 // ba, bg, g and the covariance elements among ba, bg, g (off-diagonal) are not written by ImuUpdate: their chunks
 // stay as they are in HBM (N = 18: 33 of the 43 covariance chunks are stored).
-template <typename T, int N, int DIALECT, bool MULTI>
+//
+// LD = cache policy of the record loads.  Non-temporal in a run of predicts (each line is read once per launch); the
+// FIRST predict after a correct reads with the default policy: correct stores with the default policy, its lines are
+// still in the XCD L2s, and nt loads of such lines were measured slow (first predict after a correct 15.8 us with nt
+// loads, 14.2 us with default loads, and the following launches reach their steady 12.6 us two launches earlier:
+// -5 us per camera frame; default-policy STORES there, or default loads for a second launch, lose again --
+// tools/exp_gap_after_correct.py under rocprofv3, reduced by tools/trace_positions.py).
+template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT>
 __global__ void __launch_bounds__(BLOCK)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
                const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
@@ -236,28 +243,29 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
         const size_t o = (size_t)b * 3;
         const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
         const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
+        constexpr int LDP = LD, STP = AUX_NT;
         const T h = dt_stride ? ld_once(dt + b) : dt[0];
-        load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
-        load_chunks<T, N, C_DG0, C_DG1, AUX_NT>(rs, my_lane(), P + (C_DG0 - CN) * EPC);
-        load_chunks<T, N, CN, C_PV_IN, AUX_NT>(rs, my_lane(), P);
-        load_chunks<T, N, C_PV_IN, C_DG0, AUX_NT>(rs, my_lane(), P + (C_PV_IN - CN) * EPC);
-        load_chunks<T, N, C_DG1, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_DG1 - CN) * EPC);
+        load_chunks<T, N, 0, CN, LDP>(rs, my_lane(), nom);
+        load_chunks<T, N, C_DG0, C_DG1, LDP>(rs, my_lane(), P + (C_DG0 - CN) * EPC);
+        load_chunks<T, N, CN, C_PV_IN, LDP>(rs, my_lane(), P);
+        load_chunks<T, N, C_PV_IN, C_DG0, LDP>(rs, my_lane(), P + (C_PV_IN - CN) * EPC);
+        load_chunks<T, N, C_DG1, RC::NCH, LDP>(rs, my_lane(), P + (C_DG1 - CN) * EPC);
 
         // stores are non-temporal: the lines leave the XCD's L2 while the launch is still reading (reads and writes
         // overlap) instead of piling up dirty until the end-of-kernel write-back; the sched_barriers keep the
         // compiler from sinking a stage's stores behind the next stage's arithmetic
         PredictCoef<T> k;
         predict_nominal<T, N, DIALECT>(nom, a, w, h, k);
-        store_chunks<T, N, 0, RC::CH_KIN, AUX_NT>(rs, my_lane(), nom);
+        store_chunks<T, N, 0, RC::CH_KIN, STP>(rs, my_lane(), nom);
         __builtin_amdgcn_sched_barrier(0);
         cov_stage_p<T, N>(P, k);
-        store_chunks<T, N, CN, C_P, AUX_NT>(rs, my_lane(), P);
+        store_chunks<T, N, CN, C_P, STP>(rs, my_lane(), P);
         __builtin_amdgcn_sched_barrier(0);
         cov_stage_v<T, N>(P, k, dc.qd);
-        store_chunks<T, N, C_P, C_V, AUX_NT>(rs, my_lane(), P + (C_P - CN) * EPC);
+        store_chunks<T, N, C_P, C_V, STP>(rs, my_lane(), P + (C_P - CN) * EPC);
         __builtin_amdgcn_sched_barrier(0);
         cov_stage_th<T, N>(P, k, dc.qd);
-        store_chunks<T, N, C_V, RC::CH_VAR_END, AUX_NT>(rs, my_lane(), P + (C_V - CN) * EPC);
+        store_chunks<T, N, C_V, RC::CH_VAR_END, STP>(rs, my_lane(), P + (C_V - CN) * EPC);
     }
 }
 

@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -98,6 +99,7 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
 // handle
 // ---------------------------------------------------------------------------------
 struct fbus_ekf {
+    bool records_warm = false;        // the last kernel stored the records with the default cache policy (they sit in L2)
     int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
     fbus_params prm{};
     HostConst hc;
@@ -223,9 +225,17 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
 {
     const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, K == 1 ? FBUS_KERNEL_PREDICT : FBUS_KERNEL_PREDICT_N);
-    if (K == 1)
-        hipLaunchKernelGGL((predict_kernel<T, N, D, false>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, K,
-                           (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h));
+    // the first predict after a kernel that stored the records with the default cache policy (correct, fused frame)
+    // reads them with the default policy too; the others stream them non-temporally (see predict_kernel)
+    const bool warm = h->records_warm;
+    h->records_warm = false;
+#define FBUS_LAUNCH_PREDICT(LD)                                                                                         \
+    hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, K, \
+                       (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h))
+    if (K == 1) {
+        if (warm) FBUS_LAUNCH_PREDICT(AUX_DEFAULT); else FBUS_LAUNCH_PREDICT(AUX_NT);
+    }
+#undef FBUS_LAUNCH_PREDICT
     else
         hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, K,
                            (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h));
@@ -240,6 +250,7 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
 {
     const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
+    h->records_warm = true;
     const bool joseph = h->prm.cov_form == FBUS_COV_JOSEPH, joint = mode == MODE_STACKED;
 #define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                            \
     hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs,  \
@@ -285,6 +296,7 @@ int launch_frame_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, con
 {
     const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
+    h->records_warm = true;
     const bool joseph = h->prm.cov_form == FBUS_COV_JOSEPH, joint = mode == MODE_STACKED;
 #define FBUS_LAUNCH_FRAME(COV, JOINT)                                                                                  \
     hipLaunchKernelGGL((frame_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,  \
@@ -427,6 +439,7 @@ int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void
 {
     const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
+    h->records_warm = true;
     if (h->prm.cov_form == FBUS_COV_JOSEPH)
         hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, h->stream,
                            (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
