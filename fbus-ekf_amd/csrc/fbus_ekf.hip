@@ -1078,6 +1078,7 @@ int fbus_ekf_timing_reset(fbus_ekf_t h)
     const int rc = flush_events(h);
     if (rc != FBUS_OK) return rc;
     for (int i = 0; i < FBUS_KERNEL_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    h->frame_count = 0;                 // the first frame after a reset is a sampled one, whatever the stride
     return FBUS_OK;
 }
 
