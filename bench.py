@@ -138,18 +138,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # FBUS_BENCH_DEBUG_SHARED_GPU=1: rehearsal of the N > 1 code path on a 1-GPU box (all ranks on cuda:0,
+    # gloo instead of RCCL for the control collectives); never used by the driver's multi-GPU runs.
+    shared = world > 1 and os.environ.get("FBUS_BENCH_DEBUG_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)                        # before the process group: RCCL binds to the current device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # FBUS_BENCH_DEBUG_SHARED_GPU=1: rehearsal of the N > 1 code path on a 1-GPU box (all ranks on cuda:0,
-        # gloo instead of RCCL for the control collectives); never used by the driver's multi-GPU runs.
-        shared = os.environ.get("FBUS_BENCH_DEBUG_SHARED_GPU") == "1"
-        dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
         if shared:
-            local_rank = 0
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     dialect = capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP
