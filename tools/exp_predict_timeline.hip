@@ -51,13 +51,14 @@ __device__ __forceinline__ unsigned long long now() { return __builtin_amdgcn_s_
 template <int MODE, int SAUX>
 __global__ void __launch_bounds__(64)
 timeline_kernel(float* recs, const float* accel, const float* gyro, const float* dt, float q0, float q1, float q2, float q3,
-                unsigned long long* stamps, int groups, int naps)
+                unsigned long long* stamps, int groups, int naps, int parts = 1)
 {
     // optional stagger: wave group g = (tile / 8) % groups naps g * naps * ~0.2 us before it issues its loads, so
     // that the read phase of one group overlaps the write phase of another (reads and writes travel separately)
     for (int i = ((blockIdx.x >> 3) % groups) * naps; i > 0; --i) __builtin_amdgcn_s_sleep(8);
     const unsigned long long t0 = now();
-    const unsigned tile = blockIdx.x, lane = threadIdx.x;
+    // parts > 1: a tile is shared by `parts` workgroups of 64 / parts threads (partial waves, parts waves per SIMD)
+    const unsigned tile = blockIdx.x / parts, lane = threadIdx.x + (blockIdx.x % parts) * (64 / parts);
     constexpr int CN = RC::CH_NOM;
     char* tb = reinterpret_cast<char*>(recs) + (size_t)tile * RC::NCH * 1024u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, RC::NCH * 1024, 0x00020000);
@@ -110,29 +111,29 @@ timeline_kernel(float* recs, const float* accel, const float* gyro, const float*
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t4 = now();
-    if (lane == 0) {
+    if (threadIdx.x == 0 && blockIdx.x % parts == 0) {
         unsigned long long* s = stamps + (size_t)tile * 5;
         s[0] = t0; s[1] = t1; s[2] = t2; s[3] = t3; s[4] = t4;
     }
 }
 
 template <int MODE, int SAUX>
-static void run(float* recs, const float* acc, const float* gyr, const float* dt, unsigned long long* d_st, int B, const char* name, int groups = 1, int naps = 0, bool verbose = true, int pool = 1)
+static void run(float* recs, const float* acc, const float* gyr, const float* dt, unsigned long long* d_st, int B, const char* name, int groups = 1, int naps = 0, bool verbose = true, int pool = 1, int parts = 1)
 {
     const int tiles = B / 64, reps = 30;
     reset_records(recs);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int r = 0; r < 5; ++r) timeline_kernel<MODE, SAUX><<<tiles, 64>>>(recs, acc + (size_t)(r % pool) * B * 3, gyr + (size_t)(r % pool) * B * 3, dt, 1e-4f, 1e-6f, 1e-8f, 1e-10f, d_st, groups, naps);
+    for (int r = 0; r < 5; ++r) timeline_kernel<MODE, SAUX><<<tiles * parts, 64 / parts>>>(recs, acc + (size_t)(r % pool) * B * 3, gyr + (size_t)(r % pool) * B * 3, dt, 1e-4f, 1e-6f, 1e-8f, 1e-10f, d_st, groups, naps, parts);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; ++r) timeline_kernel<MODE, SAUX><<<tiles, 64>>>(recs, acc + (size_t)(r % pool) * B * 3, gyr + (size_t)(r % pool) * B * 3, dt, 1e-4f, 1e-6f, 1e-8f, 1e-10f, d_st, groups, naps);
+    for (int r = 0; r < reps; ++r) timeline_kernel<MODE, SAUX><<<tiles * parts, 64 / parts>>>(recs, acc + (size_t)(r % pool) * B * 3, gyr + (size_t)(r % pool) * B * 3, dt, 1e-4f, 1e-6f, 1e-8f, 1e-10f, d_st, groups, naps, parts);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> s((size_t)tiles * 5);
     CK(hipMemcpy(s.data(), d_st, s.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long base = ~0ull;
     for (int t = 0; t < tiles; ++t) base = std::min(base, s[t * 5]);
-    printf("%s [pool %d]: %.2f us per launch (back to back, stamps included)\n", name, pool, ms * 1e3 / reps);
+    printf("%s [pool %d, %d workgroup(s) per tile]: %.2f us per launch (back to back, stamps included)\n", name, pool, parts, ms * 1e3 / reps);
     if (!verbose) return;
     const char* lbl0[5] = { "t0 entry", "t1 loads landed", "t2 arithmetic done", "t3 stores issued", "t4 stores acked" };
     const char* lbl1[5] = { "t0 entry", "t1 IMU sample landed", "t2 nominal landed", "t3 all stores issued", "t4 stores acked" };
@@ -229,6 +230,14 @@ int main()
         for (int K : {7, 20, 3, 1}) {
             run_mixed<0>(recs, acc, gyr, dt, d_st, B, K, "plain-store pass");
             run_mixed<2>(recs, acc, gyr, dt, d_st, B, K, "nt-store pass   ");
+        }
+        return 0;
+    }
+    if (getenv("PARTS")) {
+        // partial waves: 2 or 4 workgroups of 32 / 16 lanes per tile (2 or 4 waves per SIMD at B = 65 536)
+        for (int parts : {1, 2, 4}) {
+            run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, false, 8, parts);
+            run<0, 2>(recs, acc, gyr, dt, d_st, B, "load / compute / store, nt stores", 1, 0, false, 8, parts);
         }
         return 0;
     }
