@@ -218,3 +218,119 @@ int main() {
         exp.append(f"C 2 {frame} 1")
         exp.append(f"F {used} {len(buf)} {t_state:.9f}")
     assert got == exp
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_runs_the_filter_thread_on_the_gpu(tmp_path):
+    """The C++ side of the boundary end to end on the device: fbus::BatchedFilter<float> + fbus::FrameBatcher (what a
+    maintainer links into C++/src/filter.cpp, INTEGRATION.md section 1) fed an IMU stream and two detection frames;
+    the resulting state must equal the oracle's after the same sequence (EMA pre-filter, window rule, dt from the state
+    time, nearest-marker correct with hysteresis) and must equal what the Python mirror produces call for call."""
+    import subprocess
+    from fbus_ekf import BatchedFilter, synth
+    from replay_ref import OracleEngine
+    from util import COV_TOL, STATE_TOL, cov_rel_err, state_rel_err
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    B, M, dialect = 64, 3, 1
+    prm = capi.default_params(dialect)
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32)
+    nom, rot, P, prev = synth.initial_state(40, 40 + B, list(prm.p0_diag), 18, mixed_cov=True)
+    nom, rot, P = r32(nom), r32(rot), r32(P)
+    rng = np.random.default_rng(17)
+    n_imu = 23
+    imu_a = r32(rng.normal(0, 0.3, (n_imu, 3)) + [0.1, 9.7, 0.2])
+    imu_w = r32(rng.normal(0, 0.02, (n_imu, 3)))
+    ids, pos, quat = synth.marker_frame(40, 40 + B, 0, M, nom.astype(np.float64), prm)
+    # one robot, B hypotheses: the front door hands every filter the same detections (those of filter 0)
+    ids0, pos0, quat0 = ids[0].astype(np.int32), r32(pos[0]), r32(quat[0])
+    for name, arr in (("nom", nom), ("rot", rot), ("P", P), ("prev", prev.astype(np.int32)), ("imu_a", imu_a),
+                      ("imu_w", imu_w), ("ids", ids0), ("pos", pos0), ("quat", quat0)):
+        arr.tofile(tmp_path / f"{name}.bin")
+    src = tmp_path / "thread.cpp"
+    src.write_text(r'''
+#include <fbus/batched_filter.hpp>
+#include <fbus/frame_batcher.hpp>
+#include <cstdio>
+#include <string>
+#include <vector>
+template <typename T> std::vector<T> rd(const std::string& p, size_t n) {
+    std::vector<T> v(n); FILE* f = std::fopen(p.c_str(), "rb"); if (!f || std::fread(v.data(), sizeof(T), n, f) != n) std::abort();
+    std::fclose(f); return v; }
+int main(int argc, char** argv) {
+    const std::string d = argv[1];
+    const int B = 64, M = 3, NI = 23;
+    using F = fbus::BatchedFilter<float>;
+    F flt(B, FBUS_DIALECT_CPP);
+    auto nom = rd<float>(d + "/nom.bin", B * 19), rot = rd<float>(d + "/rot.bin", B * 9), P = rd<float>(d + "/P.bin", B * 324);
+    auto prev = rd<int32_t>(d + "/prev.bin", B);
+    auto ia = rd<float>(d + "/imu_a.bin", NI * 3), iw = rd<float>(d + "/imu_w.bin", NI * 3);
+    auto ids = rd<int32_t>(d + "/ids.bin", M); auto pos = rd<float>(d + "/pos.bin", M * 3), quat = rd<float>(d + "/quat.bin", M * 4);
+    flt.set_state(nom.data(), rot.data(), P.data(), prev.data());
+    fbus::FrameBatcher<float, F> fb(flt, B, 0.0);
+    double t = 0.0;
+    int k = 0, used = 0;
+    for (int frame = 0; frame < 2; ++frame) {
+        for (int i = 0; i < (frame ? 11 : 12); ++i, ++k) { t += 0.005; fb.set_imu(t, &ia[3 * k], &iw[3 * k]); }
+        used += fb.on_detections(t - 0.001, M, ids.data(), pos.data(), quat.data(), F::Mode::Nearest);
+    }
+    flt.get_state(nom.data(), rot.data(), P.data(), prev.data());
+    FILE* f = std::fopen((d + "/out.bin").c_str(), "wb");
+    std::fwrite(nom.data(), 4, nom.size(), f); std::fwrite(rot.data(), 4, rot.size(), f); std::fwrite(P.data(), 4, P.size(), f);
+    std::fwrite(prev.data(), 4, prev.size(), f); std::fclose(f);
+    std::printf("used %d buffered %zu\n", used, fb.buffered());
+    return 0;
+}
+''')
+    exe = tmp_path / "thread"
+    libdir = os.path.dirname(capi.library_path())
+    subprocess.run(["g++", "-std=c++14", "-O1", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lfbus_ekf", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = np.fromfile(tmp_path / "out.bin", np.float32)
+    c_nom, c_rot, c_P = out[:B * 19].reshape(B, 19), out[B * 19:B * 28].reshape(B, 9), out[B * 28:B * 352].reshape(B, 18, 18)
+    c_prev = np.fromfile(tmp_path / "out.bin", np.int32)[B * 352:]
+
+    # the same sequence, restated: EMA 0.1 against the last BUFFERED sample; window start <= t <= end; dt from the state time
+    eng = OracleEngine(B, dialect, 18)
+    eng.set_state(nom, rot, P, prev)
+    tile = lambda v: np.tile(np.asarray(v, np.float64), (B, 1))
+    with BatchedFilter(B, prm) as py:
+        py.set_state(nom, rot, P, prev)
+        buf, t_state, t, k, used = [], 0.0, 0.0, 0, 0
+        for frame in range(2):
+            for _ in range(11 if frame else 12):
+                t += 0.005
+                a, w = imu_a[k].copy(), imu_w[k].copy()
+                k += 1
+                if buf:
+                    c = np.float32(0.1)
+                    a = buf[-1][1] * (np.float32(1) - c) + a * c
+                    w = buf[-1][2] * (np.float32(1) - c) + w * c
+                buf.append((t, a, w))
+            end, consumed = t - 0.001, 0
+            for (ts, a, w) in buf:
+                if ts < t_state:
+                    consumed += 1
+                    continue
+                if ts > end:
+                    break
+                consumed += 1
+                dt = np.float32(ts - t_state)
+                eng.predict(tile(a), tile(w), np.array([float(dt)]))
+                py.predict(tile(a), tile(w), float(dt))
+                t_state = ts
+                used += 1
+            del buf[:consumed]
+            ok = eng.correct(np.tile(ids0, (B, 1)), np.tile(pos0, (B, 1, 1)), np.tile(quat0, (B, 1, 1)), 0)
+            py.correct(np.tile(ids0, (B, 1)), np.tile(pos0, (B, 1, 1)), np.tile(quat0, (B, 1, 1)), 0)
+        p_nom, p_rot, p_P, p_prev = py.get_state()
+    assert r.stdout.strip() == f"used {used} buffered {len(buf)}"
+    # C++ mirror == Python mirror, call for call (same library, same launches)
+    assert np.array_equal(c_nom, p_nom.astype(np.float32)) and np.array_equal(c_P, p_P.astype(np.float32))
+    assert np.array_equal(c_prev, p_prev)
+    # ... and both follow the oracle
+    assert ok.all()
+    assert state_rel_err(c_nom, eng.nominal, eng.P)[0] <= STATE_TOL * 3           # 22 predicts + 2 corrects
+    assert cov_rel_err(c_P, eng.P) <= COV_TOL
+    assert (c_prev == eng.prev).all()
