@@ -93,3 +93,28 @@ def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
         out.append(np.concatenate([[cur], nominal.ravel(), rot.ravel(), P.ravel()]).astype(np.float64))
         npred.append(cnt)
     return np.array(out), np.array(npred)
+
+
+# ---- recording files either side of the path ---------------------------------------
+def load_recording(directory):
+    """imu.txt (`t ax ay az gx gy gz`, main.cpp IMU callback) and image.txt (`t id px py pz qw qx qy qz`,
+    vision.cpp:101-110; rows with equal t belong to one frame) of a dataset directory."""
+    import os
+    imu = np.loadtxt(os.path.join(directory, "imu.txt"), ndmin=2)
+    image = np.loadtxt(os.path.join(directory, "image.txt"), ndmin=2)
+    if imu.shape[1] != 7 or image.shape[1] != 9:
+        raise ValueError(f"unexpected column counts: imu {imu.shape[1]} (want 7), image {image.shape[1]} (want 9)")
+    return imu, image
+
+
+def fusion_rows(states):
+    """The fused trace the reference appends to data/fusion.txt (filter.cpp:238-248): one row per camera frame,
+    `t p(3) q(wxyz) v(3) ba(3) bg(3)` = 17 columns, from the rows replay() returns
+    (nominal layout p v q ba bg g)."""
+    s = np.asarray(states, float)
+    t, nom = s[:, 0:1], s[:, 1:20]
+    return np.concatenate([t, nom[:, 0:3], nom[:, 6:10], nom[:, 3:6], nom[:, 10:13], nom[:, 13:16]], axis=1)
+
+
+def save_fusion(path, states):
+    np.savetxt(path, fusion_rows(states), fmt="%.9f")

@@ -122,3 +122,29 @@ def test_two_rank_gloo_run_equals_single_process_bitwise():
         assert np.array_equal(nom, ref[0][lo:hi]) and np.array_equal(P, ref[2][lo:hi])
         off += n
     assert off == total
+
+
+def test_recording_files_round_trip_and_fusion_trace_format(tmp_path):
+    """file formats either side of the path: imu.txt / image.txt in, fusion.txt
+    (`t p q(wxyz) v ba bg`, 17 columns, filter.cpp:238-248) out"""
+    import os
+    from fbus_ekf import replay
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "land_slice.npz"))
+    np.savetxt(tmp_path / "imu.txt", g["imu"], fmt="%.9f")
+    np.savetxt(tmp_path / "image.txt", g["image"], fmt="%.9f")
+    imu, image = replay.load_recording(str(tmp_path))
+    assert imu.shape == g["imu"].shape and image.shape == g["image"].shape
+    assert np.abs(imu - g["imu"]).max() < 1e-8 and np.abs(image - g["image"]).max() < 1e-8
+    st = g["states_matlab"]
+    rows = replay.fusion_rows(st)
+    assert rows.shape == (len(st), 17)
+    nom = st[:, 1:20]
+    assert np.array_equal(rows[:, 0], st[:, 0]) and np.array_equal(rows[:, 1:4], nom[:, 0:3])
+    assert np.array_equal(rows[:, 4:8], nom[:, 6:10]) and np.abs(np.linalg.norm(rows[:, 4:8], axis=1) - 1).max() < 1e-6
+    assert np.array_equal(rows[:, 8:11], nom[:, 3:6]) and np.array_equal(rows[:, 14:17], nom[:, 13:16])
+    replay.save_fusion(tmp_path / "fusion.txt", st)
+    back = np.loadtxt(tmp_path / "fusion.txt")
+    assert back.shape == rows.shape and np.abs(back - rows).max() < 1e-8
+    with pytest.raises(ValueError):
+        np.savetxt(tmp_path / "image.txt", g["image"][:, :8], fmt="%.9f")
+        replay.load_recording(str(tmp_path))
