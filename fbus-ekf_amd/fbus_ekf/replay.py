@@ -118,3 +118,17 @@ def fusion_rows(states):
 
 def save_fusion(path, states):
     np.savetxt(path, fusion_rows(states), fmt="%.9f")
+
+
+def image_from_corners(engine, corners, geometry):
+    """corners.txt rows -> image.txt rows through the device (`marker_pose_kernel`): what VISION::GetMarkerPose
+    hands the filter.  corners: water `t id` + 8 left + 8 right normalised coordinates (vision.cpp:111-119), geometry
+    VIS_REFRACTIVE / VIS_PINHOLE; land `t id` + four 3-D corners (`:120-124`), geometry VIS_CORNERS3D.
+    Returns rows `t id px py pz qw qx qy qz`."""
+    from . import capi
+    c = np.asarray(corners, float)
+    if geometry == capi.VIS_CORNERS3D:
+        pos, quat = engine.marker_pose(c[:, 2:14], None, geometry)
+    else:
+        pos, quat = engine.marker_pose(c[:, 2:10], c[:, 10:18], geometry)
+    return np.concatenate([c[:, 0:2], np.asarray(pos, float), np.asarray(quat, float)], axis=1)

@@ -195,3 +195,19 @@ def test_correct_from_stereo_corners_matches_oracle(dialect, mode, dtype, mult):
     assert state_rel_err(g[0], eng.nominal, eng.P)[0] <= STATE_TOL * mult
     assert cov_rel_err(g[2], eng.P) <= COV_TOL * min(mult, 1.0)
     assert not np.array_equal(g[0][2:], nom[2:].astype(g[0].dtype))           # it did update
+
+
+@pytest.mark.gpu
+def test_corner_recordings_to_image_rows():
+    """the data formats in front of the path: corners.txt rows in, image.txt rows out (fbus_ekf.replay), against the
+    image.txt the reference recorded beside them -- water (refractive stereo) and land (3-D corners)"""
+    from fbus_ekf import replay
+    with BatchedFilter(1, capi.default_params(1), dtype=64) as flt:
+        for name, geom in (("vision_water.npz", capi.VIS_REFRACTIVE), ("vision_land.npz", capi.VIS_CORNERS3D)):
+            d = np.load(os.path.join(GOLD, name))
+            rows = replay.image_from_corners(flt, d["corners"], geom)
+            im = d["image"]
+            assert rows.shape == (len(im), 9)
+            assert np.array_equal(rows[:, 0], d["corners"][:, 0]) and np.array_equal(rows[:, 1], im[:, 1])
+            assert np.abs(rows[:, 2:5] - im[:, 2:5]).max() < 1.5e-5
+            assert _qerr(rows[:, 5:9], im[:, 5:9]) < 5e-5
