@@ -228,6 +228,34 @@ struct DevConst {
     const short* id2slot;   // [FBUS_MAX_MARKER_ID + 1], -1 = not in the map
 };
 
+// Accumulates coef * (P(r,c), P(r,c+1)) for an even column c of the symmetric packed covariance: one v_pk_fma_f32 where
+// the storage holds the two elements as an aligned pair (r <= c, pair-aligned rows), two scalar FMAs otherwise (r > c
+// reads the transposed elements).  All indices are compile-time after unrolling, so the flags fold away.
+template <int N>
+struct PairAcc {
+    f32x2 v = { 0.f, 0.f };
+    float lo = 0.f, hi = 0.f;
+    bool vset = false, sset = false;
+    __device__ __forceinline__ void add(const float* P, float coef, int r, int c)
+    {
+        if (is_pair<N>(r, c)) {
+            const int o = pidx<N>(r, c);
+            const f32x2 t = f32x2{ P[o], P[o + 1] };
+            v = vset ? v + coef * t : coef * t;
+            vset = true;
+        } else {
+            const float t0 = P[pidx<N>(r, c)], t1 = P[pidx<N>(r, c + 1)];
+            lo = sset ? lo + coef * t0 : coef * t0;
+            hi = sset ? hi + coef * t1 : coef * t1;
+            sset = true;
+        }
+    }
+    __device__ __forceinline__ f32x2 get() const
+    {
+        return vset ? (sset ? v + f32x2{ lo, hi } : v) : f32x2{ lo, hi };
+    }
+};
+
 // ================================================================================
 // predict
 // ================================================================================
@@ -304,21 +332,36 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
     // U(i, c) = A_i . P(theta, c) + Bm_i . P(ba, c) + dt P(g_i, c), c = 6 .. N-1, accumulated source by source in
     // the order the rows arrive (theta rows, ba rows, then the g/bg bits)
     T U[3 * NC];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            U[NC * i + c] = k.A[3 * i] * PS(6, 6 + c) + k.A[3 * i + 1] * PS(7, 6 + c) + k.A[3 * i + 2] * PS(8, 6 + c);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            U[NC * i + c] += k.Bm[3 * i] * PS(9, 6 + c) + k.Bm[3 * i + 1] * PS(10, 6 + c) + k.Bm[3 * i + 2] * PS(11, 6 + c);
-    if (G) {
+    if constexpr (PackedMath<T, N>::on) {
+        // the same sums on aligned column pairs (6+c, 7+c): 26 of the 42 pair-terms per row are one v_pk_fma_f32
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) U[NC * i + c] += dt * PS(15 + i, 6 + c);
+            for (int c = 0; c < NC; c += 2) {
+                PairAcc<N> acc;
+                acc.add(P, k.A[3 * i], 6, 6 + c); acc.add(P, k.A[3 * i + 1], 7, 6 + c); acc.add(P, k.A[3 * i + 2], 8, 6 + c);
+                acc.add(P, k.Bm[3 * i], 9, 6 + c); acc.add(P, k.Bm[3 * i + 1], 10, 6 + c); acc.add(P, k.Bm[3 * i + 2], 11, 6 + c);
+                if (G) acc.add(P, dt, 15 + i, 6 + c);
+                const f32x2 r = acc.get();
+                U[NC * i + c] = r.x; U[NC * i + c + 1] = r.y;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                U[NC * i + c] = k.A[3 * i] * PS(6, 6 + c) + k.A[3 * i + 1] * PS(7, 6 + c) + k.A[3 * i + 2] * PS(8, 6 + c);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                U[NC * i + c] += k.Bm[3 * i] * PS(9, 6 + c) + k.Bm[3 * i + 1] * PS(10, 6 + c) + k.Bm[3 * i + 2] * PS(11, 6 + c);
+        if (G) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) U[NC * i + c] += dt * PS(15 + i, 6 + c);
+        }
     }
     // v,v block: P(v,v) += D + D',  D = (P(v,theta) + U_theta/2) A' + (P(v,ba) + U_ba/2) Bm' + dt (P(v,g) + U_g/2)
     T D[9];
@@ -339,10 +382,25 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = i; j < 3; ++j) PS(3 + i, 3 + j) += D[3 * i + j] + D[3 * j + i];
+    if constexpr (PackedMath<T, N>::on) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) PS(3 + i, 6 + c) += U[NC * i + c];
+            for (int c = 0; c < NC; c += 2) {
+                if (is_pair<N>(3 + i, 6 + c)) {
+                    const int o = pidx<N>(3 + i, 6 + c);
+                    const f32x2 r = f32x2{ P[o], P[o + 1] } + f32x2{ U[NC * i + c], U[NC * i + c + 1] };
+                    P[o] = r.x; P[o + 1] = r.y;
+                } else {
+                    PS(3 + i, 6 + c) += U[NC * i + c]; PS(3 + i, 7 + c) += U[NC * i + c + 1];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) PS(3 + i, 6 + c) += U[NC * i + c];
+    }
     // E_theta, column theta of rows v: P(v,theta) = P(v,theta) Th' - dt P(v,bg)
 #pragma unroll
     for (int c = 3; c < 6; ++c) {
