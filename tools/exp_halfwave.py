@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Experiment: does a wave64 VALU instruction with EXEC = low 32 lanes only cost half the issue time on gfx950?
-Times correct (stacked, M=4) with no skip mask, with lanes 32..63 of every wave skipped, and with odd lanes skipped."""
+Times correct (reference mode: the nearest of M=4 markers applied row by row; skipped lanes leave that kernel at once --
+the stacked kernel lets them run along, so it cannot show this) with no skip mask, with lanes 32..63 of every wave
+skipped, and with odd lanes skipped.  Round-1 result on the row-by-row stacked kernel of the time: same time in all
+three cases, i.e. a half-empty wave buys nothing."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,11 +25,11 @@ with BatchedFilter(B, prm) as flt:
         sk = None if m is None else torch.from_numpy(m.astype(np.uint8)).to(dev)
         flt.set_state(nom, rot, P, prev)
         for _ in range(3):
-            flt.correct(d_ids, d_pos, d_quat, 1, sk)
+            flt.correct(d_ids, d_pos, d_quat, 0, sk)
         flt.sync()
         flt.timing_enable(True); flt.timing_reset()
         for _ in range(20):
-            flt.correct(d_ids, d_pos, d_quat, 1, sk)
+            flt.correct(d_ids, d_pos, d_quat, 0, sk)
         ms, n = flt.timing_read(capi.KERNEL_CORRECT)
         flt.timing_enable(False)
         print(f"{name:22s}: {ms / n * 1e3:7.1f} us per correct launch   applied {int(flt.applied().sum())}")
