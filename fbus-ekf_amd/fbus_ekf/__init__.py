@@ -13,6 +13,7 @@ from .capi import (DIALECT_CPP, DIALECT_MATLAB, MODE_NEAREST, MODE_STACKED, COV_
                    VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D, POSE_INIT, POSE_RESET,
                    FbusError, FbusParams, default_params, declared_symbols, load_library, library_path)
 from .filter import BatchedFilter
+from .frame_batcher import FrameBatcher
 from . import synth, shard
 
 __all__ = [
@@ -20,5 +21,5 @@ __all__ = [
     "KERNEL_PREDICT", "KERNEL_CORRECT", "KERNEL_PREDICT_N", "KERNEL_MARKER_POSE", "KERNEL_FRAME",
     "VIS_REFRACTIVE", "VIS_PINHOLE", "VIS_CORNERS3D", "POSE_INIT", "POSE_RESET",
     "FbusError", "FbusParams", "default_params", "declared_symbols", "load_library", "library_path",
-    "BatchedFilter", "synth", "shard",
+    "BatchedFilter", "FrameBatcher", "synth", "shard",
 ]

@@ -334,3 +334,64 @@ int main(int argc, char** argv) {
     assert state_rel_err(c_nom, eng.nominal, eng.P)[0] <= STATE_TOL * 3           # 22 predicts + 2 corrects
     assert cov_rel_err(c_P, eng.P) <= COV_TOL
     assert (c_prev == eng.prev).all()
+
+
+def test_python_frame_batcher_issues_the_same_calls_as_the_cpp_header(tmp_path):
+    """fbus_ekf.FrameBatcher (Python twin) against include/fbus/frame_batcher.hpp driven with the same stream: the
+    recorded predict / correct calls must be identical (EMA, window rule, dt, trimming)."""
+    import subprocess
+    from fbus_ekf import FrameBatcher
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    src = tmp_path / "fb.cpp"
+    src.write_text(r'''
+#include <fbus/frame_batcher.hpp>
+#include <cstdio>
+struct Recorder {
+    void predict(const float* a, const float* w, float dt) { std::printf("P %.9g %.9g %.9g %.9g\n", dt, a[0], a[4], w[5]); }
+    void correct(int M, const int32_t* ids, const float* pos, const float* quat, int mode, const unsigned char*) {
+        std::printf("C %d %d %d %.9g %.9g\n", M, ids[0], mode, pos[4], quat[7]); }
+};
+int main() {
+    Recorder r;
+    fbus::FrameBatcher<float, Recorder> fb(r, 2, 0.0105, true, 40, 10);
+    double t = 0.0;
+    int k = 0;
+    for (int frame = 0; frame < 6; ++frame) {
+        const int n = (frame == 3) ? 55 : 9;
+        for (int i = 0; i < n; ++i, ++k) {
+            t += 0.001;
+            float a[3] = { 0.1f * k, 1.f + 0.01f * k, 2 }, w[3] = { 3, 4, 0.01f * k };
+            fb.set_imu(t, a, w);
+        }
+        int32_t ids[2] = { frame, 7 };
+        float pos[6] = {0, 1, 2, 3, 4.5f, 5}, quat[8] = {1, 0, 0, 0, 0.5f, 0.5f, 0.5f, 0.25f * frame};
+        int used = fb.on_detections(t - 0.0005, 2, ids, pos, quat, 1);
+        std::printf("F %d %zu %.9f\n", used, fb.buffered(), fb.state_time());
+    }
+}
+''')
+    exe = tmp_path / "fb"
+    subprocess.run(["g++", "-std=c++14", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    want = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+
+    got = []
+
+    class Recorder:
+        def predict(self, a, w, dt):
+            got.append("P %.9g %.9g %.9g %.9g" % (np.float32(dt), a[0, 0], a[1, 1], w[1, 2]))
+
+        def correct(self, ids, pos, quat, mode):
+            got.append("C %d %d %d %.9g %.9g" % (ids.shape[1], ids[0, 0], mode, pos[0, 1, 1], quat[0, 1, 3]))
+
+    fb = FrameBatcher(Recorder(), 2, 0.0105, True, 40, 10)
+    t, k = 0.0, 0
+    for frame in range(6):
+        for _ in range(55 if frame == 3 else 9):
+            t += 0.001
+            fb.set_imu(t, np.array([np.float32(0.1) * np.float32(k), np.float32(1) + np.float32(0.01) * np.float32(k), 2], np.float32),
+                       np.array([3, 4, np.float32(0.01) * np.float32(k)], np.float32))
+            k += 1
+        used = fb.on_detections(t - 0.0005, [frame, 7], [[0, 1, 2], [3, 4.5, 5]],
+                                [[1, 0, 0, 0], [0.5, 0.5, 0.5, 0.25 * frame]], 1)
+        got.append("F %d %d %.9f" % (used, fb.buffered, fb.t_state))
+    assert got == want
