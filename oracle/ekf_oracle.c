@@ -328,20 +328,15 @@ static int find_marker(const fbo_params* prm, int id)
 /* ------------------------------------------------------------------ */
 /* predict                                                             */
 /* ------------------------------------------------------------------ */
-void fbo_predict(fbo_state* s, const fbo_params* prm,
-                 const double accel[3], const double gyro[3], double dt)
+/* Fx of ImuUpdate.m:63-69 / filter.cpp:597-604 at the pre-step state (a, w bias-corrected).  fbo_predict uses
+ * exactly this matrix; it is exported (fbo_transition) so that a test can check it against finite differences of
+ * the nominal kinematics, i.e. the transcription is pinned by something other than itself. */
+static void build_Fx(const fbo_state* s, const fbo_params* prm, const double a[3], const double w[3], double dt,
+                     double* Fx)
 {
     const int n = prm->nstate;
     const int cpp = (prm->dialect == FBO_DIALECT_CPP);
-    double a[3], w[3];
-    for (int i = 0; i < 3; ++i) {           /* ImuUpdate.m:37-38 ; filter.cpp:539,568,594-595 */
-        a[i] = accel[i] - s->ba[i];
-        w[i] = gyro[i] - s->bg[i];
-    }
-
-    /* ---- covariance (reads the pre-step state; filter.cpp:588-616, ImuUpdate.m:63-73) ---- */
-    double Fx[FBO_NMAX * FBO_NMAX];
-    memset(Fx, 0, sizeof(Fx));
+    memset(Fx, 0, sizeof(double) * n * n);
     for (int i = 0; i < n; ++i) Fx[i * n + i] = 1.0;
     double ax[9], Ra[9];
     fbo_skew(a, ax);
@@ -365,6 +360,30 @@ void fbo_predict(fbo_state* s, const fbo_params* prm,
     }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) Fx[(6 + i) * n + 6 + j] = Th[3 * i + j];
+}
+
+void fbo_transition(const fbo_state* s, const fbo_params* prm, const double accel[3], const double gyro[3],
+                    double dt, double* Fx)
+{
+    double a[3], w[3];
+    for (int i = 0; i < 3; ++i) { a[i] = accel[i] - s->ba[i]; w[i] = gyro[i] - s->bg[i]; }
+    build_Fx(s, prm, a, w, dt, Fx);
+}
+
+void fbo_predict(fbo_state* s, const fbo_params* prm,
+                 const double accel[3], const double gyro[3], double dt)
+{
+    const int n = prm->nstate;
+    const int cpp = (prm->dialect == FBO_DIALECT_CPP);
+    double a[3], w[3];
+    for (int i = 0; i < 3; ++i) {           /* ImuUpdate.m:37-38 ; filter.cpp:539,568,594-595 */
+        a[i] = accel[i] - s->ba[i];
+        w[i] = gyro[i] - s->bg[i];
+    }
+
+    /* ---- covariance (reads the pre-step state; filter.cpp:588-616, ImuUpdate.m:63-73) ---- */
+    double Fx[FBO_NMAX * FBO_NMAX];
+    build_Fx(s, prm, a, w, dt, Fx);
 
     double FP[FBO_NMAX * FBO_NMAX], Pn[FBO_NMAX * FBO_NMAX];
     mat_mul(Fx, s->P, FP, n, n, n);
@@ -442,9 +461,9 @@ void fbo_predict(fbo_state* s, const fbo_params* prm,
 /* correct                                                             */
 /* ------------------------------------------------------------------ */
 /* rows for one marker: h(x), H (7 x n), residual r (7).                */
-static void marker_rows(const fbo_state* s, const fbo_params* prm, int slot,
-                        const double* yp, const double* yq,
-                        double* H /*7 x n*/, double* r /*7*/)
+static void marker_rows_h(const fbo_state* s, const fbo_params* prm, int slot,
+                          const double* yp, const double* yq,
+                          double* H /*7 x n*/, double* r /*7*/, double* h /*7, may be NULL*/)
 {
     const int n = prm->nstate;
     const int cpp = (prm->dialect == FBO_DIALECT_CPP);
@@ -506,6 +525,28 @@ static void marker_rows(const fbo_state* s, const fbo_params* prm, int slot,
     for (int i = 0; i < 3; ++i) r[i] = yp[i] - hp[i];
     for (int i = 0; i < 4; ++i)             /* MeasureUpdate.m:87-88 zeroes these rows */
         r[3 + i] = cpp ? (yq[i] - hq[i]) : 0.0;
+    if (h) {
+        for (int i = 0; i < 3; ++i) h[i] = hp[i];
+        for (int i = 0; i < 4; ++i) h[3 + i] = hq[i];      /* after the sign unification */
+    }
+}
+
+static void marker_rows(const fbo_state* s, const fbo_params* prm, int slot,
+                        const double* yp, const double* yq, double* H, double* r)
+{
+    marker_rows_h(s, prm, slot, yp, yq, H, r, NULL);
+}
+
+/* exported for the finite-difference test of the Jacobian: predicted measurement h (7, quaternion part after the
+ * sign unification against yq), H (7 x n), residual r (7) of the marker with ArUco id `id`, exactly what
+ * fbo_correct uses.  Returns 0 if the id is not in the map. */
+int fbo_measurement(const fbo_state* s, const fbo_params* prm, int id, const double* yp, const double* yq,
+                    double* h, double* H, double* r)
+{
+    const int k = find_marker(prm, id);
+    if (k < 0) return 0;
+    marker_rows_h(s, prm, k, yp, yq, H, r, h);
+    return 1;
 }
 
 /* Dense update shared by the pose-row and corner-row measurement models, exactly the reference's

@@ -98,6 +98,15 @@ int  fbo_correct(fbo_state* s, const fbo_params* prm, int M,
                  const int* ids, const double* pos /*Mx3*/, const double* quat /*Mx4 wxyz*/,
                  int mode);
 
+/* ---- the linearisation the hot path uses, exported so that tests can pin it by finite differences ---- */
+/* Fx (n x n row-major) of ImuUpdate.m:63-69 / filter.cpp:597-604 at state s.                      */
+void fbo_transition(const fbo_state* s, const fbo_params* prm, const double accel[3], const double gyro[3],
+                    double dt, double* Fx);
+/* h (7: position, quaternion after the sign unification against yq), H (7 x n), r (7) of marker `id`
+ * (MeasureUpdate.m:67-88 / filter.cpp:684-721).  Returns 0 for an id outside the map.            */
+int  fbo_measurement(const fbo_state* s, const fbo_params* prm, int id, const double* yp, const double* yq,
+                     double* h, double* H, double* r);
+
 /* ---- batched drivers (flat arrays; used by tests and the CPU baseline) ----
  * nominal: B x 19 (p v q ba bg g), rot: B x 9, P: B x n x n, prev: B ints   */
 void fbo_predict_batch(int B, double* nominal, double* rot, double* P, int* prev,

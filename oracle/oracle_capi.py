@@ -28,6 +28,14 @@ class FboParams(C.Structure):
     ]
 
 
+class FboState(C.Structure):
+    _fields_ = [
+        ("p", C.c_double * 3), ("v", C.c_double * 3), ("q", C.c_double * 4), ("ba", C.c_double * 3),
+        ("bg", C.c_double * 3), ("g", C.c_double * 3), ("R", C.c_double * 9), ("P", C.c_double * (18 * 18)),
+        ("prev_id", C.c_int),
+    ]
+
+
 class FbvParams(C.Structure):
     _fields_ = [
         ("R_IL", C.c_double * 9), ("P_LI", C.c_double * 3),
@@ -70,6 +78,9 @@ def load(native=False):
                                        C.c_int, ip, dp, dp, C.c_int, C.c_int]
     lib.fbo_correct_corners_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.c_int, ip, dp,
                                               C.c_double, C.c_int, ip]
+    lib.fbo_transition.argtypes = [C.POINTER(FboState), C.POINTER(FboParams), dp, dp, C.c_double, dp]
+    lib.fbo_measurement.argtypes = [C.POINTER(FboState), C.POINTER(FboParams), C.c_int, dp, dp, dp, dp, dp]
+    lib.fbo_predict.argtypes = [C.POINTER(FboState), C.POINTER(FboParams), dp, dp, C.c_double]
     u8 = C.POINTER(C.c_ubyte)
     lib.fbo_init_gravity_bias.argtypes = [C.c_int, dp, dp, dp, dp]
     lib.fbo_pose_init_batch.argtypes = [C.c_int, dp, dp, C.POINTER(FboParams), C.c_int, ip, dp, dp, C.c_int, C.c_double,
@@ -106,6 +117,41 @@ class Oracle:
         P = np.zeros((self.n, self.n))
         self.lib.fbo_default_P0(C.byref(self.prm), _dp(P))
         return P
+
+    # ---- single-state views of the linearisation (finite-difference tests) ----
+    def _state(self, nominal, rot):
+        st = FboState()
+        x = np.asarray(nominal, np.float64).reshape(19)
+        st.p[:] = x[0:3]; st.v[:] = x[3:6]; st.q[:] = x[6:10]; st.ba[:] = x[10:13]; st.bg[:] = x[13:16]; st.g[:] = x[16:19]
+        st.R[:] = np.asarray(rot, np.float64).reshape(9)
+        return st
+
+    def transition(self, nominal, rot, accel, gyro, dt):
+        """Fx (n x n) the oracle's predict uses at this state (ImuUpdate.m:63-69 / filter.cpp:597-604)"""
+        st = self._state(nominal, rot)
+        Fx = np.zeros((self.n, self.n))
+        self.lib.fbo_transition(C.byref(st), C.byref(self.prm), _dp(np.ascontiguousarray(accel, np.float64)),
+                                _dp(np.ascontiguousarray(gyro, np.float64)), float(dt), _dp(Fx))
+        return Fx
+
+    def predict_nominal(self, nominal, rot, accel, gyro, dt):
+        """the nominal-state kinematics of ONE filter through fbo_predict -> (nominal 19, rot 9)"""
+        st = self._state(nominal, rot)
+        self.lib.fbo_predict(C.byref(st), C.byref(self.prm), _dp(np.ascontiguousarray(accel, np.float64)),
+                             _dp(np.ascontiguousarray(gyro, np.float64)), float(dt))
+        out = np.concatenate([np.array(st.p), np.array(st.v), np.array(st.q), np.array(st.ba), np.array(st.bg), np.array(st.g)])
+        return out, np.array(st.R)
+
+    def measurement(self, nominal, rot, marker_id, yp, yq):
+        """(h 7, H 7 x n, r 7) the oracle's correct uses for this marker (MeasureUpdate.m:67-88 / filter.cpp:684-721)"""
+        st = self._state(nominal, rot)
+        h, H, r = np.zeros(7), np.zeros((7, self.n)), np.zeros(7)
+        ok = self.lib.fbo_measurement(C.byref(st), C.byref(self.prm), int(marker_id),
+                                      _dp(np.ascontiguousarray(yp, np.float64)), _dp(np.ascontiguousarray(yq, np.float64)),
+                                      _dp(h), _dp(H), _dp(r))
+        if not ok:
+            raise KeyError(marker_id)
+        return h, H, r
 
     def predict(self, nominal, rot, P, prev, accel, gyro, dt):
         B = nominal.shape[0]

@@ -229,7 +229,7 @@ def test_cpp_host_mirror_runs_the_filter_thread_on_the_gpu(tmp_path):
     import subprocess
     from fbus_ekf import BatchedFilter, synth
     from replay_ref import OracleEngine
-    from util import COV_TOL, STATE_TOL, cov_rel_err, state_rel_err
+    from util import COV_BLOCK_TOL, COV_BLOCK_TOL_F64, COV_TOL, STATE_TOL, cov_rel_err, cov_rel_err_blockwise, state_rel_err
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     B, M, dialect = 64, 3, 1
     prm = capi.default_params(dialect)
@@ -332,7 +332,7 @@ int main(int argc, char** argv) {
     # ... and both follow the oracle
     assert ok.all()
     assert state_rel_err(c_nom, eng.nominal, eng.P)[0] <= STATE_TOL * 3           # 22 predicts + 2 corrects
-    assert cov_rel_err(c_P, eng.P) <= COV_TOL
+    assert cov_rel_err(c_P, eng.P) <= COV_TOL and cov_rel_err_blockwise(c_P, eng.P) <= COV_BLOCK_TOL
     assert (c_prev == eng.prev).all()
 
 

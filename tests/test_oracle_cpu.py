@@ -277,3 +277,48 @@ def test_information_compressed_update_drops_directions_without_information():
         assert np.isfinite(dx).all() and np.isfinite(Pn).all()
         assert np.abs(dx - K @ r).max() <= 1e-9 * max(1.0, np.abs(K @ r).max())
         assert np.abs(Pn - (np.eye(18) - K @ H) @ s.P).max() <= 1e-9 * np.abs(s.P).max()
+
+
+# ---------------------------------------------------------------- the parity gate itself (tests/util.py)
+def test_parity_gate_passes_fp32_rounding_and_fails_on_block_mutations():
+    """CPU twin of the GPU mutation test: the gate accepts an fp32-rounded copy of an oracle state and rejects the
+    same copy with any one 3x3 covariance block scaled by 2, 1 + 1e-3 or 0, any nominal block scaled by 1 + 1e-3,
+    or an asymmetric covariance."""
+    from fbus_ekf import capi, synth
+    from replay_ref import OracleEngine
+    from util import assert_parity
+    B = 64
+    prm = capi.default_params(0)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18, mixed_cov=True)
+    eng = OracleEngine(B, 0, 18)
+    eng.set_state(nom, rot, P, prev)
+    acc, gyr = synth.imu_samples(0, B, 0, 1, nom)
+    ids, pos, quat = synth.marker_frame(0, B, 0, 4, nom, prm)
+    eng.predict(acc[0], gyr[0], np.array([0.005]))
+    eng.correct(ids, pos, quat, 1)
+    ref = eng.get_state()
+    got = [x.astype(np.float32).astype(np.float64) for x in ref[:3]] + [ref[3].copy()]
+    got[2] = (got[2] + np.swapaxes(got[2], 1, 2)) / 2
+    assert_parity(got, ref, 32, "fp32-rounded oracle state", verbose=False)
+    for bi in range(6):
+        for bj in range(bi, 6):
+            for factor in (2.0, 1.0 + 1e-3, 0.0):
+                mut = [x.copy() for x in got]
+                blk = mut[2][:, 3 * bi:3 * bi + 3, 3 * bj:3 * bj + 3] * factor
+                mut[2][:, 3 * bi:3 * bi + 3, 3 * bj:3 * bj + 3] = blk
+                mut[2][:, 3 * bj:3 * bj + 3, 3 * bi:3 * bi + 3] = np.swapaxes(blk, 1, 2)
+                with pytest.raises(AssertionError):
+                    assert_parity(mut, ref, 32, f"block ({bi},{bj}) x {factor}", verbose=False)
+    for a, b in ((0, 3), (3, 6), (6, 10), (10, 13), (13, 16), (16, 19)):
+        mut = [x.copy() for x in got]
+        mut[0][:, a:b] *= 1.0 + 1e-3
+        with pytest.raises(AssertionError):
+            assert_parity(mut, ref, 32, f"nominal [{a}:{b}]", verbose=False)
+    mut = [x.copy() for x in got]
+    mut[2][:, 0, 1] *= 1.0 + 1e-6
+    with pytest.raises(AssertionError):
+        assert_parity(mut, ref, 32, "asymmetric", verbose=False)
+    mut = [x.copy() for x in got]
+    mut[3][0] += 1
+    with pytest.raises(AssertionError):
+        assert_parity(mut, ref, 32, "prev id", verbose=False)

@@ -1,0 +1,223 @@
+"""CPU suite: the oracle's linearisation pinned by something other than itself.
+
+The reference ships no known-answer vector for ImuUpdate / MeasureUpdate, so the transcription of the two
+Jacobians is checked against what they are supposed to be -- derivatives of the oracle's own non-linear functions:
+
+ * H (MeasureUpdate.m:71-75 ; filter.cpp:689-694) against central differences of h (MeasureUpdate.m:67-68 ;
+   filter.cpp:684-686) under the error-state perturbation p <- p + dp, q <- q (x) exp(dtheta), both dialects and
+   both outcomes of the quaternion sign unification (MeasureUpdate.m:77-81 ; filter.cpp:698-706);
+ * Fx (ImuUpdate.m:63-69 ; filter.cpp:597-604) against central differences of the nominal kinematics
+   (ImuUpdate.m:41-60 ; filter.cpp:539-581), (f(x (+) d) (-) f(x)) / d, to O(dt^2): the error is asserted at two
+   step sizes and must shrink like dt^2 (the RK4-style position/velocity update carries second-order terms that a
+   first-order Fx does not).
+
+A transcription slip in either Jacobian (a sign, a transposed block, a missing factor 1/2 of L1) shows up here at
+O(1), independently of the HIP kernels and of the numpy twin.
+"""
+import numpy as np
+import pytest
+
+import oracle_capi as oc
+
+EPS = 1e-6
+
+
+def _quat_mul(p, q):
+    return np.array([p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3],
+                     p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2],
+                     p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1],
+                     p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0]])
+
+
+def _quat_exp(th):
+    a = np.linalg.norm(th)
+    if a == 0:
+        return np.array([1.0, 0, 0, 0])
+    return np.concatenate([[np.cos(a / 2)], np.sin(a / 2) * th / a])
+
+
+def _quat_log(q):
+    """rotation vector of a unit quaternion close to identity (either sign)"""
+    q = q if q[0] >= 0 else -q
+    v = np.linalg.norm(q[1:])
+    if v == 0:
+        return np.zeros(3)
+    return 2 * np.arctan2(v, q[0]) * q[1:] / v
+
+
+def _rotmat(q, eigen):
+    w, x, y, z = q
+    if eigen:
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
+def _boxplus(nom, d, n, dialect):
+    """x (+) dx in the reference's error-state convention (MeasureUpdate.m:92-98 ; filter.cpp:726-733), with the carried
+    rotation matrix kept consistent with the quaternion"""
+    x = nom.copy()
+    x[0:3] += d[0:3]
+    x[3:6] += d[3:6]
+    q = _quat_mul(nom[6:10], _quat_exp(d[6:9]))
+    x[6:10] = q / np.linalg.norm(q)
+    x[10:13] += d[9:12]
+    x[13:16] += d[12:15]
+    if n == 18:
+        x[16:19] += d[15:18]
+    return x, _rotmat(x[6:10], dialect == oc.CPP).reshape(9)
+
+
+def _boxminus(a, b, n):
+    """a (-) b as an error-state vector"""
+    d = np.zeros(n)
+    d[0:3] = a[0:3] - b[0:3]
+    d[3:6] = a[3:6] - b[3:6]
+    qc = b[6:10] * np.array([1, -1, -1, -1])
+    d[6:9] = _quat_log(_quat_mul(qc, a[6:10]))
+    d[9:12] = a[10:13] - b[10:13]
+    d[12:15] = a[13:16] - b[13:16]
+    if n == 18:
+        d[15:18] = a[16:19] - b[16:19]
+    return d
+
+
+def _random_state(rng, dialect):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    nom = np.concatenate([rng.uniform(-1, 1, 3), rng.normal(0, 0.3, 3), q, rng.normal(0, 0.05, 3),
+                          rng.normal(0, 0.01, 3), [9.8, 0, 0] + rng.normal(0, 0.1, 3)])
+    return nom, _rotmat(q, dialect == oc.CPP).reshape(9)
+
+
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("dialect", [oc.MATLAB, oc.CPP])
+def test_measurement_jacobian_is_the_derivative_of_h(dialect, n):
+    orc = oc.Oracle(dialect, n)
+    rng = np.random.default_rng(11 + dialect)
+    ids = [orc.prm.marker_id[k] for k in range(orc.prm.n_markers)]
+    worst = 0.0
+    for trial in range(24):
+        nom, rot = _random_state(rng, dialect)
+        mid = ids[trial % len(ids)]
+        h0, _, _ = orc.measurement(nom, rot, mid, np.zeros(3), np.array([1.0, 0, 0, 0]))
+        for sign in (+1.0, -1.0):                       # measured quaternion on either side of the double cover
+            yq = sign * h0[3:7] + rng.normal(0, 1e-3, 4)
+            yq /= np.linalg.norm(yq)
+            yp = h0[0:3] + rng.normal(0, 1e-2, 3)
+            h, H, r = orc.measurement(nom, rot, mid, yp, yq)
+            # the sign unification picked the representative next to the measurement
+            assert np.linalg.norm(yq - h[3:7]) < np.linalg.norm(yq + h[3:7])
+            assert np.allclose(r[0:3], yp - h[0:3], atol=1e-15)
+            if dialect == oc.CPP:
+                assert np.allclose(r[3:7], yq - h[3:7], atol=1e-15)
+            else:
+                assert (r[3:7] == 0).all()              # MeasureUpdate.m:88
+            J = np.zeros((7, n))
+            for k in range(n):
+                d = np.zeros(n); d[k] = EPS
+                xp, Rp = _boxplus(nom, d, n, dialect)
+                xm, Rm = _boxplus(nom, -d, n, dialect)
+                hp, _, _ = orc.measurement(xp, Rp, mid, yp, yq)
+                hm, _, _ = orc.measurement(xm, Rm, mid, yp, yq)
+                J[:, k] = (hp - hm) / (2 * EPS)
+            err = np.abs(J - H).max()
+            worst = max(worst, err)
+            assert err < 2e-8, (trial, sign, err)
+            # structure: only the p and theta columns are non-zero
+            assert np.abs(H[:, 3:6]).max() == 0 and np.abs(H[:, 9:]).max() == 0
+            assert np.abs(H[3:7, 0:3]).max() == 0
+    print(f"H vs central differences, dialect {dialect}, n {n}: worst |dH| {worst:.2e}")
+
+
+def test_measurement_jacobian_check_is_sharp():
+    """the check above must be able to fail: L1 = 0.5 [0; I] without its factor 1/2, or the position block with the
+    wrong sign, differ from the finite differences at O(1)"""
+    orc = oc.Oracle(oc.MATLAB, 18)
+    rng = np.random.default_rng(3)
+    nom, rot = _random_state(rng, oc.MATLAB)
+    mid = orc.prm.marker_id[0]
+    h0, H, _ = orc.measurement(nom, rot, mid, np.zeros(3), np.array([1.0, 0, 0, 0]))
+    yq, yp = h0[3:7], h0[0:3]
+    J = np.zeros((7, 18))
+    for k in range(18):
+        d = np.zeros(18); d[k] = EPS
+        xp, Rp = _boxplus(nom, d, 18, oc.MATLAB)
+        xm, Rm = _boxplus(nom, -d, 18, oc.MATLAB)
+        J[:, k] = (orc.measurement(xp, Rp, mid, yp, yq)[0] - orc.measurement(xm, Rm, mid, yp, yq)[0]) / (2 * EPS)
+    bad = H.copy(); bad[3:7, 6:9] *= 2
+    assert np.abs(J - bad).max() > 0.1
+    bad = H.copy(); bad[0:3, 0:3] *= -1
+    assert np.abs(J - bad).max() > 0.5
+
+
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("dialect", [oc.MATLAB, oc.CPP])
+def test_transition_matrix_linearises_the_nominal_kinematics(dialect, n):
+    orc = oc.Oracle(dialect, n)
+    rng = np.random.default_rng(5 + dialect)
+    for trial in range(12):
+        nom, rot = _random_state(rng, dialect)
+        if n == 15:
+            nom[16:19] = [9.8, 0, 0]
+        R = rot.reshape(3, 3)
+        accel = R.T @ (-nom[16:19]) + rng.normal(0, 0.5, 3) + nom[10:13]
+        gyro = rng.normal(0, 0.3, 3) + nom[13:16]          # well above the C++ dialect's 1e-4 small-rate guard
+        errs = []
+        for dt in (0.01, 0.005):
+            Fx = orc.transition(nom, rot, accel, gyro, dt)
+            f0, _ = orc.predict_nominal(nom, rot, accel, gyro, dt)
+            J = np.zeros((n, n))
+            for k in range(n):
+                d = np.zeros(n); d[k] = EPS
+                xp, Rp = _boxplus(nom, d, n, dialect)
+                xm, Rm = _boxplus(nom, -d, n, dialect)
+                fp, _ = orc.predict_nominal(xp, Rp, accel, gyro, dt)
+                fm, _ = orc.predict_nominal(xm, Rm, accel, gyro, dt)
+                J[:, k] = (_boxminus(fp, f0, n) - _boxminus(fm, f0, n)) / (2 * EPS)
+            E = np.abs(J - Fx)
+            errs.append(E.max())
+            # first-order blocks agree to O(dt^2): |a| ~ 10 m/s^2, |w| ~ 0.5 rad/s
+            assert E.max() < 12.0 * dt * dt, (trial, dt, E.max(), np.unravel_index(E.argmax(), E.shape))
+            # rows ba, bg, g of F are identity rows exactly (ImuUpdate.m:63-69)
+            assert np.abs(J[9:, :] - np.eye(n)[9:, :]).max() < 1e-9
+            assert np.abs(Fx[9:, :] - np.eye(n)[9:, :]).max() == 0
+            if dialect == oc.MATLAB:
+                # expm(-[w]x dt) is the exact error rotation: the (theta, theta) block matches to rounding
+                assert E[6:9, 6:9].max() < 1e-8
+            # the first-order entries themselves, block by block, relative to their size
+            assert np.abs(J[0:3, 3:6] - dt * np.eye(3)).max() < 1e-9
+            assert np.abs(J[6:9, 12:15] + dt * np.eye(3)).max() < 2 * dt * dt
+            assert np.abs(J[3:6, 9:12] - Fx[3:6, 9:12]).max() < 2 * dt * dt
+            assert np.abs(J[3:6, 6:9] - Fx[3:6, 6:9]).max() < 12 * dt * dt
+            if n == 18:
+                assert np.abs(J[3:6, 15:18] - dt * np.eye(3)).max() < 1e-9
+        # second-order remainder: halving dt divides the mismatch by ~4
+        assert errs[1] < 0.3 * errs[0] + 1e-9, errs
+
+
+def test_transition_check_is_sharp():
+    """a transposed or sign-flipped (v, theta) block, or (theta, bg) with the wrong sign, is caught"""
+    orc = oc.Oracle(oc.CPP, 18)
+    rng = np.random.default_rng(9)
+    nom, rot = _random_state(rng, oc.CPP)
+    R = rot.reshape(3, 3)
+    accel = R.T @ (-nom[16:19]) + rng.normal(0, 0.5, 3)
+    gyro = rng.normal(0, 0.3, 3)
+    dt = 0.005
+    Fx = orc.transition(nom, rot, accel, gyro, dt)
+    f0, _ = orc.predict_nominal(nom, rot, accel, gyro, dt)
+    J = np.zeros((18, 18))
+    for k in range(18):
+        d = np.zeros(18); d[k] = EPS
+        xp, Rp = _boxplus(nom, d, 18, oc.CPP)
+        xm, Rm = _boxplus(nom, -d, 18, oc.CPP)
+        J[:, k] = (_boxminus(orc.predict_nominal(xp, Rp, accel, gyro, dt)[0], f0, 18)
+                   - _boxminus(orc.predict_nominal(xm, Rm, accel, gyro, dt)[0], f0, 18)) / (2 * EPS)
+    for blk in ((slice(3, 6), slice(6, 9)), (slice(6, 9), slice(12, 15)), (slice(3, 6), slice(9, 12))):
+        bad = Fx.copy(); bad[blk] = -bad[blk]
+        assert np.abs(J - bad).max() > 50 * dt * dt
+    bad = Fx.copy(); bad[3:6, 6:9] = bad[3:6, 6:9].T
+    assert np.abs(J - bad).max() > 50 * dt * dt

@@ -13,8 +13,9 @@ import pytest
 import oracle_capi as oc
 from fbus_ekf import BatchedFilter, capi, replay, synth
 from replay_ref import OracleEngine
-from util import (COV_TOL, STATE_TOL, WINDOW_TOL, cov_rel_err, rot_rel_err, state_rel_err,
-                  state_rel_err_literal)
+from util import (COV_BLOCK_TOL, COV_TOL, PLAIN_TOL, STATE_TOL, WINDOW_TOL, assert_parity, cov_rel_err,
+                  cov_rel_err_blockwise, parity_errors, rot_rel_err, state_rel_err, state_rel_err_literal,
+                  state_rel_err_plain)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -48,21 +49,11 @@ def _markers(lo, hi, frame, M, nom, prm):
     return ids, _r32(pos), _r32(quat)
 
 
-def _check(flt, eng, dtype, what, state_tol=STATE_TOL, cov_tol=COV_TOL):
-    g_nom, g_rot, g_P, g_prev = flt.get_state()
-    o_nom, o_rot, o_P, o_prev = eng.get_state()
-    es, where = state_rel_err(g_nom, o_nom, o_P)
-    er = rot_rel_err(g_rot, o_rot)
-    ec = cov_rel_err(g_P, o_P)
-    if dtype == 64:
-        state_tol, cov_tol = 1e-9, 1e-9
-    assert state_rel_err_literal(g_nom, o_nom) <= min(state_tol, STATE_TOL), f"{what}: literal state rel err"
-    assert es <= state_tol, f"{what}: state rel err {es:.3g} in block {where}"
-    assert er <= max(state_tol, 2e-6 if dtype == 32 else 0), f"{what}: rotation err {er:.3g}"
-    assert ec <= cov_tol, f"{what}: covariance rel err {ec:.3g}"
-    assert (g_prev == o_prev).all(), f"{what}: prev marker id"
-    assert np.abs(g_P - np.swapaxes(g_P, 1, 2)).max() == 0
-    return es, ec
+def _check(flt, eng, dtype, what, state_tol=STATE_TOL, cov_tol=COV_TOL, plain_tol=PLAIN_TOL, cov_block_tol=COV_BLOCK_TOL):
+    """the parity gate of tests/util.py (literal, sigma-aware and plain per-block state error, rotation, max-norm and
+    block-wise covariance error, symmetry, marker id) between the device state and the oracle's"""
+    e = assert_parity(flt.get_state(), eng.get_state(), dtype, what, state_tol, cov_tol, plain_tol, cov_block_tol)
+    return e["sigma"], e["cov"]
 
 
 # ------------------------------------------------------------------ single steps
@@ -148,7 +139,9 @@ def test_golden_vectors(dialect):
             nom, rot, P, _ = flt.get_state()
             sl = slice(1, None) if dialect == 0 else slice(None)   # filter 0: w == 0, reference NaN (guarded here)
             assert state_rel_err(nom[sl], g[t + "_pred_nom"][sl], g[t + "_pred_P"][sl])[0] <= STATE_TOL
+            assert state_rel_err_plain(nom[sl], g[t + "_pred_nom"][sl])[0] <= PLAIN_TOL
             assert cov_rel_err(P, g[t + "_pred_P"]) <= COV_TOL
+            assert cov_rel_err_blockwise(P, g[t + "_pred_P"]) <= COV_BLOCK_TOL
             assert np.isfinite(nom).all() and np.isfinite(P).all()          # the guard keeps w == 0 finite
             for mode, name in ((0, "near"), (1, "stack")):
                 flt.set_state(g[t + "_nom"], g[t + "_rot"], g[t + "_P"], g[t + "_prev"])
@@ -157,7 +150,9 @@ def test_golden_vectors(dialect):
                 assert (flt.applied() == g[f"{t}_{name}_ok"]).all()
                 assert (prev == g[f"{t}_{name}_prev"]).all()
                 assert state_rel_err(nom, g[f"{t}_{name}_nom"], g[f"{t}_{name}_P"])[0] <= STATE_TOL
+                assert state_rel_err_plain(nom, g[f"{t}_{name}_nom"])[0] <= PLAIN_TOL
                 assert cov_rel_err(P, g[f"{t}_{name}_P"]) <= COV_TOL
+                assert cov_rel_err_blockwise(P, g[f"{t}_{name}_P"]) <= COV_BLOCK_TOL
 
 
 # ------------------------------------------------------------------ free-running windows
@@ -184,7 +179,8 @@ def test_free_running_100_frames(dialect):
             flt.correct(ids, pos, quat, mode)
             eng.correct(ids, pos, quat, mode)
             if frame % 10 == 9:
-                es, ec = _check(flt, eng, 32, f"frame {frame}", state_tol=WINDOW_TOL)
+                es, ec = _check(flt, eng, 32, f"frame {frame}", state_tol=WINDOW_TOL, plain_tol=10 * PLAIN_TOL,
+                                cov_block_tol=10 * COV_BLOCK_TOL)
                 worst = (max(worst[0], es), max(worst[1], ec))
         print(f"free-run dialect {dialect}: worst state {worst[0]:.3g} cov {worst[1]:.3g}")
 
@@ -202,6 +198,10 @@ def test_land_recording_slice_replay():
         assert state_rel_err_literal(states[:, 1:20], gold[:, 1:20]) <= STATE_TOL
         assert state_rel_err(states[:, 1:20], gold[:, 1:20], Pg)[0] <= WINDOW_TOL   # ~2000 fp32 steps free-running
         assert cov_rel_err(states[:, 29:].reshape(-1, 18, 18), gold[:, 29:].reshape(-1, 18, 18)) <= COV_TOL
+        assert cov_rel_err_blockwise(states[:, 29:].reshape(-1, 18, 18), Pg) <= 10 * COV_BLOCK_TOL   # ~2000 steps free-running
+        print(f"[parity] land slice replay dialect {dialect}: plain per-block "
+              f"{state_rel_err_plain(states[:, 1:20], gold[:, 1:20])[0]:.2e}, cov block-wise "
+              f"{cov_rel_err_blockwise(states[:, 29:].reshape(-1, 18, 18), Pg):.2e}")
         with BatchedFilter(1, prm, dtype=64, nstate=18) as flt:
             states, _ = replay.replay(flt, d["imu"], d["image"], prm, max_frames=len(d[key]))
         assert np.abs(states[:, 1:20] - gold[:, 1:20]).max() < 1e-9
@@ -221,7 +221,7 @@ def test_predict_n_equals_repeated_predict():
             b.predict(acc[k], gyr[k], dt[k:k + 1])
         sa, sb = a.get_state(), b.get_state()
         assert state_rel_err(sa[0], sb[0], sa[2])[0] < 2e-6
-        assert cov_rel_err(sa[2], sb[2]) < 2e-6
+        assert cov_rel_err(sa[2], sb[2]) < 2e-6 and cov_rel_err_blockwise(sa[2], sb[2]) < 5e-6
 
 
 @pytest.mark.parametrize("dialect", [0, 1])
@@ -235,7 +235,7 @@ def test_joseph_form_equals_simple_form(dialect):
             f.correct(ids, pos, quat, 1)
         sa, sb = a.get_state(), b.get_state()
         assert state_rel_err(sa[0], sb[0], sa[2])[0] < 1e-10          # algebraic identity, fp64 kernels
-        assert cov_rel_err(sa[2], sb[2]) < 1e-10
+        assert cov_rel_err(sa[2], sb[2]) < 1e-10 and cov_rel_err_blockwise(sa[2], sb[2]) < 1e-10
     with BatchedFilter(B, _params(dialect, 1)) as b:
         b.set_state(nom, rot, P, prev)
         b.correct(ids, pos, quat, 1)
@@ -259,7 +259,7 @@ def test_one_stacked_marker_is_the_nearest_marker_update():
         # nearest applies the 7 rows one by one, stacked folds them into the 6x6 information matrix first: the same
         # posterior, not the same rounding
         assert state_rel_err(sa[0], sb[0], sb[2], nom)[0] < STATE_TOL
-        assert cov_rel_err(sa[2], sb[2]) < COV_TOL
+        assert cov_rel_err(sa[2], sb[2]) < COV_TOL and cov_rel_err_blockwise(sa[2], sb[2]) < COV_BLOCK_TOL
 
 
 @pytest.mark.parametrize("dialect", [0, 1])
@@ -281,6 +281,7 @@ def test_n15_is_n18_without_gravity_uncertainty(dialect):
             sa, sb = a.get_state(), b.get_state()
             assert state_rel_err(sa[0], sb[0], sa[2])[0] < tol
             assert cov_rel_err(sa[2], sb[2][:, :15, :15]) < tol
+            assert cov_rel_err_blockwise(sa[2], sb[2][:, :15, :15]) < tol
             assert np.abs(sb[2][:, 15:, :]).max() == 0
 
 
@@ -403,6 +404,8 @@ def test_full_batch_properties_and_shard_equality():
     eng.correct(ids[sub], pos[sub], quat[sub], 1)
     assert state_rel_err(full[0][sub], eng.nominal, eng.P)[0] <= STATE_TOL
     assert cov_rel_err(full[2][sub], eng.P) <= COV_TOL
+    assert cov_rel_err_blockwise(full[2][sub], eng.P) <= COV_BLOCK_TOL
+    assert state_rel_err_plain(full[0][sub], eng.nominal)[0] <= PLAIN_TOL
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -437,6 +440,7 @@ def test_fused_frame_equals_per_call_launches(dialect, mode):
         # same device functions, but two separately compiled kernels: fp contraction / association may differ,
         # so the two fp32 results agree to rounding (compounded over 16 steps), not bit for bit
         assert state_rel_err(sb[0], sa[0], sa[2])[0] < WINDOW_TOL and cov_rel_err(sb[2], sa[2]) < 1e-5
+        assert cov_rel_err_blockwise(sb[2], sa[2]) < COV_BLOCK_TOL
         eng = OracleEngine(B, dialect, 18)
         eng.set_state(nom, rot, P, prev)
         skip_h = skip.cpu().numpy()
@@ -455,6 +459,9 @@ def test_fused_frame_equals_per_call_launches(dialect, mode):
                 ok[skip_h == 1] = 0
         assert (b.applied() == ok).all()
         assert state_rel_err(sb[0], eng.nominal, eng.P)[0] < WINDOW_TOL and cov_rel_err(sb[2], eng.P) < COV_TOL
+        assert cov_rel_err_blockwise(sb[2], eng.P) < COV_BLOCK_TOL
+        print(f"[parity] fused frame dialect {dialect} mode {mode}: plain per-block "
+              f"{state_rel_err_plain(sb[0], eng.nominal)[0]:.2e}, cov block-wise {cov_rel_err_blockwise(sb[2], eng.P):.2e}")
         # predicts only (M = 0) through the fused entry point
         b.set_state(nom, rot, P, prev)
         a.set_state(nom, rot, P, prev)
@@ -463,6 +470,7 @@ def test_fused_frame_equals_per_call_launches(dialect, mode):
         a.sync(); b.sync()
         sa, sb = a.get_state(), b.get_state()
         assert state_rel_err(sb[0], sa[0], sa[2])[0] < STATE_TOL and cov_rel_err(sb[2], sa[2]) < 1e-5
+        assert cov_rel_err_blockwise(sb[2], sa[2]) < COV_BLOCK_TOL
 
 
 def test_sixteen_marker_slots_stacked():
@@ -481,7 +489,7 @@ def test_sixteen_marker_slots_stacked():
             flt.correct(ids16, pos16, quat16, 1)
             ok = eng.correct(ids16, pos16, quat16, 1)
             assert ok.all() and (flt.applied() == 1).all()
-            _check(flt, eng, dtype, "16 slots stacked", state_tol=STATE_TOL * 3)    # 84 sequential rank-1 updates
+            _check(flt, eng, dtype, "16 slots stacked", state_tol=STATE_TOL * 3)    # 84 rows at one linearisation point
 
 
 def test_long_run_stability_and_degenerate_inputs():
@@ -556,6 +564,7 @@ def test_device_state_io_records_aliasing_and_checkpoint_resume():
         for k in range(4):
             eng.predict(acc[k], gyr[k], dt[k])
         assert state_rel_err(got[0], eng.nominal, eng.P)[0] <= STATE_TOL and cov_rel_err(got[2], eng.P) <= COV_TOL
+        assert cov_rel_err_blockwise(got[2], eng.P) <= COV_BLOCK_TOL and state_rel_err_plain(got[0], eng.nominal)[0] <= PLAIN_TOL
 
 
 def test_hip_graph_replay_equals_eager_launches():
@@ -581,3 +590,45 @@ def test_hip_graph_replay_equals_eager_launches():
         sa, sb = a.get_state(), b.get_state()
         assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
         assert (a.applied() == b.applied()).all()
+
+
+# ------------------------------------------------------------------ the gate can fail
+def test_parity_gate_goes_red_on_a_mutated_result():
+    """mutation check of the gate itself: take a green GPU result and damage ONE 3x3 block (or one nominal block) by a
+    relative 1e-3 / a factor of two -- every such mutation must turn the gate red.  (The round-1 gate,
+    max|dP| / max|P| alone, let a doubled position block pass at 1.3e-6 because P_gg ~ 100 dominates it.)"""
+    B, M = 256, 4
+    prm, nom, rot, P, prev = _batch(B, 0, 18)
+    acc, gyr = _imu(0, B, 0, 1, nom)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    with BatchedFilter(B, prm) as flt:
+        eng = OracleEngine(B, 0, 18)
+        flt.set_state(nom, rot, P, prev)
+        eng.set_state(nom, rot, P, prev)
+        flt.predict(acc[0], gyr[0], DT)
+        eng.predict(acc[0], gyr[0], DT)
+        flt.correct(ids, pos, quat, 1)
+        eng.correct(ids, pos, quat, 1)
+        got, ref = flt.get_state(), eng.get_state()
+    assert_parity(got, ref, 32, "unmutated")
+    names = ("p", "v", "theta", "ba", "bg", "g")
+    for bi in range(6):
+        for bj in range(bi, 6):
+            for factor in (2.0, 1.0 + 1e-3, 0.0):
+                mut = [x.copy() for x in got]
+                blk = mut[2][:, 3 * bi:3 * bi + 3, 3 * bj:3 * bj + 3] * factor
+                mut[2][:, 3 * bi:3 * bi + 3, 3 * bj:3 * bj + 3] = blk
+                mut[2][:, 3 * bj:3 * bj + 3, 3 * bi:3 * bi + 3] = np.swapaxes(blk, 1, 2)     # keep it symmetric
+                if np.array_equal(mut[2], got[2]):
+                    continue                                                               # an all-zero block
+                with pytest.raises(AssertionError):
+                    assert_parity(mut, ref, 32, f"P({names[bi]},{names[bj]}) x {factor}", verbose=False)
+    for name, a, b in (("p", 0, 3), ("v", 3, 6), ("q", 6, 10), ("ba", 10, 13), ("bg", 13, 16), ("g", 16, 19)):
+        mut = [x.copy() for x in got]
+        mut[0][:, a:b] *= 1.0 + 1e-3
+        with pytest.raises(AssertionError):
+            assert_parity(mut, ref, 32, f"nominal {name} x (1 + 1e-3)", verbose=False)
+    mut = [x.copy() for x in got]
+    mut[2][:, 0, 1] *= 1.0 + 1e-6                                                          # asymmetry
+    with pytest.raises(AssertionError):
+        assert_parity(mut, ref, 32, "asymmetric", verbose=False)

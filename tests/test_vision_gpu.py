@@ -94,7 +94,7 @@ def test_corners_to_correct_chain_on_device():
     import torch
     from fbus_ekf import synth
     from replay_ref import OracleEngine
-    from util import COV_TOL, STATE_TOL, cov_rel_err, state_rel_err
+    from util import COV_BLOCK_TOL, COV_BLOCK_TOL_F64, COV_TOL, STATE_TOL, cov_rel_err, cov_rel_err_blockwise, state_rel_err
     B = 512
     prm = capi.default_params(1)
     d = np.load(os.path.join(GOLD, "vision_water.npz"))["corners"]
@@ -126,6 +126,7 @@ def test_corners_to_correct_chain_on_device():
     # the measurement itself carries fp32 triangulation error (~2e-6 m): compare at that scale
     assert state_rel_err(g[0], eng.nominal, eng.P)[0] <= 10 * STATE_TOL
     assert cov_rel_err(g[2], eng.P) <= COV_TOL
+    assert cov_rel_err_blockwise(g[2], eng.P) <= 10 * COV_BLOCK_TOL
 
 
 def test_large_batch_properties():
@@ -154,7 +155,7 @@ def test_correct_from_stereo_corners_matches_oracle(dialect, mode, dtype, mult):
     ~2e-6 m of rounding, so the bound is 10x the single-step one; fp64 is tight."""
     from fbus_ekf import synth
     from replay_ref import OracleEngine
-    from util import COV_TOL, STATE_TOL, cov_rel_err, state_rel_err
+    from util import COV_BLOCK_TOL, COV_BLOCK_TOL_F64, COV_TOL, STATE_TOL, cov_rel_err, cov_rel_err_blockwise, state_rel_err
     B, M, size = 256, 3, 0.117
     prm = capi.default_params(dialect)
     prm.marker_size = size
@@ -194,6 +195,7 @@ def test_correct_from_stereo_corners_matches_oracle(dialect, mode, dtype, mult):
     assert (g[3] == eng.prev).all()
     assert state_rel_err(g[0], eng.nominal, eng.P)[0] <= STATE_TOL * mult
     assert cov_rel_err(g[2], eng.P) <= COV_TOL * min(mult, 1.0)
+    assert cov_rel_err_blockwise(g[2], eng.P) <= (COV_BLOCK_TOL_F64 if dtype == 64 else COV_BLOCK_TOL * mult)
     assert not np.array_equal(g[0][2:], nom[2:].astype(g[0].dtype))           # it did update
 
 
