@@ -2,24 +2,33 @@
 """bench.py -- EKF steps/s of the batched predict/correct hot path on N MI355X.
 
 Workload (BASELINE.json / BASELINE.md section 2.1): 200 Hz IMU + 30 Hz stereo, 4 markers
-per frame, batch 65 536 filters PER GPU (weak scaling), fp32, N = 18 parity layout,
-Matlab dialect.  One bench "step" = 0.1 s of simulated time for the whole batch
-= 20 predict launches + 3 correct launches in the 7/7/6 pattern = 23 EKF steps per
-filter, every launch through the per-call C ABI (the state makes a full HBM round
-trip per EKF step).  Inputs are generated on the host with the seeded synthetic
-generator and are resident in HBM before the timed region starts.
+per frame, fp32, N = 18 parity layout, Matlab dialect.  One bench "step" = 0.1 s of
+simulated time for the whole batch = 20 predict launches + 3 correct launches in the
+7/7/6 pattern = 23 EKF steps per filter, every launch through the per-call C ABI (the
+state makes a full HBM round trip per EKF step).  Inputs are generated on the host with
+the seeded synthetic generator and are resident in HBM before the timed region starts.
 
-Prints ONE JSON line on rank 0 (contract: see the task statement).  `roofline` is for the
-dominant kernel (predict): algorithmic bytes per launch (1620 B x B) / its average
-duration measured with HIP events on the launch stream inside the timed region.
-`cpu_baseline` is the fp64 dense oracle port (oracle/), timed on a bounded sample.
+  python bench.py [--gpus N] [--steps K] [--warmup W]            weak scaling: 65 536 filters per GPU
+  python bench.py --gpus N --total-batch 262144                  strong scaling: BASELINE config 4, the same
+                                                                 262 144 filters over 1 / 2 / 4 / 8 GPUs
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (what the driver runs)
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N rank processes itself
+(`python -m torch.distributed.run ...` as a CHILD process, before this process has touched the GPU),
+relays their output and exits with their return code; it fails loudly when the box has fewer than N GPUs.
+Under a launcher, WORLD_SIZE must equal --gpus.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (predict): bytes the kernel MOVES per
+launch (1436 B per filter: 828 read, 608 written -- the predict-invariant covariance tail and ba/bg/g are not
+written back) / its average duration measured with HIP events on the launch stream inside the timed region;
+`achieved_api` prices SURVEY.md 8(d)'s full record round trip (1620 B) instead.  `roofline_hbm_resident` is the
+same measurement at 262 144 filters per GPU (210 MB of records: past the 256 MB Infinity Cache once the inputs are
+counted).  `cpu_baseline` is the fp64 dense oracle port (oracle/), timed on a bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,10 +41,16 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 PATTERN = (7, 7, 6)                 # predicts between corrects: 200 Hz IMU / 30 Hz stereo
 STEPS_PER_BENCH_STEP = sum(PATTERN) + len(PATTERN)      # 23 EKF steps per filter
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PREDICT_BYTES = 2 * 796 + 28        # packed record round trip + IMU sample
-CORRECT_BYTES_M4 = 2 * 796 + 32 * 4
+# packed record round trip + inputs (what the per-call API implies)
+PREDICT_BYTES_API = 2 * 796 + 28
+CORRECT_BYTES_API = lambda M: 2 * 796 + 32 * M
+# what the kernels move (fp32, N = 18): records are 50 chunks of 16 B
+#   predict: reads 50 chunks + 28 B IMU sample, writes 5 (p q R v) + 33 (covariance elements ImuUpdate can change)
+#   correct: reads 50 chunks + 32 B per marker slot, writes 2 (p q) + 3 (v ba bg g) + 43 (covariance + prev id) + 1 B flag
+PREDICT_BYTES_MOVED = 50 * 16 + 28 + 38 * 16
+CORRECT_BYTES_MOVED = lambda M: 50 * 16 + 32 * M + 48 * 16 + 1
 POOL = 4                            # distinct bench steps of input data resident in HBM, cycled
-TIMING_STRIDE = 16                  # HIP-event brackets on every 16th camera frame of the timed region (every 4th cost 2 %)
+HBM_LEG_BATCH = 262144              # the HBM-roofline claim needs B >= 262 144 per GPU
 
 
 def parse():
@@ -43,30 +58,72 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=65536, help="filters per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="filters per GPU (weak scaling)")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="strong scaling: this many filters in total, cut into contiguous 64-aligned shards over the "
+                         "ranks (BASELINE.json config 4: 262144 over 1/2/4/8 GPUs)")
     ap.add_argument("--markers", type=int, default=4)
     ap.add_argument("--mode", choices=["stacked", "nearest"], default="stacked")
     ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 262 144-filter HBM-resident roofline leg")
     ap.add_argument("--graphs", action="store_true",
                     help="replay each bench step (23 launches) from a captured HIP graph (launch-bound small batches); "
                          "the per-kernel HIP-event timing then comes from a short eager pass after the timed region")
     ap.add_argument("--kernel-timing", choices=["on", "off"], default="on",
-                    help="bracket every launch with HIP events inside the timed region (feeds `roofline`)")
+                    help="bracket runs of launches with HIP events inside the timed region (feeds `roofline`)")
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_prefix="predict_kernel<float, 18"):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_digest.json, written by tools/profile_digest.py: separate FETCH_SIZE / WRITE_SIZE
-    passes, KiB units, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  bench.py cannot
-    collect PMC counters itself; None if the digest is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_digest.json")
+# ------------------------------------------------------------------------------------------------
+# multi-GPU front door
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child `torch.distributed.run` and relay.
+    Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise it), and the ranks
+    are CHILD processes -- this process is never replaced by another program."""
+    import torch
+    shared = os.environ.get("FBUS_BENCH_DEBUG_SHARED_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not shared:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but this box has {have} GPU(s); refusing to report a "
+                         f"{args.gpus}-GPU number from fewer devices (there is no CPU fallback)\n")
+        return 3
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def pmc_traffic(batch, args, world, kernel="predict"):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r02_digest*.json, written
+    by tools/profile_digest.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE doubled on gfx950 as
+    MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself.  The digest is only quoted when
+    it was taken on THIS configuration (batch, dialect, markers, mode, eager launches, one GPU); otherwise None."""
+    if world != 1 or args.graphs:
+        return None, None
+    path = os.path.join(ROOT, "profiles", f"r02_digest_b{batch}.json")
     try:
         d = json.load(open(path))
+        cfg = d.get("_config", {})
+        if (cfg.get("batch"), cfg.get("dialect"), cfg.get("markers"), cfg.get("mode")) != \
+                (batch, args.dialect, args.markers, args.mode):
+            return None, None
         for name, v in d.items():
-            if name.startswith(kernel_prefix) and "fetch_bytes" in v:
+            if name.startswith(kernel + "_kernel<float, 18") and "fetch_bytes" in v:
                 return v["fetch_bytes"] + v["write_bytes"], os.path.relpath(path, ROOT)
     except Exception:
         pass
@@ -93,8 +150,16 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(args, prm_dialect, seconds):
-    """fp64 dense oracle port on the host cores, on a bounded sample of the same workload."""
+def cpu_baseline(args, seconds):
+    """The fp64 dense oracle port on the host cores, on a bounded sample, two legs:
+
+    value          the reference's own CPU path: C++ dialect, nearest marker with hysteresis, ONE 7-row update per frame
+                   solved by LDLT -- FILTER::UpdateCovariance + UpdateNominalState (filter.cpp:588-616,533-582) and
+                   FILTER::ObservationUpdate (filter.cpp:622-741) restated operation for operation with dense 18 x 18 loops;
+    same_workload  what the GPU number runs: the bench's dialect and correct mode (Matlab dialect, all 4 markers stacked
+                   into one 28-row update with `inv`, MeasureUpdate.m:84 generalised) -- more work per correct than the
+                   reference ever does.
+    Both on all usable host cores (one thread team per schedule), `value_1thread` beside."""
     import oracle_capi as oc
     from fbus_ekf import capi, synth
     try:
@@ -103,40 +168,145 @@ def cpu_baseline(args, prm_dialect, seconds):
     except Exception:
         native = False
     cores = usable_cores()
-    prm = capi.default_params(prm_dialect)
-    mode = 1 if args.mode == "stacked" else 0
 
-    def run(Bs, threads, reps):
-        orc = oc.Oracle(prm_dialect, 18, native=native, nthreads=threads)
-        nom, rot, P, prev = synth.initial_state(0, Bs, list(prm.p0_diag), 18)
-        acc, gyr = synth.imu_samples(0, Bs, 0, sum(PATTERN), nom)
-        frames = [synth.marker_frame(0, Bs, f, args.markers, nom, prm) for f in range(len(PATTERN))]
-        ids = np.stack([f[0] for f in frames]); pos = np.stack([f[1] for f in frames]); quat = np.stack([f[2] for f in frames])
-        dt = np.full(sum(PATTERN), 0.005)
-        t0 = time.perf_counter()                             # one thread team runs the whole schedule
-        orc.schedule(nom, rot, P, prev, PATTERN, reps, acc, gyr, dt, ids, pos, quat, mode)
-        return Bs * STEPS_PER_BENCH_STEP * reps / (time.perf_counter() - t0)
+    def leg(dialect, mode, secs):
+        prm = capi.default_params(dialect)
 
-    probe = run(256, 1, 1)                                   # steps/s of one thread, short probe
-    Bs1 = int(min(8192, max(256, probe * min(seconds, 4.0) / STEPS_PER_BENCH_STEP)))
-    one = run(Bs1, 1, 1)
-    BsN = 256 * cores                                        # 256 filters per thread, reps sized for ~`seconds`
-    reps = int(max(1, min(2000, one * cores * 0.6 * seconds / (BsN * STEPS_PER_BENCH_STEP))))
-    allc = run(BsN, cores, reps)
-    return {"value": allc, "unit": "EKF steps/s", "cores": cores, "kind": "port",
-            "sample": f"{BsN} filters x {reps} bench steps (20 predict + 3 correct each, M={args.markers}, {args.mode}), "
-                      f"fp64 dense oracle port, {cores} threads, {'-march=native' if native else 'generic x86-64'}",
-            "value_1thread": one}
+        def run(Bs, threads, reps):
+            orc = oc.Oracle(dialect, 18, native=native, nthreads=threads)
+            nom, rot, P, prev = synth.initial_state(0, Bs, list(prm.p0_diag), 18)
+            acc, gyr = synth.imu_samples(0, Bs, 0, sum(PATTERN), nom)
+            frames = [synth.marker_frame(0, Bs, f, args.markers, nom, prm) for f in range(len(PATTERN))]
+            ids = np.stack([f[0] for f in frames]); pos = np.stack([f[1] for f in frames]); quat = np.stack([f[2] for f in frames])
+            dt = np.full(sum(PATTERN), 0.005)
+            t0 = time.perf_counter()                             # one thread team runs the whole schedule
+            orc.schedule(nom, rot, P, prev, PATTERN, reps, acc, gyr, dt, ids, pos, quat, mode)
+            return Bs * STEPS_PER_BENCH_STEP * reps / (time.perf_counter() - t0)
+
+        probe = run(256, 1, 1)                                   # steps/s of one thread, short probe
+        Bs1 = int(min(8192, max(256, probe * min(secs, 4.0) * 0.3 / STEPS_PER_BENCH_STEP)))
+        one = run(Bs1, 1, 1)
+        BsN = 256 * cores                                        # 256 filters per thread, reps sized for ~`secs`
+        reps = int(max(1, min(2000, one * cores * 0.6 * secs / (BsN * STEPS_PER_BENCH_STEP))))
+        allc = run(BsN, cores, reps)
+        return allc, one, f"{BsN} filters x {reps} bench steps (20 predict + 3 correct each, M={args.markers})"
+
+    ref_v, ref_1, ref_s = leg(capi.DIALECT_CPP, capi.MODE_NEAREST, seconds * 0.5)
+    d = capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP
+    m = capi.MODE_STACKED if args.mode == "stacked" else capi.MODE_NEAREST
+    same_v, same_1, same_s = leg(d, m, seconds * 0.5)
+    flags = "-march=native" if native else "generic x86-64"
+    return {"value": ref_v, "unit": "EKF steps/s", "cores": cores, "kind": "port",
+            "path": "reference CPU path restated: C++ dialect, UpdateCovariance+UpdateNominalState (filter.cpp:533-616) per "
+                    "IMU sample, ObservationUpdate (filter.cpp:622-741) per frame = nearest marker with hysteresis, 7 rows, LDLT",
+            "sample": f"{ref_s}, fp64 dense oracle port, {cores} threads, {flags}",
+            "value_1thread": ref_1,
+            "same_workload": {"value": same_v, "value_1thread": same_1, "unit": "EKF steps/s",
+                              "path": f"the GPU run's own configuration ({args.dialect} dialect, correct mode {args.mode}: "
+                                      f"{7 * args.markers if args.mode == 'stacked' else 7}-row dense update), "
+                                      "MeasureUpdate.m:37-103 / ImuUpdate.m:36-82 restated",
+                              "sample": f"{same_s}, fp64 dense oracle port, {cores} threads, {flags}"}}
+
+
+class Workload:
+    """device-resident inputs of `pool` distinct bench steps for the filters [lo, hi) + the filter handle"""
+
+    def __init__(self, torch, dev, local_rank, lo, hi, args, pool, with_cov=True):
+        from fbus_ekf import BatchedFilter, capi, synth
+        self.torch, self.capi = torch, capi
+        dialect = capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP
+        self.mode = capi.MODE_STACKED if args.mode == "stacked" else capi.MODE_NEAREST
+        self.B, self.M = hi - lo, args.markers
+        prm = capi.default_params(dialect)
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+        nom, rot, P, prev = synth.initial_state(lo, hi, list(prm.p0_diag), 18, with_cov=with_cov)
+        self.pool = []
+        for s in range(pool):
+            acc, gyr = synth.imu_samples(lo, hi, s * sum(PATTERN), sum(PATTERN), nom)
+            frames = []
+            for f in range(len(PATTERN)):
+                ids, pos, quat = synth.marker_frame(lo, hi, s * len(PATTERN) + f, self.M, nom, prm)
+                frames.append((torch.from_numpy(ids).to(dev), f32(pos), f32(quat)))
+            self.pool.append((f32(acc), f32(gyr), frames))
+        self.d_dt = f32(np.full(max(PATTERN), 0.005))
+        # The handle stays on its own (non-blocking) stream; the inputs above were uploaded on torch's stream, so
+        # the device is synchronised before the first launch and on both sides of every timed region.
+        self.flt = BatchedFilter(self.B, prm, device=local_rank, dtype=32, nstate=18)
+        self.state0 = (nom, rot, P, prev)
+        self.reset_state()
+        _, self.bpf, total = self.flt.records()
+        self.rec = torch.empty(total, dtype=torch.uint8, device=dev)  # records live in a torch tensor -> RCCL can ship them
+        self.flt.attach_records(self.rec)
+        torch.cuda.synchronize()
+
+    def reset_state(self):
+        nom, rot, P, prev = self.state0
+        self.flt.set_state(nom, rot, P, prev)
+        if P is None:
+            self.flt.reset_cov()                                  # P0 diagonal written by the device (no 680 MB host array)
+
+    def step(self, i, fused=False):
+        acc, gyr, frames = self.pool[i % len(self.pool)]
+        k = 0
+        for f, K in enumerate(PATTERN):
+            ids, pos, quat = frames[f]
+            self.flt.frame(acc[k:k + K], gyr[k:k + K], self.d_dt[:K], ids, pos, quat, self.mode, fused=fused)
+            k += K
+
+
+def timed(torch, fn, steps, warmup, barrier=lambda: None, before_timing=lambda: None):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    before_timing()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src):
+    B, M = w.B, w.M
+    pred_us = pred_ms / pred_n * 1e3 if pred_n else float("nan")
+    corr_us = corr_ms / corr_n * 1e3 if corr_n else float("nan")
+    moved = PREDICT_BYTES_MOVED * B
+    achieved = moved / (pred_us * 1e-6) / 1e9
+    api = PREDICT_BYTES_API * B / (pred_us * 1e-6) / 1e9
+    roof = {"bound": "hbm", "kernel": "predict_kernel<float,18>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_us": pred_us, "launches": pred_n, "bytes_moved_per_launch": moved,
+            "achieved_api": api, "frac_api": api / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": PREDICT_BYTES_API * B,
+            "traffic_GBs": (traffic / (pred_us * 1e-6) / 1e9) if traffic else None,
+            "note": "achieved = bytes the kernel moves (1436 B per filter: 828 read, 608 written; the PMC `traffic` of the "
+                    "committed profile is the cross-check) / HIP-event launch time; achieved_api prices SURVEY 8(d)'s full "
+                    "record round trip (1620 B) and can pass the peak. At 65 536 filters the 52 MB of records stay in the "
+                    "256 MB Infinity Cache between launches: that rate is cache + HBM, see roofline_hbm_resident"}
+    corr = {"kernel": "correct_kernel<float,18,stacked>" if w.mode == w.capi.MODE_STACKED else "correct_kernel<float,18,nearest>",
+            "avg_launch_us": corr_us, "launches": corr_n,
+            "achieved_GBs": CORRECT_BYTES_MOVED(M) * B / (corr_us * 1e-6) / 1e9,
+            "frac": CORRECT_BYTES_MOVED(M) * B / (corr_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "bytes_moved_per_launch": CORRECT_BYTES_MOVED(M) * B,
+            "achieved_api_GBs": CORRECT_BYTES_API(M) * B / (corr_us * 1e-6) / 1e9}
+    return roof, corr
 
 
 def main():
     args = parse()
-    import torch
-    from fbus_ekf import BatchedFilter, capi, shard, synth
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch {args.gpus} ranks or pass --gpus {world}\n")
+        sys.exit(2)
+
+    import torch
+    from fbus_ekf import capi, shard
     dist = None
     # FBUS_BENCH_DEBUG_SHARED_GPU=1: rehearsal of the N > 1 code path on a 1-GPU box (all ranks on cuda:0,
     # gloo instead of RCCL for the control collectives); never used by the driver's multi-GPU runs.
@@ -145,147 +315,98 @@ def main():
         local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if not shared and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but the box has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)                        # before the process group: RCCL binds to the current device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if shared:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    ctl_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev
 
-    dialect = capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP
-    mode = capi.MODE_STACKED if args.mode == "stacked" else capi.MODE_NEAREST
-    B, M = args.batch, args.markers
-    prm = capi.default_params(dialect)
-    lo, hi = shard.weak_range(B, rank)                       # this rank's filters in the global index space
-
-    # ---- synthetic inputs, uploaded before timing --------------------------------------
-    nom, rot, P, prev = synth.initial_state(lo, hi, list(prm.p0_diag), 18)
-    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-    pool = []
-    for s in range(POOL):
-        acc, gyr = synth.imu_samples(lo, hi, s * sum(PATTERN), sum(PATTERN), nom)
-        frames = []
-        for f in range(len(PATTERN)):
-            ids, pos, quat = synth.marker_frame(lo, hi, s * len(PATTERN) + f, M, nom, prm)
-            frames.append((torch.from_numpy(ids).to(dev), f32(pos), f32(quat)))
-        pool.append((f32(acc), f32(gyr), frames))
-    d_dt = f32(np.full(max(PATTERN), 0.005))
-
-    flt = BatchedFilter(B, prm, device=local_rank, dtype=32, nstate=18)
-    flt.set_stream(torch.cuda.current_stream())
-    flt.set_state(nom, rot, P, prev)
-    ptr, bpf, total = flt.records()
-    rec = torch.empty(total, dtype=torch.uint8, device=dev)  # records live in a torch tensor -> RCCL can ship them
-    flt.attach_records(rec)
-
-    def bench_step(i):
-        acc, gyr, frames = pool[i % POOL]
-        k = 0
-        for f, K in enumerate(PATTERN):
-            ids, pos, quat = frames[f]
-            flt.frame(acc[k:k + K], gyr[k:k + K], d_dt[:K], ids, pos, quat, mode)
-            k += K
+    strong = args.total_batch > 0
+    if strong:
+        lo, hi = shard.shard_range(args.total_batch, rank, world)
+    else:
+        lo, hi = shard.weak_range(args.batch, rank)          # this rank's filters in the global index space
+    total_filters = args.total_batch if strong else args.batch * world
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    flt.timing_enable(args.kernel_timing == "on", stride=TIMING_STRIDE)
+    w = Workload(torch, dev, local_rank, lo, hi, args, POOL)
+    flt = w.flt
+    frames_timed = args.steps * len(PATTERN)
+    stride = max(4, min(16, frames_timed // 16))             # HIP-event brackets on every stride-th camera frame
+    flt.timing_enable(args.kernel_timing == "on", stride=stride)
+    bench_step = w.step
     if args.graphs:
-        graph_ids = [flt.graph_capture(lambda j=j: bench_step(j)) for j in range(POOL)]
-        eager_step = bench_step
+        graph_ids = [flt.graph_capture(lambda j=j: w.step(j)) for j in range(POOL)]
         bench_step = lambda i: flt.graph_launch(graph_ids[i % POOL])
-    for i in range(args.warmup):
-        bench_step(i)
-    torch.cuda.synchronize()
-    flt.timing_reset()
-    flt._keep.clear()
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        bench_step(args.warmup + i)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctl_dev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev
+    def clear():
+        flt.timing_reset()
+        flt._keep.clear()
+
+    elapsed = timed(torch, bench_step, args.steps, args.warmup, barrier, clear)
     elapsed = shard.max_over_ranks(elapsed, dist, world, ctl_dev)
 
     if args.graphs and args.kernel_timing == "on":          # events cannot live inside a graph: short eager pass
         flt.timing_reset()
         for i in range(4):
-            eager_step(i)
+            w.step(i)
         torch.cuda.synchronize()
     pred_ms, pred_n = flt.timing_read(capi.KERNEL_PREDICT)
     corr_ms, corr_n = flt.timing_read(capi.KERNEL_CORRECT)
     flt.timing_enable(False)
 
     # ---- extra (never `value`): the same frames through the fused one-launch-per-frame kernel ----
-    def fused_step(i):
-        acc, gyr, frames = pool[i % POOL]
-        k = 0
-        for f, K in enumerate(PATTERN):
-            ids, pos, quat = frames[f]
-            flt.frame(acc[k:k + K], gyr[k:k + K], d_dt[:K], ids, pos, quat, mode, fused=True)
-            k += K
-
-    flt.set_state(nom, rot, P, prev)
-    for i in range(args.warmup):
-        fused_step(i)
-    barrier()
-    torch.cuda.synchronize()
-    tf0 = time.perf_counter()
-    for i in range(args.steps):
-        fused_step(args.warmup + i)
-    torch.cuda.synchronize()
-    barrier()
-    fused_elapsed = shard.max_over_ranks(time.perf_counter() - tf0, dist, world, ctl_dev)
+    w.reset_state()
+    fused_elapsed = timed(torch, lambda i: w.step(i, fused=True), args.steps, args.warmup, barrier)
+    fused_elapsed = shard.max_over_ranks(fused_elapsed, dist, world, ctl_dev)
     flt._keep.clear()
 
     # ---- the single end-of-run collective: gather the packed records (timed separately) ----
     torch.cuda.synchronize()
     barrier()
     tg = time.perf_counter()
-    gathered = shard.gather_records(rec.cpu() if ctl_dev == "cpu" else rec, dist, world)
+    gathered = shard.gather_records(w.rec.cpu() if ctl_dev == "cpu" else w.rec, dist, world) if not strong else \
+        shard.gather_records_ragged(w.rec.cpu() if ctl_dev == "cpu" else w.rec, dist, world, ctl_dev)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - tg) * 1e3
     nomf, _, Pf, _ = flt.get_state()
     finite = bool(np.isfinite(nomf).all() and np.isfinite(Pf).all())
+    finite = shard.max_over_ranks(0.0 if finite else 1.0, dist, world, ctl_dev) == 0.0
+    ranks_seen = int(shard.sum_over_ranks(1.0, dist, world, ctl_dev))
 
     if rank == 0:
-        total_steps = world * B * STEPS_PER_BENCH_STEP * args.steps
+        total_steps = total_filters * STEPS_PER_BENCH_STEP * args.steps
         value = total_steps / elapsed
-        pred_avg_ms = pred_ms / max(pred_n, 1) if pred_n else float("nan")
-        corr_ms = corr_ms if corr_n else float("nan")
-        achieved = PREDICT_BYTES * B / (pred_avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic() if (B == 65536 and world == 1) else (None, None)
+        traffic, traffic_src = pmc_traffic(w.B, args, world)
+        roof, corr = roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src)
         out = {
             "metric": "EKF steps/s (ImuUpdate+MeasureUpdate), batch=65536, 4 markers",
             "value": value, "unit": "EKF steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"batch {B} filters/GPU, 200 Hz IMU + 30 Hz stereo (7/7/6 predicts per correct), "
-                                   f"{M} markers/frame, N=18, {args.dialect} dialect, correct mode {args.mode}, "
+            "config": {"workload": (f"{args.total_batch} filters in total, sharded over {world} GPU(s) "
+                                    f"({w.B} on rank 0)" if strong else f"batch {w.B} filters/GPU") +
+                                   f", 200 Hz IMU + 30 Hz stereo (7/7/6 predicts per correct), "
+                                   f"{w.M} markers/frame, N=18, {args.dialect} dialect, correct mode {args.mode}, "
                                    "per-call API (one launch per EKF step)" + (", replayed from HIP graphs" if args.graphs else ""),
-                       "batch_per_gpu": B, "markers": M, "ekf_steps_per_bench_step": STEPS_PER_BENCH_STEP,
-                       "parallelism": f"independent filter shards x{world}, one RCCL gather at the end"},
-            "roofline": {"bound": "hbm", "kernel": "predict_kernel<float,18>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "avg_launch_us": pred_avg_ms * 1e3, "launches": pred_n,
-                         "algorithmic_bytes_per_launch": PREDICT_BYTES * B,
-                         "moved_GBs": (traffic / (pred_avg_ms * 1e-3) / 1e9) if traffic else None,
-                         "note": "achieved prices the SURVEY 8(d) figure (full record round trip, 1620 B); the kernel "
-                                 "moves less (the predict-invariant covariance tail is not written back) and the 52 MB "
-                                 "of records sit in the 256 MB Infinity Cache between launches, so achieved can "
-                                 "approach or pass the HBM peak; moved_GBs = PMC traffic / launch time is the "
-                                 "physical rate"},
-            "correct_kernel": {"avg_launch_us": corr_ms / max(corr_n, 1) * 1e3, "launches": corr_n,
-                               "achieved_GBs": CORRECT_BYTES_M4 * B / (corr_ms / max(corr_n, 1) * 1e-3) / 1e9},
+                       "batch_per_gpu": w.B, "total_filters": total_filters, "markers": w.M,
+                       "ekf_steps_per_bench_step": STEPS_PER_BENCH_STEP,
+                       "parallelism": f"independent filter shards x{world}, one RCCL gather at the end",
+                       "ranks_seen": ranks_seen,
+                       "collective_backend": (dist.get_backend() if dist is not None else None)},
+            "roofline": roof, "correct_kernel": corr,
             "fused_frame": {"value": total_steps / fused_elapsed, "unit": "EKF steps/s",
                             "ms_per_step": fused_elapsed / args.steps * 1e3,
                             "note": "same frames, one launch per camera frame (K predicts + correct, records "
@@ -294,12 +415,37 @@ def main():
             "gather_ms": gather_ms, "gathered_bytes": int(sum(g.numel() for g in gathered)),
             "state_finite": finite,
         }
+    flt.close()
+    del w
+
+    # ---- HBM-resident roofline leg: the same bench at 262 144 filters on this GPU (rank 0, N = 1 only) ----
+    if rank == 0:
+        out["roofline_hbm_resident"] = None
+        if world == 1 and not args.no_hbm_leg and not strong and args.batch < HBM_LEG_BATCH:
+            torch.cuda.empty_cache()
+            w2 = Workload(torch, dev, local_rank, 0, HBM_LEG_BATCH, args, 1, with_cov=False)
+            steps2, warm2 = max(5, min(args.steps, 20)), 3
+            w2.flt.timing_enable(True, stride=2)
+            el2 = timed(torch, w2.step, steps2, warm2, before_timing=lambda: (w2.flt.timing_reset(), w2.flt._keep.clear()))
+            p_ms, p_n = w2.flt.timing_read(capi.KERNEL_PREDICT)
+            c_ms, c_n = w2.flt.timing_read(capi.KERNEL_CORRECT)
+            tr2, src2 = pmc_traffic(HBM_LEG_BATCH, args, 1)
+            roof2, corr2 = roofline_block(w2, p_ms, p_n, c_ms, c_n, tr2, src2)
+            roof2.pop("note")
+            roof2.update({"batch": HBM_LEG_BATCH, "records_MB": HBM_LEG_BATCH * 800 / 1e6, "steps": steps2,
+                          "value": HBM_LEG_BATCH * STEPS_PER_BENCH_STEP * steps2 / el2, "unit_value": "EKF steps/s",
+                          "correct_kernel": corr2,
+                          "note": "same bench pattern at 262 144 filters on one GPU: 210 MB of records + the per-step inputs "
+                                  "exceed what stays resident in the 256 MB Infinity Cache between launches, so this is the "
+                                  "HBM streaming rate (the guide's float4-copy ceiling is 6.29 TB/s = 0.79 of the 8 TB/s spec)"})
+            out["roofline_hbm_resident"] = roof2
+            w2.flt.close()
+            del w2
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, dialect, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    flt.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,14 +1,28 @@
 #!/usr/bin/env python3
-"""Builds fbus-ekf_amd/lib/libfbus_ekf.so (HIP, gfx950) in-tree with hipcc."""
+"""Builds fbus-ekf_amd/lib/libfbus_ekf.so (HIP, gfx950) in-tree with hipcc.
+
+The library is 17 translation units compiled in parallel and linked into one shared object:
+  fbus_ekf.hip                          handle, C ABI, the small kernels (pack/unpack, init, EMA, marker pose)
+  kernels_tu.hip x 16                   one kernel family (predict / correct / fused frame / corners) for one
+                                        (float|double, N = 18|15), both dialects: -DFBUS_TU_T/N/FAMILY
+Objects live in fbus-ekf_amd/lib/obj/ (git-ignored) and are rebuilt when a source they include is newer.
+  python build.py [--force] [--only f32_18_correct,...] [--jobs N]
+FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds (A/B of differently built kernels via FBUS_EKF_LIB).
+"""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", "fbus_ekf.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "ekf_kernels.hpp"), os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "csrc", "vision_device.hpp"),
-              os.path.join(HERE, "..", "include", "fbus_ekf.h")]
+CSRC = os.path.join(HERE, "csrc")
+HEADERS = [os.path.join(CSRC, h) for h in ("ekf_kernels.hpp", "ekf_device.hpp", "vision_device.hpp", "ekf_launch.hpp")] + \
+          [os.path.join(HERE, "..", "include", "fbus_ekf.h")]
 OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so")   # FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds
+OBJDIR = os.environ.get("FBUS_OBJDIR") or os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("FBUS_OUT") else
+                                                       "obj_" + os.path.splitext(os.path.basename(OUT))[0])
+FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4}
+TYPES = {"f32": "float", "f64": "double"}
 
 
 def hipcc():
@@ -18,26 +32,77 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def units():
+    """(name, source, defines)"""
+    out = [("main", os.path.join(CSRC, "fbus_ekf.hip"), [])]
+    for tn, t in TYPES.items():
+        for n in (18, 15):
+            for fam, code in FAMILIES.items():
+                out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
+                            [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"]))
+    return out
+
+
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in [src, os.path.abspath(__file__)] + HEADERS)
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+    return any(_stale(os.path.join(OBJDIR, name + ".o"), src) for name, src, _ in units()) or \
+        any(os.path.getmtime(os.path.join(OBJDIR, name + ".o")) > os.path.getmtime(OUT) for name, _, _ in units())
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, only=None, jobs=None):
     if not force and not needs_build():
         return OUT
+    os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    srcs = [s for s in SRC if os.path.exists(s)]
     # -fno-slp-vectorize: the SLP pass packs the unrolled scalar FMAs into v_pk_fma_f32 and pays for it with
     # ~1.9x more instructions (v_mov / v_accvgpr shuffles to form register pairs) -- measured on the .s
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", OUT] + os.environ.get("FBUS_EXTRA_FLAGS", "").split() + srcs
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"] + \
+        os.environ.get("FBUS_EXTRA_FLAGS", "").split()
+    todo = []
+    for name, src, defs in units():
+        obj = os.path.join(OBJDIR, name + ".o")
+        if only and not any(o in name for o in only) and os.path.exists(obj):
+            continue
+        if force or _stale(obj, src) or (only and any(o in name for o in only)):
+            todo.append((name, [hipcc()] + flags + defs + ["-c", src, "-o", obj]))
+    # the fp64 / fused-frame units take longest: start them first
+    todo.sort(key=lambda u: (("f64" in u[0]) * 2 + ("frame" in u[0]) + ("correct" in u[0])), reverse=True)
+    jobs = jobs or int(os.environ.get("FBUS_JOBS", "0")) or min(8, os.cpu_count() or 1)
+
+    def run(u):
+        if verbose:
+            print("  hipcc", u[0], flush=True)
+        r = subprocess.run(u[1], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{u[0]}: {' '.join(u[1])}\n{r.stderr[-4000:]}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr[-2000:])
+        return u[0]
+
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(run, todo))
+    objs = [os.path.join(OBJDIR, name + ".o") for name, _, _ in units()]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
-        print(" ".join(cmd))
+        print("  link", os.path.relpath(OUT, HERE), flush=True)
     subprocess.run(cmd, check=True)
     return OUT
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    only = None
+    jobs = None
+    for i, a in enumerate(sys.argv):
+        if a == "--only":
+            only = sys.argv[i + 1].split(",")
+        if a == "--jobs":
+            jobs = int(sys.argv[i + 1])
+    print(build(force="--force" in sys.argv, verbose=True, only=only, jobs=jobs))

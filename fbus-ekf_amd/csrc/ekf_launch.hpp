@@ -1,0 +1,35 @@
+// ekf_launch.hpp -- host-callable launchers of the four large kernel families.
+//
+// The library is built from several translation units so that the kernels compile in parallel (and a kernel under
+// work rebuilds in seconds): kernels_tu.hip is compiled once per (scalar type, state size, family) with
+// -DFBUS_TU_T / -DFBUS_TU_N / -DFBUS_TU_FAMILY and holds the explicit instantiations of the function templates
+// declared here (both dialects); fbus_ekf.hip (handle, C ABI, the small kernels) only sees these declarations.
+#pragma once
+#include "ekf_device.hpp"
+#include "vision_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace fbus {
+
+// K == 1: the streamed per-call kernel (`warm` = the records were last stored with the default cache policy);
+// K > 1: predict_n, K samples per launch with the record resident in registers
+template <typename T, int N, int D>
+void launch_predict_k(hipStream_t s, T* recs, int B, int K, bool warm, const T* accel, const T* gyro, const T* dt,
+                      int dt_stride, const DevConst<T>& dc);
+
+template <typename T, int N, int D>
+void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode,
+                      bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
+
+template <typename T, int N, int D>
+void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
+                    int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
+                    const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
+
+template <typename T, int N, int D>
+void launch_corners_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right,
+                      int geometry, int mode, bool joseph, T size, const unsigned char* skip, unsigned char* applied,
+                      const DevConst<T>& dc, const VisConst<T>& vc);
+
+}  // namespace fbus

@@ -10,6 +10,7 @@
 // NCH KiB region, and a rank's records are one contiguous block for the RCCL gather.
 #include "../../include/fbus_ekf.h"
 #include "ekf_kernels.hpp"
+#include "ekf_launch.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -104,6 +105,7 @@ struct fbus_ekf {
     fbus_params prm{};
     HostConst hc;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t order_ev = nullptr;    // fbus_ekf_wait_stream / fbus_ekf_signal_stream
     void* recs = nullptr;
     bool own_recs = false;
     size_t rec_bytes = 0, bytes_per_filter = 0;
@@ -223,22 +225,13 @@ void timing_end(fbus_ekf_t h, int i)
 template <typename T, int N, int D>
 int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
 {
-    const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, K == 1 ? FBUS_KERNEL_PREDICT : FBUS_KERNEL_PREDICT_N);
     // the first predict after a kernel that stored the records with the default cache policy (correct, fused frame)
     // reads them with the default policy too; the others stream them non-temporally (see predict_kernel)
     const bool warm = h->records_warm;
     h->records_warm = false;
-#define FBUS_LAUNCH_PREDICT(LD)                                                                                         \
-    hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, K, \
-                       (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h))
-    if (K == 1) {
-        if (warm) FBUS_LAUNCH_PREDICT(AUX_DEFAULT); else FBUS_LAUNCH_PREDICT(AUX_NT);
-    }
-#undef FBUS_LAUNCH_PREDICT
-    else
-        hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B, K,
-                           (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h));
+    launch_predict_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, warm, (const T*)accel, (const T*)gyro, (const T*)dt,
+                              dt_per_filter ? 1 : 0, make_dc<T>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -248,17 +241,10 @@ template <typename T, int N, int D>
 int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,
                      const uint8_t* skip)
 {
-    const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
     h->records_warm = true;
-    const bool joseph = h->prm.cov_form == FBUS_COV_JOSEPH, joint = mode == MODE_STACKED;
-#define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                            \
-    hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs,  \
-                       h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip,  \
-                       h->d_applied, make_dc<T>(h))
-    if (joseph) { if (joint) FBUS_LAUNCH_CORRECT(COV_JOSEPH, true); else FBUS_LAUNCH_CORRECT(COV_JOSEPH, false); }
-    else        { if (joint) FBUS_LAUNCH_CORRECT(COV_SIMPLE, true); else FBUS_LAUNCH_CORRECT(COV_SIMPLE, false); }
-#undef FBUS_LAUNCH_CORRECT
+    launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+                              h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -294,17 +280,11 @@ template <typename T, int N, int D>
 int launch_frame_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter, int M,
                    const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
 {
-    const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
     h->records_warm = true;
-    const bool joseph = h->prm.cov_form == FBUS_COV_JOSEPH, joint = mode == MODE_STACKED;
-#define FBUS_LAUNCH_FRAME(COV, JOINT)                                                                                  \
-    hipLaunchKernelGGL((frame_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,  \
-                       K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0, M, (const int*)ids,    \
-                       (const T*)pos, (const T*)quat, mode, (const unsigned char*)skip, h->d_applied, make_dc<T>(h))
-    if (joseph) { if (joint) FBUS_LAUNCH_FRAME(COV_JOSEPH, true); else FBUS_LAUNCH_FRAME(COV_JOSEPH, false); }
-    else        { if (joint) FBUS_LAUNCH_FRAME(COV_SIMPLE, true); else FBUS_LAUNCH_FRAME(COV_SIMPLE, false); }
-#undef FBUS_LAUNCH_FRAME
+    launch_frame_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, (const T*)accel, (const T*)gyro, (const T*)dt,
+                            dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+                            h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -437,17 +417,11 @@ template <typename T, int N, int D>
 int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, int geometry,
                              int mode, const uint8_t* skip)
 {
-    const int grid = (h->B + BLOCK - 1) / BLOCK;
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
     h->records_warm = true;
-    if (h->prm.cov_form == FBUS_COV_JOSEPH)
-        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, h->stream,
-                           (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
-                           (T)h->prm.marker_size, (const unsigned char*)skip, h->d_applied, make_dc<T>(h), make_vc<T>(h));
-    else
-        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, h->stream,
-                           (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
-                           (T)h->prm.marker_size, (const unsigned char*)skip, h->d_applied, make_dc<T>(h), make_vc<T>(h));
+    launch_corners_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry,
+                              mode, h->prm.cov_form == FBUS_COV_JOSEPH, (T)h->prm.marker_size, (const unsigned char*)skip,
+                              h->d_applied, make_dc<T>(h), make_vc<T>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -618,7 +592,7 @@ int fbus_ekf_destroy(fbus_ekf_t h)
 {
     DeviceGuard guard_(h);
     if (!h) return FBUS_OK;
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);
     for (auto& p : h->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto g : h->graphs) if (g) (void)hipGraphExecDestroy(g);
     for (int i = 0; i < 6; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
@@ -627,6 +601,7 @@ int fbus_ekf_destroy(fbus_ekf_t h)
     if (h->d_ema_carry) (void)hipFree(h->d_ema_carry);
     if (h->d_mk) (void)hipFree(h->d_mk);
     if (h->d_id2slot) (void)hipFree(h->d_id2slot);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return FBUS_OK;
@@ -637,8 +612,32 @@ int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream)
     DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = (hip_stream == FBUS_STREAM_OWN) ? h->own_stream : (hipStream_t)hip_stream;   // NULL = legacy default stream
     return FBUS_OK;
+}
+
+// cross-stream ordering without a host sync: one reusable event per handle
+static int order_streams(fbus_ekf_t h, hipStream_t first, hipStream_t then)
+{
+    if (first == then) return FBUS_OK;
+    if (!h->order_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->order_ev, first));
+    HIP_TRY(h, hipStreamWaitEvent(then, h->order_ev, 0));
+    return FBUS_OK;
+}
+
+int fbus_ekf_wait_stream(fbus_ekf_t h, void* other_stream)
+{
+    DeviceGuard guard_(h);
+    if (!h || other_stream == FBUS_STREAM_OWN) return FBUS_ERR_INVALID;
+    return order_streams(h, (hipStream_t)other_stream, h->stream);
+}
+
+int fbus_ekf_signal_stream(fbus_ekf_t h, void* other_stream)
+{
+    DeviceGuard guard_(h);
+    if (!h || other_stream == FBUS_STREAM_OWN) return FBUS_ERR_INVALID;
+    return order_streams(h, h->stream, (hipStream_t)other_stream);
 }
 
 int fbus_ekf_sync(fbus_ekf_t h)
@@ -848,7 +847,12 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
                        int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
 {
     DeviceGuard guard_(h);
-    if (!h || K < 0) return FBUS_ERR_INVALID;
+    // everything is validated before the first launch (the same checks as frame_fused_dev): a rejected call must not
+    // leave the state advanced by the K predicts
+    if (!h || K < 0 || M < 0 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (K > 0 && (!accel || !gyro || !dt)) return FBUS_ERR_INVALID;
+    if (M > 0 && (!ids || !pos || !quat)) return FBUS_ERR_INVALID;
+    if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     const size_t es = esize(h), B = (size_t)h->B;
     // one event pair around the whole run of K back-to-back predict launches: a pair per launch
     // would cost ~8 us of stream time each and read ~3 us long; duration / K is the per-launch time

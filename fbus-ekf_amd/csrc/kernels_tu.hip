@@ -1,0 +1,110 @@
+// kernels_tu.hip -- one kernel family for one (scalar type, state size), both dialects.
+// Compiled 16 times by build.py:  -DFBUS_TU_T=float|double  -DFBUS_TU_N=18|15  -DFBUS_TU_FAMILY=1..4
+//   1 predict (per-call streamed kernel, both record-load policies, and predict_n)
+//   2 correct (nearest / stacked x simple / Joseph)
+//   3 fused frame (K predicts + correct in one launch)
+//   4 correct from stereo corners
+// gfx950 only.
+#include "ekf_kernels.hpp"
+#include "ekf_launch.hpp"
+
+#ifndef FBUS_TU_T
+#error "kernels_tu.hip: define FBUS_TU_T, FBUS_TU_N and FBUS_TU_FAMILY (see build.py)"
+#endif
+
+namespace fbus {
+
+#if FBUS_TU_FAMILY == 1
+template <typename T, int N, int D>
+void launch_predict_k(hipStream_t s, T* recs, int B, int K, bool warm, const T* accel, const T* gyro, const T* dt,
+                      int dt_stride, const DevConst<T>& dc)
+{
+    const int grid = (B + BLOCK - 1) / BLOCK;
+    // the first predict after a kernel that stored the records with the default cache policy (correct, fused frame)
+    // reads them with the default policy too; the others stream them non-temporally (see predict_kernel)
+    if (K == 1) {
+        if (warm)
+            hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_DEFAULT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K,
+                               accel, gyro, dt, dt_stride, dc);
+        else
+            hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_NT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K,
+                               accel, gyro, dt, dt_stride, dc);
+    } else {
+        hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt,
+                           dt_stride, dc);
+    }
+}
+#define FBUS_INST(D)                                                                                                  \
+    template void launch_predict_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, bool, const FBUS_TU_T*, \
+                                                            const FBUS_TU_T*, const FBUS_TU_T*, int,                  \
+                                                            const DevConst<FBUS_TU_T>&);
+
+#elif FBUS_TU_FAMILY == 2
+template <typename T, int N, int D>
+void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode,
+                      bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
+{
+    const int grid = (B + BLOCK - 1) / BLOCK;
+    const bool joint = mode == MODE_STACKED;
+#define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                              \
+    hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, pos, quat, \
+                       mode, skip, applied, dc)
+    if (joseph) { if (joint) FBUS_LAUNCH_CORRECT(COV_JOSEPH, true); else FBUS_LAUNCH_CORRECT(COV_JOSEPH, false); }
+    else        { if (joint) FBUS_LAUNCH_CORRECT(COV_SIMPLE, true); else FBUS_LAUNCH_CORRECT(COV_SIMPLE, false); }
+#undef FBUS_LAUNCH_CORRECT
+}
+#define FBUS_INST(D)                                                                                                   \
+    template void launch_correct_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,             \
+                                                            const FBUS_TU_T*, const FBUS_TU_T*, int, bool,             \
+                                                            const unsigned char*, unsigned char*,                      \
+                                                            const DevConst<FBUS_TU_T>&);
+
+#elif FBUS_TU_FAMILY == 3
+template <typename T, int N, int D>
+void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
+                    int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
+                    const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
+{
+    const int grid = (B + BLOCK - 1) / BLOCK;
+    const bool joint = mode == MODE_STACKED;
+#define FBUS_LAUNCH_FRAME(COV, JOINT)                                                                                 \
+    hipLaunchKernelGGL((frame_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, \
+                       dt_stride, M, ids, pos, quat, mode, skip, applied, dc)
+    if (joseph) { if (joint) FBUS_LAUNCH_FRAME(COV_JOSEPH, true); else FBUS_LAUNCH_FRAME(COV_JOSEPH, false); }
+    else        { if (joint) FBUS_LAUNCH_FRAME(COV_SIMPLE, true); else FBUS_LAUNCH_FRAME(COV_SIMPLE, false); }
+#undef FBUS_LAUNCH_FRAME
+}
+#define FBUS_INST(D)                                                                                                  \
+    template void launch_frame_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const FBUS_TU_T*,        \
+                                                          const FBUS_TU_T*, const FBUS_TU_T*, int, int, const int*,   \
+                                                          const FBUS_TU_T*, const FBUS_TU_T*, int, bool,              \
+                                                          const unsigned char*, unsigned char*,                       \
+                                                          const DevConst<FBUS_TU_T>&);
+
+#elif FBUS_TU_FAMILY == 4
+template <typename T, int N, int D>
+void launch_corners_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right,
+                      int geometry, int mode, bool joseph, T size, const unsigned char* skip, unsigned char* applied,
+                      const DevConst<T>& dc, const VisConst<T>& vc)
+{
+    const int grid = (B + BLOCK - 1) / BLOCK;
+    if (joseph)
+        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
+                           left, right, geometry, mode, size, skip, applied, dc, vc);
+    else
+        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
+                           left, right, geometry, mode, size, skip, applied, dc, vc);
+}
+#define FBUS_INST(D)                                                                                                  \
+    template void launch_corners_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,            \
+                                                            const FBUS_TU_T*, const FBUS_TU_T*, int, int, bool,       \
+                                                            FBUS_TU_T, const unsigned char*, unsigned char*,          \
+                                                            const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&);
+#else
+#error "FBUS_TU_FAMILY must be 1..4"
+#endif
+
+FBUS_INST(DIALECT_MATLAB)
+FBUS_INST(DIALECT_CPP)
+
+}  // namespace fbus

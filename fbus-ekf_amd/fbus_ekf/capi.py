@@ -15,6 +15,7 @@ KERNEL_CORRECT_CORNERS = 5
 VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D = 0, 1, 2
 POSE_INIT, POSE_RESET = 0, 1
 MAX_MARKERS, MAX_VISIBLE = 32, 16
+STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
 
 
 class FbusError(RuntimeError):
@@ -78,6 +79,8 @@ def load_library():
         "fbus_ekf_create": ([C.POINTER(H), C.POINTER(FbusParams), C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
         "fbus_ekf_destroy": ([H], C.c_int),
         "fbus_ekf_set_stream": ([H, vp], C.c_int),
+        "fbus_ekf_wait_stream": ([H, vp], C.c_int),
+        "fbus_ekf_signal_stream": ([H, vp], C.c_int),
         "fbus_ekf_sync": ([H], C.c_int),
         "fbus_ekf_last_error": ([H], C.c_char_p),
         "fbus_status_string": ([C.c_int], C.c_char_p),

@@ -35,6 +35,10 @@ class BatchedFilter:
             self._h = C.c_void_p()
             raise capi.FbusError(rc, "fbus_ekf_create", self._lib.fbus_status_string(rc).decode())
         self._keep = []          # device arrays that must outlive asynchronous launches
+        # The handle starts on its own NON-BLOCKING stream: device arrays handed to predict/correct/frame must be
+        # complete before the call and results are complete after sync() (or order the streams with
+        # wait_stream()/signal_stream(), or share the caller's stream with set_stream()).
+        self._own_stream = True
         if stream is not None:
             self.set_stream(stream)
 
@@ -62,9 +66,23 @@ class BatchedFilter:
         self.close()
 
     def set_stream(self, stream):
-        """stream: an int/hipStream_t handle or an object with `.cuda_stream` (torch.cuda.Stream)."""
-        handle = getattr(stream, "cuda_stream", stream)
-        self._check(self._lib.fbus_ekf_set_stream(self._h, C.c_void_p(handle or None)), "set_stream")
+        """stream: an int/hipStream_t handle or an object with `.cuda_stream` (torch.cuda.Stream); the handle is passed
+        as it is -- 0 is HIP's legacy default stream (what torch.cuda.current_stream() is unless the caller switched
+        streams), so the launches are ordered with the caller's own work.  stream=None restores the handle's own stream."""
+        if stream is None:
+            handle = capi.STREAM_OWN
+        else:
+            handle = int(getattr(stream, "cuda_stream", stream))
+        self._check(self._lib.fbus_ekf_set_stream(self._h, C.c_void_p(handle)), "set_stream")
+        self._own_stream = stream is None
+
+    def wait_stream(self, stream):
+        """work submitted to this filter from now on starts after everything already queued on `stream`"""
+        self._check(self._lib.fbus_ekf_wait_stream(self._h, C.c_void_p(int(getattr(stream, "cuda_stream", stream)))), "wait_stream")
+
+    def signal_stream(self, stream):
+        """work submitted to `stream` from now on starts after everything already queued on this filter"""
+        self._check(self._lib.fbus_ekf_signal_stream(self._h, C.c_void_p(int(getattr(stream, "cuda_stream", stream)))), "signal_stream")
 
     def sync(self):
         self._check(self._lib.fbus_ekf_sync(self._h), "sync")
@@ -209,12 +227,20 @@ class BatchedFilter:
         """K per-sample predict launches followed by one correct launch (device arrays only);
         fused=True: the same frame as ONE launch with the records resident in registers."""
         B = self.B
-        K = accel.numel() // (3 * B)
-        per = 1 if (dt.numel() == K * B and B > 1) else 0
+        K = accel.numel() // (3 * B) if accel is not None else 0
         M = ids.numel() // B if ids is not None else 0
-        for a in (accel, gyro, dt, ids, pos, quat, skip):
-            if a is not None:
-                self._keep.append(a)
+        per = 0
+        if K > 0:
+            per = 1 if (dt.numel() == K * B and B > 1) else 0
+            if not per and dt.numel() < K:
+                raise ValueError("dt must have K or K*B elements")
+            self._dev_checked(accel, K * B * 3, "accel"); self._dev_checked(gyro, K * B * 3, "gyro")
+            self._dev_checked(dt, dt.numel(), "dt")
+        if M > 0:
+            self._dev_checked(ids, B * M, "ids"); self._dev_checked(pos, B * M * 3, "pos")
+            self._dev_checked(quat, B * M * 4, "quat")
+        if skip is not None:
+            self._dev_checked(skip, B, "skip")
         fn = self._lib.fbus_ekf_frame_fused_dev if fused else self._lib.fbus_ekf_frame_dev
         rc = fn(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per, M,
                                           self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
@@ -269,9 +295,14 @@ class BatchedFilter:
             quat = torch.empty((n, 4), dtype=left.dtype, device=left.device)
             c3 = torch.empty((n, 4, 3), dtype=left.dtype, device=left.device) if want_corners else None
             self._keep += [left, right, pos, quat, c3]
+            cur = torch.cuda.current_stream(left.device) if self._own_stream else None
+            if cur is not None:                     # inputs come from / outputs go to torch's stream: order both ways
+                self.wait_stream(cur)
             rc = self._lib.fbus_ekf_marker_pose_dev(self._h, n, geometry, self._p(left), self._p(right),
                                                     self._p(pos), self._p(quat), self._p(c3))
             self._check(rc, "marker_pose_dev")
+            if cur is not None:
+                self.signal_stream(cur)
             return (pos, quat, c3) if want_corners else (pos, quat)
         left = np.ascontiguousarray(left, self.np_dtype).reshape(-1, w)
         n = left.shape[0]

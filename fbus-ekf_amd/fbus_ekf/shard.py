@@ -32,6 +32,35 @@ def gather_records(local, dist=None, world=1):
     return out
 
 
+def gather_records_ragged(local, dist=None, world=1, device="cpu"):
+    """All-gather of 1-D record tensors whose lengths may differ by a tile (strong scaling with a total that is not
+    a multiple of 64 x world): padded to the longest shard for the collective, trimmed afterwards."""
+    if dist is None or world == 1:
+        return [local]
+    import torch
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    longest = max(sizes)
+    padded = local
+    if local.numel() < longest:
+        padded = torch.zeros(longest, dtype=local.dtype, device=local.device)
+        padded[:local.numel()] = local
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded)
+    return [o[:k] for o, k in zip(out, sizes)]
+
+
+def sum_over_ranks(value, dist=None, world=1, device="cpu"):
+    if dist is None or world == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def max_over_ranks(value, dist=None, world=1, device="cpu"):
     if dist is None or world == 1:
         return float(value)

@@ -92,9 +92,11 @@ def marker_table(params):
 
 
 # ---- streams ----------------------------------------------------------------------------
-def initial_state(lo, hi, p0_diag, nstate=18, seed=BASE_SEED, mixed_cov=False):
-    """nominal (n,19), rot (n,9), P (n,N,N), prev_id (n,) for filters [lo, hi)."""
+def initial_state(lo, hi, p0_diag, nstate=18, seed=BASE_SEED, mixed_cov=False, with_cov=True):
+    """nominal (n,19), rot (n,9), P (n,N,N), prev_id (n,) for filters [lo, hi).  with_cov=False returns P = None
+    (large batches: the caller lets the device write the P0 diagonal instead of shipping n x N x N doubles)."""
     N = nstate
+    mixed_cov = mixed_cov and with_cov
 
     def gen(r):
         p = r.uniform(-1, 1, (RNG_BLOCK, 3))
@@ -104,6 +106,8 @@ def initial_state(lo, hi, p0_diag, nstate=18, seed=BASE_SEED, mixed_cov=False):
         ba = r.normal(0, 0.05, (RNG_BLOCK, 3))
         bg = r.normal(0, 0.002, (RNG_BLOCK, 3))
         g = np.broadcast_to(GRAVITY, (RNG_BLOCK, 3))
+        if not mixed_cov:                              # A is drawn last: skipping it leaves p .. bg unchanged
+            return np.concatenate([p, v, q, ba, bg, g], axis=1)
         A = r.normal(0, 0.05, (RNG_BLOCK, 18, 18))
         return np.concatenate([p, v, q, ba, bg, g, A.reshape(RNG_BLOCK, -1)], axis=1)
 
@@ -112,6 +116,8 @@ def initial_state(lo, hi, p0_diag, nstate=18, seed=BASE_SEED, mixed_cov=False):
     rot = q2R(nominal[:, 6:10]).reshape(-1, 9)
     P0 = np.diag(np.repeat(np.asarray(p0_diag, float), 3)[:N])
     n = hi - lo
+    if not with_cov:
+        return nominal, rot, None, np.zeros(n, np.int32)
     if mixed_cov:   # S C S with S = sqrt(P0) and C = A A' a random correlation-like matrix (A = I + small):
         # dense, symmetric positive definite, every block at its physical scale
         A = np.eye(N) + raw[:, 19:].reshape(n, 18, 18)[:, :N, :N]

@@ -90,7 +90,10 @@ public:
         check(fbus_ekf_get_applied(h_, a.data()), "get_applied");
         return a;
     }
+    // hip_stream is the hipStream_t itself (nullptr = HIP's legacy default stream); FBUS_STREAM_OWN = the handle's own
     void set_stream(void* hip_stream) { check(fbus_ekf_set_stream(h_, hip_stream), "set_stream"); }
+    void wait_stream(void* other) { check(fbus_ekf_wait_stream(h_, other), "wait_stream"); }
+    void signal_stream(void* other) { check(fbus_ekf_signal_stream(h_, other), "signal_stream"); }
     void sync() { check(fbus_ekf_sync(h_), "sync"); }
 
 private:

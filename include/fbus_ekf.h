@@ -99,8 +99,22 @@ int fbus_params_default(fbus_params* prm, int dialect);
 int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int device, int dtype, int nstate);
 int fbus_ekf_destroy(fbus_ekf_t h);
 /* Run all work of this handle on an existing hipStream_t (e.g. the caller's
- * framework stream).  NULL restores the handle's own stream. */
+ * framework stream).  hip_stream is the hipStream_t itself: NULL (0) is HIP's
+ * legacy default stream, as everywhere in HIP -- a caller whose framework is
+ * on the default stream passes 0 and gets launches ordered with its own work.
+ * FBUS_STREAM_OWN restores the handle's own stream, which is non-blocking:
+ * it is ordered against NO other stream, so a caller that stays on it orders
+ * its device buffers itself (fbus_ekf_sync / device sync, or the two calls
+ * below). */
+#define FBUS_STREAM_OWN ((void*)(intptr_t)-1)
 int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream);
+/* Cross-stream ordering without a host sync (hipEventRecord + hipStreamWaitEvent):
+ * wait_stream   -- work submitted to the handle's stream after this call starts
+ *                  only when everything already submitted to other_stream is done
+ *                  (inputs produced on the caller's stream);
+ * signal_stream -- the reverse (outputs consumed on the caller's stream). */
+int fbus_ekf_wait_stream(fbus_ekf_t h, void* other_stream);
+int fbus_ekf_signal_stream(fbus_ekf_t h, void* other_stream);
 int fbus_ekf_sync(fbus_ekf_t h);
 const char* fbus_ekf_last_error(fbus_ekf_t h);
 const char* fbus_status_string(int status);

@@ -13,6 +13,14 @@
       seeded random single-step vectors (state in, inputs, state out) from the
       numpy twin for both dialects, N in {15, 18}, both correct() modes.
 
+  recordings.npz
+      the reference's two COMPLETE recordings (matlab/dataset/landdata/dataset-02 and
+      waterdata/dataset-06: imu.txt, image.txt; GPL-3.0, (c) the FBUS-EKF authors) -- inputs only,
+      float64, compressed -- for the full-length replay tests (the oracle runs beside
+      the device in the test; no expected outputs are stored).  fusion.txt's gyro-bias
+      columns (the only part of the recorded C++ output that survives the revision
+      change) ride along as a loose sanity band.
+
 The EKF vectors are NOT reference outputs (the reference cannot run here): they pin
 the two restatements and the HIP kernels to each other ("parity unpinned").
 """
@@ -164,7 +172,17 @@ def ekf_random():
     np.savez_compressed(os.path.join(HERE, "ekf_random.npz"), **out)
 
 
+def recordings():
+    out = {}
+    for tag, d in (("land", "landdata/dataset-02"), ("water", "waterdata/dataset-06")):
+        out[f"{tag}_imu"] = np.loadtxt(f"{REF}/{d}/imu.txt")
+        out[f"{tag}_image"] = np.loadtxt(f"{REF}/{d}/image.txt")
+        out[f"{tag}_fusion_bg"] = np.loadtxt(f"{REF}/{d}/fusion.txt")[:, [0, 14, 15, 16]]
+    np.savez_compressed(os.path.join(HERE, "recordings.npz"), **out)
+
+
 if __name__ == "__main__":
+    recordings()
     vision()
     land_slice()
     ekf_random()

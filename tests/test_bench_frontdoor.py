@@ -1,0 +1,120 @@
+"""bench.py's multi-GPU front door.
+
+CPU part: `--gpus N` on a box with fewer GPUs fails loudly (no JSON line, non-zero exit), a launcher whose
+WORLD_SIZE disagrees with --gpus is refused, and the ragged gather used by the strong-scaling mode works over gloo.
+GPU part (one GPU is enough): the N > 1 code path rehearsed with all ranks on cuda:0 and gloo for the control
+collectives (FBUS_BENCH_DEBUG_SHARED_GPU=1), weak and strong scaling, started the way the driver's `--gpus N` does.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_flag_without_enough_devices_fails_loudly():
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 8 requested" in r.stderr and "refusing" in r.stderr
+    assert "\"metric\"" not in r.stdout                      # no number is reported
+
+
+def test_world_size_must_match_gpus_flag():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=4 but --gpus 2" in r.stderr
+    r = subprocess.run([sys.executable, BENCH], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2
+
+
+def _ragged_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
+    from fbus_ekf import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard.shard_range(200, rank, world)            # 200 filters over 3 ranks: 64 / 64 / 72 (ragged)
+    local = torch.arange(lo * 800, hi * 800, dtype=torch.int64).to(torch.uint8)
+    out = shard.gather_records_ragged(local, dist, world, "cpu")
+    n = shard.sum_over_ranks(1.0, dist, world, "cpu")
+    if rank == 0:
+        q.put(([o.numpy() for o in out], n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_gather_over_gloo():
+    import socket
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
+    from fbus_ekf import shard
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, n = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert n == 3.0
+    covered = 0
+    for r in range(world):
+        lo, hi = shard.shard_range(200, r, world)
+        assert lo % 64 == 0 and out[r].size == (hi - lo) * 800
+        assert np.array_equal(out[r], (np.arange(lo * 800, hi * 800) % 256).astype(np.uint8))
+        covered += hi - lo
+    assert covered == 200
+
+
+def _run_bench(extra, env):
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-leg"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and "\"metric\"" in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_weak_and_strong_scaling():
+    """`python bench.py --gpus 2` starts two rank processes by itself (child torch.distributed.run); with
+    FBUS_BENCH_DEBUG_SHARED_GPU=1 both sit on cuda:0 and use gloo, which exercises everything but RCCL itself."""
+    env = _env(FBUS_BENCH_DEBUG_SHARED_GPU="1")
+    one = _run_bench(["--batch", "4096"], _env())
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["config"]["ranks_seen"] == 1
+    assert one["state_finite"] and one["roofline"]["frac"] > 0 and one["roofline"]["launches"] > 0
+    assert one["roofline"]["bytes_moved_per_launch"] == 1436 * 4096
+    weak = _run_bench(["--gpus", "2", "--batch", "4096"], env)
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["ranks_seen"] == 2
+    assert weak["config"]["total_filters"] == 8192 and weak["config"]["batch_per_gpu"] == 4096
+    assert weak["gathered_bytes"] == 2 * 4096 * 800 and weak["state_finite"]
+    assert weak["config"]["collective_backend"] == "gloo" and weak["cpu_baseline"] is None
+    strong = _run_bench(["--gpus", "2", "--total-batch", "8192"], env)
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["ranks_seen"] == 2
+    assert strong["config"]["total_filters"] == 8192 and strong["config"]["batch_per_gpu"] == 4096
+    assert strong["gathered_bytes"] == 8192 * 800 and strong["state_finite"]
+    # value counts the filters of ALL ranks
+    assert strong["value"] == pytest.approx(8192 * 23 * 3 / (strong["ms_per_step"] * 3e-3), rel=1e-6)

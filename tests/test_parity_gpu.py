@@ -13,7 +13,7 @@ import pytest
 import oracle_capi as oc
 from fbus_ekf import BatchedFilter, capi, replay, synth
 from replay_ref import OracleEngine
-from util import (COV_BLOCK_TOL, COV_TOL, PLAIN_TOL, STATE_TOL, WINDOW_TOL, assert_parity, cov_rel_err,
+from util import (COV_BLOCK_TOL, COV_TOL, PLAIN_TOL, PLAIN_WINDOW_TOL, STATE_TOL, WINDOW_TOL, assert_parity, cov_rel_err,
                   cov_rel_err_blockwise, parity_errors, rot_rel_err, state_rel_err, state_rel_err_literal,
                   state_rel_err_plain)
 
@@ -179,7 +179,11 @@ def test_free_running_100_frames(dialect):
             flt.correct(ids, pos, quat, mode)
             eng.correct(ids, pos, quat, mode)
             if frame % 10 == 9:
-                es, ec = _check(flt, eng, 32, f"frame {frame}", state_tol=WINDOW_TOL, plain_tol=10 * PLAIN_TOL,
+                # free running: both sides carry their own fp32 / fp64 state, so the innovation y - h(x) (|y| ~ 1 m,
+                # |y - h| ~ 1e-3 m) differs by the ~1e-7 m the fp32 position has drifted, times gains of ~10 (rad/s)/m
+                # on the weakly observed gyro bias: ~1e-6 rad/s absolute on a 2e-3 rad/s bias whose sigma is 0.1 rad/s.
+                # The plain per-block figure (relative to |x| alone) is printed and bounded at PLAIN_WINDOW_TOL.
+                es, ec = _check(flt, eng, 32, f"frame {frame}", state_tol=WINDOW_TOL, plain_tol=PLAIN_WINDOW_TOL,
                                 cov_block_tol=10 * COV_BLOCK_TOL)
                 worst = (max(worst[0], es), max(worst[1], ec))
         print(f"free-run dialect {dialect}: worst state {worst[0]:.3g} cov {worst[1]:.3g}")
