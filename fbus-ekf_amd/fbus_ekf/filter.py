@@ -255,13 +255,15 @@ class BatchedFilter:
         self._check(self._lib.fbus_ekf_init_gravity_bias(self._h, T, self._p(accel), self._p(gyro)), "init_gravity_bias")
 
     def pose_init(self, ids, pos, quat, what=capi.POSE_INIT, mask=None):
-        """InitPositionAndQuaternion.m / ResetState.m (what = POSE_INIT / POSE_RESET) from the nearest marker."""
+        """InitPositionAndQuaternion.m / ResetState.m (what = POSE_INIT / POSE_RESET) from the nearest marker;
+        returns the per-filter applied flags."""
         ids = np.ascontiguousarray(ids, np.int32).reshape(self.B, -1)
         M = ids.shape[1]
         pos = self._host(pos, (self.B, M, 3)); quat = self._host(quat, (self.B, M, 4))
         mask = None if mask is None else self._host(mask, (self.B,), np.uint8)
         rc = self._lib.fbus_ekf_pose_init(self._h, M, self._p(ids), self._p(pos), self._p(quat), what, self._p(mask))
         self._check(rc, "pose_init")
+        return self.applied()                      # 0 where nothing happened (no marker in range / in the map / masked)
 
     def vision_only_pose(self, ids, pos, quat):
         """ComputeVisionOnlyResults.m:39-79 -> (B, 7) [p3, q4]; the state is not touched."""

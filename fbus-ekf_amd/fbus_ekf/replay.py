@@ -95,6 +95,64 @@ def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
     return np.array(out), np.array(npred)
 
 
+def replay_cpp_loop(engine, imu, image, params, max_frames=None, n_init=500):
+    """The recording through the loop of FILTER::FilterThreadFunction (C++/src/filter.cpp:190-250) instead of the
+    Matlab script's: per camera frame
+
+        ResetSystemState()      filter.cpp:405-477  if the detection is more than 0.1 s past the state's time stamp the
+                                nominal pose is reset from the nearest marker (v = ba = bg = 0, covariance and the
+                                carried rotation matrix untouched, state time := detection time) -- and the frame
+                                CONTINUES: it is not skipped as in FBUS_EKF.m:168-171;
+        BatchImuProcessing()    filter.cpp:483-531  every buffered IMU sample with state time <= t <= detection time,
+                                dt = t - state time (after a reset that window is empty or a single sample);
+        ObservationUpdate()     filter.cpp:622-754  nearest marker (hysteresis in the C++ dialect).
+
+    The state's time stamp is the time of the last IMU sample used (filter.cpp:516), which is also what the trace
+    row carries (filter.cpp:241).  Gravity / gyro bias come from the first `n_init` IMU rows (the live filter averages
+    what arrived during its first second, filter.cpp:256-285), the pose from the first frame (filter.cpp:291-399).
+    Returns (states, npredict, nreset) with states[k] = [t_state, nominal(19), rot(9), P(N*N)] after frame k."""
+    imu = np.asarray(imu, float)
+    image = np.asarray(image, float)
+    N = engine.N
+    P0 = np.diag(np.repeat(np.array(list(params.p0_diag)), 3)[:N])[None]
+    engine.set_state(np.zeros((1, 19)), np.zeros((1, 9)), P0, np.zeros(1, np.int32))
+    engine.init_gravity_bias(imu[:n_init, None, 1:4], imu[:n_init, None, 4:7])
+    j = 1
+    while j < len(image) and image[j, 0] == image[0, 0]:
+        j += 1
+    meas = image[0:j, 1:9]
+    engine.pose_init(meas[:, 0].astype(np.int32)[None], meas[None, :, 1:4], meas[None, :, 4:8], 0)
+    t_state = image[0, 0]                                           # filter.cpp:375
+    idx = int(np.searchsorted(imu[:, 0], t_state, side="right"))    # samples up to the detection are consumed (:300-305,388)
+    n_img = j
+    out, npred, nreset = [], [], 0
+    while n_img < len(image) and (max_frames is None or len(out) < max_frames):
+        j = n_img + 1
+        while j < len(image) and image[j, 0] == image[n_img, 0]:
+            j += 1
+        t_det = image[n_img, 0]
+        meas = image[n_img:j, 1:9]
+        n_img = j
+        ids, pos, quat = meas[:, 0].astype(np.int32)[None], meas[None, :, 1:4], meas[None, :, 4:8]
+        if t_det - t_state > 0.1:                                   # filter.cpp:462
+            ok = engine.pose_init(ids, pos, quat, 1)
+            if ok is None or np.all(ok):                            # a marker out of range / not in the map: no reset (:432-447)
+                t_state = t_det
+                nreset += 1
+        cnt = 0
+        while idx < len(imu) and imu[idx, 0] <= t_det:              # filter.cpp:493-517
+            if imu[idx, 0] >= t_state:
+                engine.predict(imu[idx:idx + 1, 1:4], imu[idx:idx + 1, 4:7], np.array([imu[idx, 0] - t_state]))
+                t_state = imu[idx, 0]
+                cnt += 1
+            idx += 1
+        engine.correct(ids, pos, quat, 0)
+        nominal, rot, P, _ = engine.get_state()
+        out.append(np.concatenate([[t_state], nominal.ravel(), rot.ravel(), P.ravel()]).astype(np.float64))
+        npred.append(cnt)
+    return np.array(out), np.array(npred), nreset
+
+
 # ---- recording files either side of the path (SURVEY.md App. C) ---------------------------------------
 def load_recording(directory):
     """imu.txt (`t ax ay az gx gy gz`, main.cpp IMU callback) and image.txt (`t id px py pz qw qx qy qz`,

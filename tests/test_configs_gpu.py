@@ -1,0 +1,330 @@
+"""GPU suite: BASELINE.json configs 2, 3 and 5 as asserted tests, and full-length replays of the reference's recordings.
+
+  config 2   B = 4096, predict only, fp32, 2000 consecutive steps through `predict` and through `predict_n` (K = 8)
+  config 3   B = 16 384, one MeasureUpdate with 4 markers: nearest / stacked pose rows, and from stereo corner pixels
+             through the flat-port refraction model (`correct_corners`, VIS_REFRACTIVE)
+  config 5   B = 65 536, 16 marker slots per frame (12 map markers), pose rows (84) and corner rows (144 >= the
+             north star's 128), fp32 against fp64 on the device after one frame and after 1 s
+  config 1   (the plumbing config, on the device): the complete land and water recordings through both frame loops
+
+The oracle runs on strided subsets (it finishes in seconds); every filter of the batch is checked through
+size-independent properties (exact symmetry, positive definiteness, unit quaternions, finiteness).
+Bounds are stated next to each assertion; the measured figure is printed.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_capi as oc
+from fbus_ekf import BatchedFilter, capi, replay, synth
+from replay_ref import OracleEngine
+from util import (COV_BLOCK_TOL, COV_BLOCK_TOL_F64, COV_TOL, PLAIN_TOL, PLAIN_WINDOW_TOL, STATE_TOL, WINDOW_TOL,
+                  assert_parity, cov_rel_err, cov_rel_err_blockwise, parity_errors, state_rel_err, state_rel_err_literal,
+                  state_rel_err_plain)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DT = np.float64(np.float32(0.005))
+r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+
+
+def _dev():
+    import torch
+    return torch, torch.device("cuda:0")
+
+
+def _properties(state, what, psd_stride=1):
+    nom, rot, P, _ = state
+    assert np.isfinite(nom).all() and np.isfinite(P).all(), what
+    assert np.abs(np.linalg.norm(nom[:, 6:10], axis=1) - 1).max() < 1e-6, what
+    assert np.abs(P - np.swapaxes(P, 1, 2)).max() == 0, what
+    assert np.linalg.eigvalsh(P[::psd_stride].astype(np.float64)).min() > 0, what
+
+
+# ------------------------------------------------------------------------------------------- config 2
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_config2_predict_only_2000_steps(dialect):
+    torch, dev = _dev()
+    B, STEPS, K, CH = 4096, 2000, 8, 200
+    prm = capi.default_params(dialect)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18, mixed_cov=True)
+    nom, rot, P = r32(nom), r32(rot), r32(P)
+    sub = np.arange(0, B, 64)                                    # 64 filters, one per tile
+    eng = OracleEngine(len(sub), dialect, 18)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_dt1, d_dtK = f32(np.full(1, DT)), f32(np.full(K, DT))
+    with BatchedFilter(B, prm) as a, BatchedFilter(B, prm) as b:
+        a.set_state(nom, rot, P, prev)
+        b.set_state(nom, rot, P, prev)
+        for c in range(STEPS // CH):
+            acc, gyr = synth.imu_samples(0, B, c * CH, CH, nom)
+            acc, gyr = r32(acc), r32(gyr)
+            d_acc, d_gyr = f32(acc), f32(gyr)
+            for k in range(CH):
+                a.predict(d_acc[k], d_gyr[k], d_dt1)
+                eng.predict(acc[k][sub], gyr[k][sub], np.array([DT]))
+            for j in range(CH // K):
+                b.predict_n(d_acc[j * K:(j + 1) * K], d_gyr[j * K:(j + 1) * K], d_dtK)
+            a.sync(); b.sync()
+            if c == 0:                                           # 200 steps in: still the per-window bounds
+                ga = a.get_state()
+                assert_parity([x[sub] for x in ga], eng.get_state(), 32, f"config 2 dialect {dialect}, 200 steps",
+                              state_tol=WINDOW_TOL, plain_tol=PLAIN_WINDOW_TOL, cov_block_tol=10 * COV_BLOCK_TOL)
+        ga, gb = a.get_state(), b.get_state()
+    _properties(ga, "predict x 2000")
+    _properties(gb, "predict_n x 250")
+    # 10 s of pure dead reckoning: nothing pulls the fp32 state back, the position has random-walked to ~dt^2 * sum(noise).
+    # Bounds: literal <= 1e-5 (north star), sigma-aware <= 1e-4, covariance <= 1e-4 max-norm and <= 1e-4 block-wise
+    e = parity_errors([x[sub] for x in ga], eng.get_state())
+    print(f"[parity] config 2 dialect {dialect}, 2000 predict steps: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} "
+          f"({e['sigma_block']}) plain {e['plain']:.2e} ({e['plain_block']}) cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
+    assert e["literal"] <= STATE_TOL and e["sigma"] <= WINDOW_TOL and e["plain"] <= PLAIN_WINDOW_TOL
+    assert e["cov"] <= COV_TOL and e["cov_block"] <= 10 * COV_BLOCK_TOL and e["asym"] == 0
+    # predict_n (K = 8, record resident in registers) against 2000 single launches: same arithmetic, separately compiled
+    e2 = parity_errors(gb, ga)
+    print(f"[parity] config 2 dialect {dialect}, predict_n K=8 vs predict: sigma-aware {e2['sigma']:.2e} cov block-wise {e2['cov_block']:.2e}")
+    assert e2["sigma"] <= WINDOW_TOL and e2["cov_block"] <= 10 * COV_BLOCK_TOL
+    eb = parity_errors([x[sub] for x in gb], eng.get_state())
+    assert eb["literal"] <= STATE_TOL and eb["sigma"] <= WINDOW_TOL and eb["cov_block"] <= 10 * COV_BLOCK_TOL
+
+
+# ------------------------------------------------------------------------------------------- config 3
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_config3_correct_16384_filters_4_markers(dialect, mode):
+    B, M = 16384, 4
+    prm = capi.default_params(dialect)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18, mixed_cov=True)
+    nom, rot, P = r32(nom), r32(rot), r32(P)
+    ids, pos, quat = synth.marker_frame(0, B, 0, M, nom, prm)
+    rng = np.random.default_rng(31)
+    pos = r32(pos + rng.normal(0, 0.01, pos.shape)); quat = r32(quat)
+    prev = rng.choice([0, 1, 2, 16], B).astype(np.int32)
+    sub = np.arange(0, B, 61)                                    # 269 filters, every lane position
+    with BatchedFilter(B, prm) as flt:
+        flt.set_state(nom, rot, P, prev)
+        flt.correct(ids, pos, quat, mode)
+        g = flt.get_state()
+        ap = flt.applied()
+    _properties(g, f"config 3 mode {mode}", psd_stride=7)
+    eng = OracleEngine(len(sub), dialect, 18)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    ok = eng.correct(ids[sub], pos[sub], quat[sub], mode)
+    assert (ap[sub] == ok).all() and ap.all()
+    assert_parity([x[sub] for x in g], eng.get_state(), 32, f"config 3 dialect {dialect} mode {mode}")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_config3_correct_from_refracted_stereo_corners(mode):
+    """the flat-port refraction model in front of MeasureUpdate: stereo corner pixels of the water recording (perturbed)
+    -> refractive triangulation on the device -> 12 corner rows per marker.  fp64 device == fp64 oracle chain;
+    fp32 device within 10x the single-step bounds (the triangulated corners carry ~2e-6 m of fp32 rounding)."""
+    B, M, size, dialect = 16384, 4, 0.117, 1
+    prm = capi.default_params(dialect)
+    prm.marker_size = size
+    rng = np.random.default_rng(7)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18, mixed_cov=True)
+    ids, _, _ = synth.marker_frame(0, B, 0, M, nom, prm)
+    d = np.load(os.path.join(GOLD, "vision_water.npz"))["corners"]
+    base = d[rng.integers(0, len(d), B * M)]
+    left = r32(base[:, 2:10] + rng.normal(0, 0.003, (B * M, 8))).reshape(B, M, 8)
+    right = r32(base[:, 10:18] + rng.normal(0, 0.003, (B * M, 8))).reshape(B, M, 8)
+    # place every filter where its nearest marker is seen (modest innovations): poses from the fp64 device chain
+    with BatchedFilter(1, prm, dtype=64) as v:
+        vpos, vquat = v.marker_pose(left.reshape(-1, 8), right.reshape(-1, 8), capi.VIS_REFRACTIVE)
+    vpos, vquat = vpos.reshape(B, M, 3), vquat.reshape(B, M, 4)
+    near = np.linalg.norm(vpos, axis=2).argmin(axis=1)
+    R_IL, P_IL, Q_IL = synth.camera_constants(prm)
+    mids, mpos, mquat = synth.marker_table(prm)
+    slot = np.array([int(np.nonzero(mids == i)[0][0]) for i in ids[np.arange(B), near]])
+    yq = vquat[np.arange(B), near] * np.array([1.0, -1, -1, -1])
+    q = synth.qmul(synth.qmul(mquat[slot], yq), np.broadcast_to(Q_IL, (B, 4)))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    R = synth.q2R(q)
+    p = -np.einsum("nij,nj->ni", R, (R_IL.T @ vpos[np.arange(B), near].T).T) + mpos[slot] - R @ P_IL
+    nom[:, 0:3], nom[:, 6:10] = p + rng.normal(0, 0.005, (B, 3)), q
+    rot = synth.q2R(nom[:, 6:10]).reshape(B, 9)
+    nom, rot, P = r32(nom), r32(rot), r32(P)
+    sub = np.arange(0, B, 127)
+    p_or = oc.vision_params()
+    corners = np.array([oc.refraction_triangulate(p_or, l, r) for l, r in
+                        zip(left[sub].reshape(-1, 8), right[sub].reshape(-1, 8))]).reshape(len(sub), M, 4, 3)
+    eng = OracleEngine(len(sub), dialect, 18)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids[sub], corners, size, mode)
+    for dtype in (64, 32):
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            flt.set_state(nom, rot, P, prev)
+            flt.correct_corners(ids, left, right, capi.VIS_REFRACTIVE, mode)
+            g = flt.get_state()
+            ap = flt.applied()
+        assert (ap[sub] == ok).all() and ok.all()
+        _properties(g, f"config 3 corners mode {mode} fp{dtype}", psd_stride=7)
+        mult = 10.0
+        assert_parity([x[sub] for x in g], eng.get_state(), dtype, f"config 3 refractive corners, mode {mode}, fp{dtype}",
+                      state_tol=mult * STATE_TOL, plain_tol=mult * PLAIN_TOL, cov_block_tol=mult * COV_BLOCK_TOL)
+
+
+# ------------------------------------------------------------------------------------------- config 5
+def _corners3d(nom, ids, prm, size, noise, rng):
+    """the four corners of every visible marker in the left camera frame: R_IL R'(P_m + R_m c_k - p - R P_IL)"""
+    B, M = ids.shape
+    R_IL, P_IL, _ = synth.camera_constants(prm)
+    mids, mpos, mquat = synth.marker_table(prm)
+    lut = np.full(mids.max() + 1, 0); lut[mids] = np.arange(len(mids))
+    slot = lut[np.clip(ids, 0, None)]
+    Rm = synth.q2R(mquat)[slot]                                  # (B, M, 3, 3)
+    c = np.array([[0, 0, 0], [0, size, 0], [size, size, 0], [size, 0, 0.0]])
+    world = mpos[slot][:, :, None, :] + np.einsum("bmij,kj->bmki", Rm, c)
+    R0 = synth.q2R(nom[:, 6:10])
+    d = world - nom[:, None, None, 0:3] - (R0 @ P_IL)[:, None, None, :]
+    cam = np.einsum("ij,bmkj->bmki", R_IL, np.einsum("bji,bmkj->bmki", R0, d))
+    return (cam + rng.normal(0, noise, cam.shape)).reshape(B, M, 12)
+
+
+def test_config5_sixteen_slots_fp32_against_fp64():
+    """B = 65 536, 16 marker slots (12 map markers + 4 absent): stacked pose rows (84) and stacked corner rows (144),
+    fp32 kernels against the fp64 kernels on the device after ONE frame and after 1 s (30 frames, 230 EKF steps), and
+    the fp64 kernels against the oracle on a strided subset after one frame."""
+    torch, dev = _dev()
+    B, M, SLOTS, size = 65536, 12, 16, 0.28
+    PATTERN = (7, 7, 6)
+    prm = capi.default_params(0)
+    prm.marker_size = size
+    rng = np.random.default_rng(55)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18)
+    nom, rot, P = r32(nom), r32(rot), r32(P)
+    cols = [0, 1, 2, 4, 5, 7, 8, 9, 11, 12, 14, 15]               # the 12 markers spread over the 16 slots
+    sub = np.arange(0, B, 1021)
+
+    def frame_inputs(f):
+        ids, pos, quat = synth.marker_frame(0, B, f, M, nom, prm)
+        ids16 = np.full((B, SLOTS), -1, np.int32); ids16[:, cols] = ids
+        pos16 = np.zeros((B, SLOTS, 3)); pos16[:, cols] = pos
+        quat16 = np.zeros((B, SLOTS, 4)); quat16[:, :, 0] = 1; quat16[:, cols] = quat
+        c16 = np.zeros((B, SLOTS, 12)); c16[:, cols] = _corners3d(nom, ids, prm, size, 1e-3, rng)
+        return ids16, r32(pos16), r32(quat16), r32(c16)
+
+    frames = [frame_inputs(f) for f in range(3)]                 # cycled: the measurements stay consistent with x0
+    for form in ("pose", "corners"):
+        res = {}
+        for dtype, tdt in ((64, torch.float64), (32, torch.float32)):
+            cv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(tdt)
+            d_frames = [(torch.from_numpy(f[0]).to(dev), cv(f[1]), cv(f[2]), cv(f[3])) for f in frames]
+            snaps = []
+            with BatchedFilter(B, prm, dtype=dtype) as flt:
+                flt.set_state(nom, rot, P, prev)
+                step = 0
+                for f in range(30):
+                    K = PATTERN[f % 3]
+                    acc, gyr = synth.imu_samples(0, B, step, K, nom); step += K
+                    flt.predict_n(cv(r32(acc)), cv(r32(gyr)), cv(np.full(K, DT)))
+                    ids16, p16, q16, c16 = d_frames[f % 3]
+                    if form == "pose":
+                        flt.correct(ids16, p16, q16, capi.MODE_STACKED)
+                    else:
+                        flt.correct_corners(ids16, c16, None, capi.VIS_CORNERS3D, capi.MODE_STACKED)
+                    if f in (0, 29):
+                        flt.sync()
+                        snaps.append(flt.get_state())
+                        assert (flt.applied() == 1).all()
+            res[dtype] = snaps
+        # fp64 device against the oracle, one frame, subset
+        eng = OracleEngine(len(sub), 0, 18)
+        eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+        acc, gyr = synth.imu_samples(0, B, 0, PATTERN[0], nom)
+        for k in range(PATTERN[0]):
+            eng.predict(r32(acc[k][sub]), r32(gyr[k][sub]), np.array([DT]))
+        if form == "pose":
+            eng.correct(frames[0][0][sub], frames[0][1][sub], frames[0][2][sub], 1)
+        else:
+            eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, frames[0][0][sub],
+                                    frames[0][3][sub].reshape(len(sub), SLOTS, 4, 3), size, 1)
+        assert_parity([x[sub] for x in res[64][0]], eng.get_state(), 64, f"config 5 {form} rows, fp64 device vs oracle")
+        # fp32 against fp64 on the device, every filter.  Bounds: one frame = the single-step gates (the sigma-aware
+        # state figure gets 3x: 84 / 144 rows at one linearisation point); 1 s = the free-running window gates.
+        for i, name, st, pl, cb in ((0, "one frame", 3 * STATE_TOL, PLAIN_TOL, COV_BLOCK_TOL),
+                                    (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL)):
+            _properties(res[32][i], f"config 5 {form} {name}", psd_stride=97)
+            assert_parity(res[32][i], res[64][i], 32, f"config 5 {form} rows, fp32 vs fp64, {name}",
+                          state_tol=st, plain_tol=pl, cov_block_tol=cb)
+
+
+# ------------------------------------------------------------------------------------------- full recordings
+@pytest.mark.parametrize("rec", ["land", "water"])
+def test_full_recording_replay_matlab_loop(rec):
+    """FBUS_EKF.m:118-210 over the COMPLETE recording (1256 land / 1061 water frames, ~47 000 / 40 000 IMU samples), both
+    dialects: fp64 device == oracle to 1e-9 at every frame; fp32 drift over the whole ~50 s run printed and bounded."""
+    d = np.load(os.path.join(GOLD, "recordings.npz"))
+    imu, image = d[rec + "_imu"], d[rec + "_image"]
+    for dialect in (0, 1):
+        prm = capi.default_params(dialect)
+        eng = OracleEngine(1, dialect, 18)
+        ref, nref = replay.replay(eng, imu, image, prm)
+        assert len(ref) == len(np.unique(image[:, 0])) - 1
+        with BatchedFilter(1, prm, dtype=64) as flt:
+            got, n = replay.replay(flt, imu, image, prm)
+        assert (n == nref).all() and n.sum() > 0.9 * (len(imu) - 700)
+        assert np.abs(got[:, 1:20] - ref[:, 1:20]).max() < 1e-9
+        assert cov_rel_err_blockwise(got[:, 29:].reshape(-1, 18, 18), ref[:, 29:].reshape(-1, 18, 18)) < 1e-8
+        with BatchedFilter(1, prm, dtype=32) as flt:
+            g32, _ = replay.replay(flt, imu, image, prm)
+        P32, Pr = g32[:, 29:].reshape(-1, 18, 18), ref[:, 29:].reshape(-1, 18, 18)
+        lit = state_rel_err_literal(g32[:, 1:20], ref[:, 1:20])
+        sig = state_rel_err(g32[:, 1:20], ref[:, 1:20], Pr)
+        print(f"[parity] {rec} recording, Matlab loop, dialect {dialect}, {len(ref)} frames / {int(n.sum())} IMU steps, fp32 drift: "
+              f"literal {lit:.2e} sigma-aware {sig[0]:.2e} ({sig[1]}) plain {state_rel_err_plain(g32[:, 1:20], ref[:, 1:20])[0]:.2e} "
+              f"cov {cov_rel_err(P32, Pr):.2e} cov block-wise {cov_rel_err_blockwise(P32, Pr):.2e}")
+        # the full sequence drifts to ~2e-4 / 3e-4 in fp32 -- reported, bounded loosely
+        assert lit < 1e-4 and sig[0] < 3e-3 and cov_rel_err(P32, Pr) < 3e-3
+        # the loose band the recorded C++ output (an older revision) still supports: the gyro bias
+        # the run starts from (mean of the first IMU rows, refined by the first correct) within 1e-3 rad/s of fusion.txt's
+        fb = d[rec + "_fusion_bg"]
+        assert np.abs(got[0, 14:17] - fb[0, 1:4]).max() < 1e-3
+
+
+def test_cpp_frame_loop_with_resets_and_gapped_recording():
+    """FILTER::FilterThreadFunction's loop (filter.cpp:229-235): reset-then-CONTINUE after a vision gap of more than 0.1 s
+    (filter.cpp:462-474), on the land recording with three stretches of camera frames removed; and the Matlab loop's
+    reset-instead-of-update (FBUS_EKF.m:168-171, ResetState.m) on the same data."""
+    d = np.load(os.path.join(GOLD, "recordings.npz"))
+    imu, image = d["land_imu"], d["land_image"]
+    keep = np.ones(len(image), bool)
+    for t0, t1 in ((5.0, 5.3), (12.0, 13.1), (20.0, 20.13)):
+        keep &= ~((image[:, 0] > t0) & (image[:, 0] < t1))
+    image = image[keep]
+    image = image[image[:, 0] < 26.0]
+    imu = imu[imu[:, 0] < 26.2]
+    assert (np.diff(np.unique(image[:, 0])) > 0.1).sum() == 3
+    prm = capi.default_params(1)
+    eng = OracleEngine(1, 1, 18)
+    ref, nref, resets = replay.replay_cpp_loop(eng, imu, image, prm)
+    # 3 removed stretches + 2 places where the recorded IMU stream itself pauses for > 0.1 s (t = 6.0 and 15.9 s)
+    assert resets == 5 and len(ref) == len(np.unique(image[:, 0])) - 1
+    with BatchedFilter(1, prm, dtype=64) as flt:
+        got, n, r = replay.replay_cpp_loop(flt, imu, image, prm)
+    assert r == 5 and (n == nref).all()
+    assert np.abs(got[:, 0:20] - ref[:, 0:20]).max() < 1e-9 and np.abs(got[:, 20:29] - ref[:, 20:29]).max() < 1e-9
+    assert cov_rel_err_blockwise(got[:, 29:].reshape(-1, 18, 18), ref[:, 29:].reshape(-1, 18, 18)) < 1e-8
+    # the frame after a gap: the reset zeroed v, ba, bg and then the frame went on to its correct (so bg is NOT exactly 0)
+    t = ref[:, 0]
+    k = int(np.argmax(t > 5.3))
+    assert n[k] <= 1 and np.abs(ref[k, 4:7]).max() < 0.05 and np.abs(ref[k, 14:17]).max() > 0
+    with BatchedFilter(1, prm, dtype=32) as flt:
+        g32, _, r32_ = replay.replay_cpp_loop(flt, imu, image, prm)
+    assert r32_ == 5
+    lit = state_rel_err_literal(g32[:, 1:20], ref[:, 1:20])
+    print(f"[parity] C++ loop with 3 resets, {len(ref)} frames, fp32 drift: literal {lit:.2e} "
+          f"cov block-wise {cov_rel_err_blockwise(g32[:, 29:].reshape(-1, 18, 18), ref[:, 29:].reshape(-1, 18, 18)):.2e}")
+    assert lit < 1e-4
+    # Matlab loop on the same gapped recording: the reset REPLACES predict + correct for that frame
+    for dialect in (0, 1):
+        prm = capi.default_params(dialect)
+        eng = OracleEngine(1, dialect, 18)
+        ref, nref = replay.replay(eng, imu, image, prm)
+        assert (nref == 0).sum() >= 3
+        with BatchedFilter(1, prm, dtype=64) as flt:
+            got, n = replay.replay(flt, imu, image, prm)
+        assert (n == nref).all() and np.abs(got[:, 1:29] - ref[:, 1:29]).max() < 1e-9
