@@ -22,6 +22,14 @@ OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so") 
 OBJDIR = os.environ.get("FBUS_OBJDIR") or os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("FBUS_OUT") else
                                                        "obj_" + os.path.splitext(os.path.basename(OUT))[0])
 FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4}
+# Per-family scheduler choice (measured in one run, B = 65 536, tools/ab_bench.sh, gpurun_out/r02_ab2.log): the
+# max-ILP strategy of the AMDGPU machine scheduler shortens the per-call kernels, where one wave per SIMD has nothing
+# but its own independent instructions to cover dependent-issue stalls (predict 13.4 -> 13.05 us, stacked correct
+# 23.0 -> 21.6 us, headline +3.5 %), and lengthens the fused frame kernel (-2.8 %: more live registers, more
+# v_accvgpr traffic), which therefore keeps the default strategy.
+FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+                "correct": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+                "frame": [], "corners": []}
 TYPES = {"f32": "float", "f64": "double"}
 
 
@@ -39,7 +47,9 @@ def units():
         for n in (18, 15):
             for fam, code in FAMILIES.items():
                 out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
-                            [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"]))
+                            [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"] +
+                            # fp32 only: the fp64 kernels sit at the 512-register limit and spill more under max-ILP
+                            ([] if (os.environ.get("FBUS_NO_FAMILY_FLAGS") or tn != "f32") else FAMILY_FLAGS[fam])))
     return out
 
 

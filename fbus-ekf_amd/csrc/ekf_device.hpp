@@ -22,6 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace fbus {
 
 enum { DIALECT_MATLAB = 0, DIALECT_CPP = 1 };
@@ -142,6 +144,21 @@ __host__ __device__ constexpr bool is_pair(int r, int c)
 using f32x2 = float __attribute__((ext_vector_type(2)));
 template <typename T, int N> struct PackedMath { static constexpr bool on = false; };
 template <int N> struct PackedMath<float, N> { static constexpr bool on = (N % 2 == 0); };
+
+// ---- compile-time loop (the body sees its index as a constant expression) ---------
+template <int I, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+// hook called by the LAST rank-1 pass of a correct step when row I of the covariance is final (the kernels use it to
+// store the finished chunks while the pass is still running); the default does nothing
+struct NoRowHook {
+    template <int I> __device__ __forceinline__ void row_done() const {}
+};
 
 // ---- scalar helpers -------------------------------------------------------------
 __device__ __forceinline__ void fb_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
@@ -838,8 +855,8 @@ __device__ __forceinline__ void marker_info(InfoAcc<T>& acc, const T* pqr, const
 
 // One equivalent scalar measurement: row = (0,..,0, 1, l[A+1..5]) in the J columns, information d, beta.
 //   s' = 1 + d h P h' ; dx += P h' (beta - d h dx) / s' ; P -= (d / s') (P h')(P h')'
-template <typename T, int N, int A, int COV>
-__device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d, T beta)
+template <typename T, int N, int A, int COV, typename HOOK = NoRowHook>
+__device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d, T beta, const HOOK& hook = HOOK())
 {
 #define PS(i, j) P[pidx<N>((i), (j))]
     T Ph[N];
@@ -890,8 +907,8 @@ __device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d,
     }
     const T g = (beta - d * hdx) * is, dk = d * is;
     if constexpr (PackedMath<T, N>::on && COV == COV_SIMPLE) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
+        static_for<0, N>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const float ki = Ph[i] * dk;
             dx[i] += Ph[i] * g;
 #pragma unroll
@@ -905,7 +922,8 @@ __device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d,
                     if (c + 1 >= i && c + 1 < N) PS(i, c + 1) -= ki * Ph[c + 1];
                 }
             }
-        }
+            hook.template row_done<i>();
+        });
     } else if (COV == COV_JOSEPH) {
         // P - K Ph' - Ph K' + s K K' with s K_i K_j = Ph_i Ph_j d / s' (finite for d -> 0)
 #pragma unroll
@@ -919,21 +937,22 @@ __device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d,
             }
         }
     } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
+        static_for<0, N>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const T ki = Ph[i] * dk;
             dx[i] += Ph[i] * g;
 #pragma unroll
             for (int j = i; j < N; ++j) PS(i, j) -= ki * Ph[j];
-        }
+            hook.template row_done<i>();
+        });
     }
 #undef PS
 }
 
 // Lam = L D L' in place (no pivoting: Lam is positive semi-definite; a pivot that is not clearly positive relative
 // to its original diagonal carries no information and is dropped), beta = L^-1 b, then the six scalar updates.
-template <typename T, int N, int COV>
-__device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc)
+template <typename T, int N, int COV, typename HOOK = NoRowHook>
+__device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc, const HOOK& hook = HOOK())
 {
     T (&A)[21] = acc.Lam;
     T (&bt)[6] = acc.b;
@@ -962,7 +981,7 @@ __device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc)
     scalar_update_info<T, N, 2, COV>(P, dx, l[2], d[2], bt[2]);
     scalar_update_info<T, N, 3, COV>(P, dx, l[3], d[3], bt[3]);
     scalar_update_info<T, N, 4, COV>(P, dx, l[4], d[4], bt[4]);
-    scalar_update_info<T, N, 5, COV>(P, dx, l[5], d[5], bt[5]);
+    scalar_update_info<T, N, 5, COV, HOOK>(P, dx, l[5], d[5], bt[5], hook);       // rows become final one by one
 }
 
 // Corner-row measurement model (north-star extension, no reference counterpart): the four triangulated

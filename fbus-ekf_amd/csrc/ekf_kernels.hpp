@@ -48,6 +48,18 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_MEAS_NT
 #define FBUS_X_MEAS_NT 0
 #endif
+#ifndef FBUS_X_STREAM_ST
+#define FBUS_X_STREAM_ST 1      // stacked correct / fused frame: the last rank-1 pass stores each chunk when its rows are final
+#endif
+#ifndef FBUS_X_FRAME_WAVES
+#define FBUS_X_FRAME_WAVES 1    // __launch_bounds__ waves per SIMD of the fused frame kernel (2 = at most 256 registers)
+#endif
+#ifndef FBUS_X_CORRECT_WAVES
+#define FBUS_X_CORRECT_WAVES 1
+#endif
+#ifndef FBUS_X_IMU_PREFETCH
+#define FBUS_X_IMU_PREFETCH 1   // predict_n / fused frame: the IMU sample of step k + 1 is requested before step k is computed
+#endif
 template <typename T>
 __device__ __forceinline__ T ld_meas(const T* p) { return FBUS_X_MEAS_NT ? __builtin_nontemporal_load(p) : *p; }
 
@@ -86,6 +98,14 @@ __device__ __forceinline__ void store_chunks(__amdgpu_buffer_rsrc_t rs, unsigned
 #pragma unroll
         for (int k = 0; k < EPC; ++k) e[k] = src[(c - C0) * EPC + k];
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c & 3) * 1024u, (c >> 2) * 4096, AUX);
+        // HAZARD (measured on gfx950, round 2): a buffer_store_dwordx4 reads its four data registers over several
+        // cycles, and a VALU write to one of them in the very next issue slot (here: the register allocator's
+        // v_accvgpr_read into the fourth data register right behind a store in the middle of a kernel) reaches
+        // memory on lanes 12-15 of every 16 instead of the stored value.  LLVM's hazard recognizer pads this case only
+        // when soffset is NOT a register (GCNHazardRecognizer::createsVALUHazard), and ours is an SGPR.  Two wait
+        // states behind every store, fenced so that nothing written after the store can be scheduled in front of them.
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -106,6 +126,31 @@ __device__ __forceinline__ void order_fence()
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// Row hook of the last rank-1 pass (NoRowHook's counterpart): when row I of the covariance is final, every 16-byte
+// chunk whose elements all belong to rows <= I goes out -- the stores of the first 30 of the 43 covariance chunks are
+// issued while the pass is still running instead of in one burst behind it.
+template <typename T, int N, int AUX>
+struct RowStore {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned lane;
+    const T* P;
+    static constexpr int fin(int r)          // chunks [CH_NOM, fin(r)) are final once rows < r are
+    {
+        return r >= N ? Rec<T, N>::NCH : Rec<T, N>::CH_NOM + cov_final_before_row<N>(r) / Rec<T, N>::EPC;
+    }
+    template <int I>
+    __device__ __forceinline__ void row_done() const
+    {
+        constexpr int C0 = fin(I), C1 = fin(I + 1);
+        if constexpr (C1 > C0 && I + 1 < N) {            // the last group goes out with the rest of the record
+            __builtin_amdgcn_sched_barrier(0);
+            store_chunks<T, N, C0, C1, AUX>(rs, lane, P + (C0 - Rec<T, N>::CH_NOM) * Rec<T, N>::EPC);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    static constexpr int streamed_end() { return fin(N - 1); }     // chunks [CH_NOM, streamed_end()) were stored by the hook
+};
 
 // Marker map in LDS.  A measurement names its marker by ArUco id: id -> map slot -> map constants are two dependent
 // lookups.  As vector loads they queue behind the 50 KiB of record loads the wave already has in flight (vector loads
@@ -186,6 +231,19 @@ struct MarkerGroup {
     }
 };
 
+// one IMU sample of one filter (accel/gyro: [K][B][3]; dt: [K] or [K][B]), read once: non-temporal
+template <typename T>
+struct ImuSample {
+    T a[3], w[3], h;
+    __device__ __forceinline__ void load(const T* accel, const T* gyro, const T* dt, int dt_stride, int k, int B, int b)
+    {
+        const size_t o = ((size_t)k * B + b) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a[i] = ld_once(accel + o + i); w[i] = ld_once(gyro + o + i); }
+        h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
+    }
+};
+
 // ---------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------
@@ -221,12 +279,15 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     if (MULTI) {
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        ImuSample<T> cur, nxt;
+        cur.load(accel, gyro, dt, dt_stride, 0, B, b);
         for (int k = 0; k < K; ++k) {
-            const size_t o = ((size_t)k * B + b) * 3;
-            const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
-            const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
-            const T h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
-            predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
+            // the sample of step k + 1 is requested before step k is computed: its latency hides behind ~1000 VALU
+            // instructions instead of stalling the wave at the top of every iteration
+            if (FBUS_X_IMU_PREFETCH && k + 1 < K) nxt.load(accel, gyro, dt, dt_stride, k + 1, B, b);
+            if (!FBUS_X_IMU_PREFETCH && k > 0) cur.load(accel, gyro, dt, dt_stride, k, B, b);
+            predict_step<T, N, DIALECT>(nom, P, cur.a, cur.w, cur.h, dc.qd);
+            if (FBUS_X_IMU_PREFETCH) cur = nxt;
         }
         store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
         store_chunks<T, N, CN, RC::CH_VAR_END>(rs, my_lane(), P);
@@ -279,7 +340,7 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
 // and leave before the stores: an early exit in front of the loads would let the compiler sink loads into the live
 // branch, behind the covariance stream.
 template <typename T, int N, int DIALECT, int COV, bool JOINT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, FBUS_X_CORRECT_WAVES)
 correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
                const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
                unsigned char* __restrict__ applied, DevConst<T> dc)
@@ -300,6 +361,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     // the stacked path asks for the predict-invariant covariance tail behind the fold: fewer registers are tied up
     // while the rows are built, and the first scalar update only needs it for its last rows
     constexpr int C_SPLIT = JOINT ? FBUS_X_SPLIT : RC::NCH;
+    constexpr bool STREAM_ST = JOINT && FBUS_X_STREAM_ST;
     T prev_raw = T(0);
     {
         MarkerTableRegs<T> treg;
@@ -348,7 +410,11 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         }
         order_fence();
         load_chunks<T, N, C_SPLIT, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_SPLIT - RC::CH_NOM) * RC::EPC);
-        if (used > 0) joint_update<T, N, COV>(P, dx, acc);
+        // the last of the six passes stores every covariance chunk as soon as its rows are final (FBUS_X_STREAM_ST)
+        if (used > 0) {
+            if constexpr (STREAM_ST) joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_CORRECT_ST>{ rs, my_lane(), P });
+            else joint_update<T, N, COV>(P, dx, acc);
+        }
     } else {
         // nearest visible marker, start threshold 10   MeasureUpdate.m:51-60 ; filter.cpp:639-664.
         // The candidates keep their measurement with them: no reload behind the covariance stream.
@@ -408,7 +474,8 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     // the carried rotation is NOT refreshed by MeasureUpdate: chunks holding only R are left alone
     store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, my_lane(), nom);
     store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, my_lane(), nom + L::NPQR);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, my_lane(), P);
+    constexpr int C_REST = STREAM_ST ? RowStore<T, N, FBUS_X_CORRECT_ST>::streamed_end() : RC::CH_NOM;
+    store_chunks<T, N, C_REST, RC::NCH, FBUS_X_CORRECT_ST>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
     applied[b] = 1;
 }
 
@@ -417,7 +484,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
 // Same device functions, same arithmetic as K predict launches + one correct launch; the record makes
 // one HBM round trip per frame instead of one per EKF step.
 template <typename T, int N, int DIALECT, int COV, bool JOINT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, FBUS_X_FRAME_WAVES)
 frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
              const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
              const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
@@ -442,19 +509,27 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
         order_fence();
     }
     if (b >= B) return;
-    for (int k = 0; k < K; ++k) {
-        const size_t o = ((size_t)k * B + b) * 3;
-        const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
-        const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
-        const T h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
-        predict_step<T, N, DIALECT>(nom, P, a, w, h, dc.qd);
-    }
-
     int first = 0, last = (M > 0 && !(skip && skip[b])) ? M : 0;
     int new_prev = -1;
     const int* my_ids = ids + (size_t)b * M;
     const T* my_pos = pos + (size_t)b * M * 3;
     const T* my_quat = quat + (size_t)b * M * 4;
+    // stacked mode: the measurements of the first marker group are requested before the predicts run (they do not
+    // depend on them), so the fold behind the last predict starts without a round trip to memory
+    MarkerGroup<T, FBUS_MARKER_GROUP> mg0;
+    const bool pre = JOINT && FBUS_X_IMU_PREFETCH && last > 0;
+    if (pre) mg0.fetch(my_ids, my_pos, my_quat, 0, last);
+    if (K > 0) {
+        ImuSample<T> cur, nxt;
+        cur.load(accel, gyro, dt, dt_stride, 0, B, b);
+        for (int k = 0; k < K; ++k) {
+            if (FBUS_X_IMU_PREFETCH && k + 1 < K) nxt.load(accel, gyro, dt, dt_stride, k + 1, B, b);
+            if (!FBUS_X_IMU_PREFETCH && k > 0) cur.load(accel, gyro, dt, dt_stride, k, B, b);
+            predict_step<T, N, DIALECT>(nom, P, cur.a, cur.w, cur.h, dc.qd);
+            if (FBUS_X_IMU_PREFETCH) cur = nxt;
+        }
+    }
+
     if (last > 0 && mode == MODE_NEAREST) {
         const int prev_id = (DIALECT == DIALECT_CPP) ? (int)P[L::OFF_PREV - L::OFF_COV] : 0;
         int min_i = -1, prev_i = -1;
@@ -490,7 +565,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     if (joint) acc.clear();
     for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
         MarkerGroup<T, FBUS_MARKER_GROUP> mg;
-        mg.fetch(my_ids, my_pos, my_quat, i0, last);
+        if (pre && i0 == 0) mg = mg0; else mg.fetch(my_ids, my_pos, my_quat, i0, last);
         mg.resolve(tbl);
 #pragma unroll
         for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
@@ -500,14 +575,23 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
             ++used;
         }
     }
-    if constexpr (joint) { if (used > 0) joint_update<T, N, COV>(P, dx, acc); }
+    constexpr bool STREAM_ST = JOINT && FBUS_X_STREAM_ST;
+    bool streamed = false;
+    if constexpr (joint) {
+        if (used > 0) {
+            if constexpr (STREAM_ST) { joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, AUX_DEFAULT>{ rs, my_lane(), P }); streamed = true; }
+            else joint_update<T, N, COV>(P, dx, acc);
+        }
+    }
     if (used > 0) {
         inject<T, N>(nom, dx);
         if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     }
     if (M > 0) applied[b] = used > 0 ? 1 : 0;
     store_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+    constexpr int C_REST = RowStore<T, N, AUX_DEFAULT>::streamed_end();
+    if (!streamed) store_chunks<T, N, RC::CH_NOM, C_REST>(rs, my_lane(), P);
+    store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
 }
 
 // correct() from stereo corners: triangulation + 12 corner rows per marker (north-star extension).
