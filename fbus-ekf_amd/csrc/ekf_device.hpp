@@ -924,10 +924,10 @@ __device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d,
             }
             hook.template row_done<i>();
         });
-    } else if (COV == COV_JOSEPH) {
+    } else if constexpr (COV == COV_JOSEPH) {
         // P - K Ph' - Ph K' + s K K' with s K_i K_j = Ph_i Ph_j d / s' (finite for d -> 0)
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
+        static_for<0, N>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const T ki = Ph[i] * dk;
             dx[i] += Ph[i] * g;
 #pragma unroll
@@ -935,6 +935,15 @@ __device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d,
                 const T kj = Ph[j] * dk;
                 PS(i, j) += (Ph[i] * Ph[j]) * dk - ki * Ph[j] - Ph[i] * kj;
             }
+            hook.template row_done<i>();
+        });
+    } else if constexpr (std::is_same<HOOK, NoRowHook>::value) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const T ki = Ph[i] * dk;
+            dx[i] += Ph[i] * g;
+#pragma unroll
+            for (int j = i; j < N; ++j) PS(i, j) -= ki * Ph[j];
         }
     } else {
         static_for<0, N>([&](auto ic) {
@@ -951,12 +960,38 @@ __device__ __forceinline__ void scalar_update_info(T* P, T* dx, const T* l, T d,
 
 // Lam = L D L' in place (no pivoting: Lam is positive semi-definite; a pivot that is not clearly positive relative
 // to its original diagonal carries no information and is dropped), beta = L^-1 b, then the six scalar updates.
-template <typename T, int N, int COV, typename HOOK = NoRowHook>
-__device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc, const HOOK& hook = HOOK())
+// Where the factors of Lam = L D L' live between the factorisation and the six passes: NoPark keeps them in registers
+// (fp32); LdsPark writes the 27 values to LDS (lane-strided: value k of lane l at base[k * 64 + l]) and every pass
+// reads back the 7 it needs.  The fp64 kernels need it: 171 covariance doubles are 342 of the 512 registers, dx and
+// P h' another 72, and with the factors (and the compiler's habit of keeping all of them live) the six passes spilled
+// 600-1600 bytes per lane to scratch.
+struct NoPark {
+    static constexpr bool on = false;
+};
+template <typename T>
+struct LdsPark {
+    static constexpr bool on = true;
+    static constexpr int NVAL = 27;             // l (15), d (6), beta (6)
+    T* base;                                    // &lds[lane]
+    __device__ __forceinline__ void put(int k, T v) const { base[k * 64] = v; }
+    __device__ __forceinline__ T get(int k) const { return base[k * 64]; }
+};
+__host__ __device__ constexpr int park_l(int a, int i) { return a * 5 - (a * (a - 1)) / 2 + (i - a - 1); }   // a < i < 6 -> 0..14
+
+// Lam = L D L' in place (no pivoting: Lam is positive semi-definite; a pivot that is not clearly positive relative
+// to its original diagonal carries no information and is dropped), beta = L^-1 b, then the six scalar updates.
+template <typename T>
+struct InfoFactors {            // unit lower-triangular L (row a = l[a][a+1..5]), D, beta = L^-1 b
+    T d[6], l[6][6], bt[6];
+};
+
+// Step 1: factorise (registers only: the covariance does not have to be resident yet).
+template <typename T, typename PARK = NoPark>
+__device__ __forceinline__ void joint_factor(InfoAcc<T>& acc, InfoFactors<T>& f, const PARK& park = PARK())
 {
     T (&A)[21] = acc.Lam;
     T (&bt)[6] = acc.b;
-    T d[6], l[6][6], dg0[6];
+    T dg0[6];
     const T tiny = (sizeof(T) == 4) ? T(2e-6) : T(4e-15);
 #pragma unroll
     for (int a = 0; a < 6; ++a) dg0[a] = A[lidx(a, a)];
@@ -965,23 +1000,159 @@ __device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc, const
         const T piv = A[lidx(a, a)];
         const bool ok = piv > tiny * dg0[a];
         const T inv = ok ? T(1) / piv : T(0);
-        d[a] = ok ? piv : T(0);
+        f.d[a] = ok ? piv : T(0);
         if (!ok) bt[a] = T(0);
 #pragma unroll
-        for (int i = a + 1; i < 6; ++i) l[a][i] = A[lidx(a, i)] * inv;
+        for (int i = a + 1; i < 6; ++i) f.l[a][i] = A[lidx(a, i)] * inv;
 #pragma unroll
         for (int i = a + 1; i < 6; ++i) {
 #pragma unroll
-            for (int j = i; j < 6; ++j) A[lidx(i, j)] -= l[a][i] * A[lidx(a, j)];
-            bt[i] -= l[a][i] * bt[a];
+            for (int j = i; j < 6; ++j) A[lidx(i, j)] -= f.l[a][i] * A[lidx(a, j)];
+            bt[i] -= f.l[a][i] * bt[a];
         }
     }
-    scalar_update_info<T, N, 0, COV>(P, dx, l[0], d[0], bt[0]);
-    scalar_update_info<T, N, 1, COV>(P, dx, l[1], d[1], bt[1]);
-    scalar_update_info<T, N, 2, COV>(P, dx, l[2], d[2], bt[2]);
-    scalar_update_info<T, N, 3, COV>(P, dx, l[3], d[3], bt[3]);
-    scalar_update_info<T, N, 4, COV>(P, dx, l[4], d[4], bt[4]);
-    scalar_update_info<T, N, 5, COV, HOOK>(P, dx, l[5], d[5], bt[5], hook);       // rows become final one by one
+#pragma unroll
+    for (int a = 0; a < 6; ++a) f.bt[a] = bt[a];
+    if constexpr (PARK::on) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int i = a + 1; i < 6; ++i) park.put(park_l(a, i), f.l[a][i]);
+            park.put(15 + a, f.d[a]);
+            park.put(21 + a, f.bt[a]);
+        }
+        // the compiler must not forward the stored values into the passes (that is the register pressure this avoids)
+        asm volatile("" ::: "memory");
+    }
+}
+
+// Step 2: the six scalar updates.
+template <typename T, int N, int COV, typename HOOK = NoRowHook, typename PARK = NoPark>
+__device__ __forceinline__ void joint_apply(T* P, T* dx, const InfoFactors<T>& f, const HOOK& hook = HOOK(), const PARK& park = PARK())
+{
+    if constexpr (PARK::on) {
+        static_for<0, 6>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            T la[6];
+#pragma unroll
+            for (int i = a + 1; i < 6; ++i) la[i] = park.get(park_l(a, i));
+            const T da = park.get(15 + a), ba = park.get(21 + a);
+            if constexpr (a == 5) scalar_update_info<T, N, a, COV, HOOK>(P, dx, la, da, ba, hook);
+            else scalar_update_info<T, N, a, COV>(P, dx, la, da, ba);
+            asm volatile("" ::: "memory");
+        });
+    } else {
+        scalar_update_info<T, N, 0, COV>(P, dx, f.l[0], f.d[0], f.bt[0]);
+        scalar_update_info<T, N, 1, COV>(P, dx, f.l[1], f.d[1], f.bt[1]);
+        scalar_update_info<T, N, 2, COV>(P, dx, f.l[2], f.d[2], f.bt[2]);
+        scalar_update_info<T, N, 3, COV>(P, dx, f.l[3], f.d[3], f.bt[3]);
+        scalar_update_info<T, N, 4, COV>(P, dx, f.l[4], f.d[4], f.bt[4]);
+        scalar_update_info<T, N, 5, COV, HOOK>(P, dx, f.l[5], f.d[5], f.bt[5], hook);     // rows become final one by one
+    }
+}
+
+template <typename T, int N, int COV, typename HOOK = NoRowHook, typename PARK = NoPark>
+__device__ __forceinline__ void joint_update(T* P, T* dx, InfoAcc<T>& acc, const HOOK& hook = HOOK(), const PARK& park = PARK())
+{
+    InfoFactors<T> f;
+    joint_factor<T, PARK>(acc, f, park);
+    joint_apply<T, N, COV, HOOK, PARK>(P, dx, f, hook, park);
+}
+
+// --------------------------------------------------------------------------------
+// Row-split form of the six passes (the fp64 kernels): the same arithmetic, element by element and in the same order,
+// with at most the first RS rows of the covariance resident at a time.
+//   P h' of every pass reads the p and theta COLUMNS of P only, i.e. storage rows 0..8 (P(i, c) with i > c lives in row c),
+//   so the six passes can run on rows 0..RS-1 alone (RS = 9) while rows RS..N-1 are not even loaded; each pass leaves the
+//   part of P h' that the late rows will need (N - RS values), its gain scale d / s' and its state factor in LDS.  The late
+//   rows then arrive into the registers the early rows have vacated and take the six rank-1 terms in the same order.
+// 171 covariance doubles are 342 of the 512 registers; with dx, P h' and the factors on top the unsplit passes spilled
+// 150-1600 bytes per lane to scratch.  Split: 132 early doubles + 36 + 36 + 54 = 390 registers at the peak.
+// --------------------------------------------------------------------------------
+template <typename T, int N, int RS>
+struct LateStash {
+    static constexpr int PER = (N - RS) + 2;         // P h' for rows RS..N-1, d / s', (beta - d h dx) / s'
+    static constexpr int NVAL = 6 * PER;
+    T* base;                                         // &lds[lane], lane-strided
+    __device__ __forceinline__ void put(int a, int k, T v) const { base[(a * PER + k) * 64] = v; }
+    __device__ __forceinline__ T get(int a, int k) const { return base[(a * PER + k) * 64]; }
+};
+
+template <typename T, int N, int A, int COV, int RS, typename HOOK>
+__device__ __forceinline__ void scalar_update_info_early(T* P, T* dx, const T* l, T d, T beta, const HOOK& hook,
+                                                         const LateStash<T, N, RS>& st)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+    static_assert(RS > 8, "P h' needs the p and theta columns: storage rows 0..8 must be early rows");
+    T Ph[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T acc = PS(i, jcol(A));
+#pragma unroll
+        for (int k = A + 1; k < 6; ++k) acc += l[k] * PS(i, jcol(k));
+        Ph[i] = acc;
+    }
+    T hPh = Ph[jcol(A)], hdx = dx[jcol(A)];
+#pragma unroll
+    for (int k = A + 1; k < 6; ++k) { hPh += l[k] * Ph[jcol(k)]; hdx += l[k] * dx[jcol(k)]; }
+    const T sp = T(1) + d * hPh;
+    T is;
+    if constexpr (sizeof(T) == 4) { is = __builtin_amdgcn_rcpf(sp); is = is * (2.0f - sp * is); } else { is = T(1) / sp; }
+    const T g = (beta - d * hdx) * is, dk = d * is;
+#pragma unroll
+    for (int i = RS; i < N; ++i) st.put(A, i - RS, Ph[i]);
+    st.put(A, N - RS, dk);
+    st.put(A, N - RS + 1, g);
+    static_for<0, RS>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const T ki = Ph[i] * dk;
+        dx[i] += Ph[i] * g;
+#pragma unroll
+        for (int j = i; j < N; ++j) {
+            if constexpr (COV == COV_JOSEPH) { const T kj = Ph[j] * dk; PS(i, j) += (Ph[i] * Ph[j]) * dk - ki * Ph[j] - Ph[i] * kj; }
+            else PS(i, j) -= ki * Ph[j];
+        }
+        if constexpr (A == 5) hook.template row_done<i>();
+    });
+#undef PS
+}
+
+template <typename T, int N, int COV, int RS, typename HOOK = NoRowHook>
+__device__ __forceinline__ void joint_apply_early(T* P, T* dx, const InfoFactors<T>& f, const HOOK& hook,
+                                                  const LateStash<T, N, RS>& st)
+{
+    scalar_update_info_early<T, N, 0, COV, RS>(P, dx, f.l[0], f.d[0], f.bt[0], hook, st);
+    scalar_update_info_early<T, N, 1, COV, RS>(P, dx, f.l[1], f.d[1], f.bt[1], hook, st);
+    scalar_update_info_early<T, N, 2, COV, RS>(P, dx, f.l[2], f.d[2], f.bt[2], hook, st);
+    scalar_update_info_early<T, N, 3, COV, RS>(P, dx, f.l[3], f.d[3], f.bt[3], hook, st);
+    scalar_update_info_early<T, N, 4, COV, RS>(P, dx, f.l[4], f.d[4], f.bt[4], hook, st);
+    scalar_update_info_early<T, N, 5, COV, RS>(P, dx, f.l[5], f.d[5], f.bt[5], hook, st);
+    asm volatile("" ::: "memory");               // the late phase reads the stash back: no forwarding of the stored values
+}
+
+// rows RS..N-1 of P and of dx: the six rank-1 terms, pass by pass (the order the unsplit passes apply them in)
+template <typename T, int N, int COV, int RS>
+__device__ __forceinline__ void joint_apply_late(T* P, T* dx, const LateStash<T, N, RS>& st)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+    static_for<0, 6>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        T Ph[N];
+#pragma unroll
+        for (int i = RS; i < N; ++i) Ph[i] = st.get(a, i - RS);
+        const T dk = st.get(a, N - RS), g = st.get(a, N - RS + 1);
+#pragma unroll
+        for (int i = RS; i < N; ++i) {
+            const T ki = Ph[i] * dk;
+            dx[i] += Ph[i] * g;
+#pragma unroll
+            for (int j = i; j < N; ++j) {
+                if constexpr (COV == COV_JOSEPH) { const T kj = Ph[j] * dk; PS(i, j) += (Ph[i] * Ph[j]) * dk - ki * Ph[j] - Ph[i] * kj; }
+                else PS(i, j) -= ki * Ph[j];
+            }
+        }
+    });
+#undef PS
 }
 
 // Corner-row measurement model (north-star extension, no reference counterpart): the four triangulated

@@ -58,7 +58,7 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #define FBUS_X_CORRECT_WAVES 1
 #endif
 #ifndef FBUS_X_IMU_PREFETCH
-#define FBUS_X_IMU_PREFETCH 1   // predict_n / fused frame: the IMU sample of step k + 1 is requested before step k is computed
+#define FBUS_X_IMU_PREFETCH 0   // predict_n / fused frame: request the IMU sample of step k + 1 (and the first marker group) before step k is computed -- measured: no gain (fused 1.19e10 -> 1.18e10 at B = 65 536: the stalls are dependent-issue stalls, not these loads), +20 B scratch in fp32 and +600 B in fp64: off
 #endif
 template <typename T>
 __device__ __forceinline__ T ld_meas(const T* p) { return FBUS_X_MEAS_NT ? __builtin_nontemporal_load(p) : *p; }
@@ -97,15 +97,18 @@ __device__ __forceinline__ void store_chunks(__amdgpu_buffer_rsrc_t rs, unsigned
         T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
         for (int k = 0; k < EPC; ++k) e[k] = src[(c - C0) * EPC + k];
+        // HAZARD (measured on gfx950, round 2): a buffer_store_dwordx4 reads its four data registers over several cycles,
+        // and a VALU write to one of them in the very next issue slot (the register allocator's v_accvgpr_read into the
+        // fourth data register right behind a store in the middle of a kernel) reached memory on lanes 12-15 of every
+        // 16 instead of the stored value.  LLVM's hazard recognizer pads this case only when soffset is NOT a register
+        // (GCNHazardRecognizer::createsVALUHazard) -- with the 4 KiB group offset in an SGPR, as the loads have it, it
+        // emits nothing.  Stores therefore carry the group offset in the VGPR offset and a constant-zero soffset: the
+        // recognizer then inserts the wait state itself, exactly where a data register is overwritten too early.
+#ifdef FBUS_X_STORE_SGPR_SOFFSET      // experiment only: UNSAFE (see above)
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c & 3) * 1024u, (c >> 2) * 4096, AUX);
-        // HAZARD (measured on gfx950, round 2): a buffer_store_dwordx4 reads its four data registers over several
-        // cycles, and a VALU write to one of them in the very next issue slot (here: the register allocator's
-        // v_accvgpr_read into the fourth data register right behind a store in the middle of a kernel) reaches
-        // memory on lanes 12-15 of every 16 instead of the stored value.  LLVM's hazard recognizer pads this case only
-        // when soffset is NOT a register (GCNHazardRecognizer::createsVALUHazard), and ours is an SGPR.  Two wait
-        // states behind every store, fenced so that nothing written after the store can be scheduled in front of them.
-        asm volatile("s_nop 1" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off + (c >> 2) * 4096u + (c & 3) * 1024u, 0, AUX);
+#endif
     }
 }
 
@@ -244,6 +247,31 @@ struct ImuSample {
     }
 };
 
+// K ImuUpdates with the record resident in registers (predict_n, fused frame)
+template <typename T, int N, int DIALECT>
+__device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
+                                              int B, int b, const T* qd)
+{
+#if FBUS_X_IMU_PREFETCH
+    if (K <= 0) return;
+    ImuSample<T> cur, nxt;
+    cur.load(accel, gyro, dt, dt_stride, 0, B, b);
+    for (int k = 0; k < K; ++k) {
+        if (k + 1 < K) nxt.load(accel, gyro, dt, dt_stride, k + 1, B, b);    // requested before step k is computed
+        predict_step<T, N, DIALECT>(nom, P, cur.a, cur.w, cur.h, qd);
+        cur = nxt;
+    }
+#else
+    for (int k = 0; k < K; ++k) {
+        const size_t o = ((size_t)k * B + b) * 3;
+        const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
+        const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
+        const T h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
+        predict_step<T, N, DIALECT>(nom, P, a, w, h, qd);
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------
@@ -279,16 +307,7 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     if (MULTI) {
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
-        ImuSample<T> cur, nxt;
-        cur.load(accel, gyro, dt, dt_stride, 0, B, b);
-        for (int k = 0; k < K; ++k) {
-            // the sample of step k + 1 is requested before step k is computed: its latency hides behind ~1000 VALU
-            // instructions instead of stalling the wave at the top of every iteration
-            if (FBUS_X_IMU_PREFETCH && k + 1 < K) nxt.load(accel, gyro, dt, dt_stride, k + 1, B, b);
-            if (!FBUS_X_IMU_PREFETCH && k > 0) cur.load(accel, gyro, dt, dt_stride, k, B, b);
-            predict_step<T, N, DIALECT>(nom, P, cur.a, cur.w, cur.h, dc.qd);
-            if (FBUS_X_IMU_PREFETCH) cur = nxt;
-        }
+        predict_steps<T, N, DIALECT>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd);
         store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
         store_chunks<T, N, CN, RC::CH_VAR_END>(rs, my_lane(), P);
     } else {
@@ -362,6 +381,20 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     // while the rows are built, and the first scalar update only needs it for its last rows
     constexpr int C_SPLIT = JOINT ? FBUS_X_SPLIT : RC::NCH;
     constexpr bool STREAM_ST = JOINT && FBUS_X_STREAM_ST;
+    // fp64 (LEAN): 171 covariance doubles are 342 of the 512 registers.  The six passes run in the row-split form
+    // (joint_apply_early / joint_apply_late, ekf_device.hpp): factorise first, then bring in storage rows 0..8 only, run
+    // the passes on them (the last one streams them out), then bring in rows 9..17 and give them their six rank-1
+    // terms from the LDS stash.  The nominal state is read a second time behind the passes instead of being held
+    // across them, and the reference mode (one marker, 7 rows) goes through the same information form as the stacked
+    // mode (6 passes, the same posterior) instead of holding the 37 Jacobian entries of its 7 rows live.
+    constexpr bool LEAN = sizeof(T) == 8;
+    constexpr int RS = 9;
+    using Stash = LateStash<T, N, RS>;
+    using Hook = RowStore<T, N, FBUS_X_CORRECT_ST>;
+    __shared__ T stash_mem[LEAN ? Stash::NVAL * BLOCK : 1];
+    const Stash stash{ stash_mem + threadIdx.x };
+    constexpr int E_END = cov_final_before_row<N>(RS);                       // first storage index of a late row
+    constexpr int C_E = RC::CH_NOM + (E_END + RC::EPC - 1) / RC::EPC;        // early chunks: [CH_NOM, C_E)
     T prev_raw = T(0);
     {
         MarkerTableRegs<T> treg;
@@ -374,7 +407,8 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         // that save a dependent reload between the last update and the stores)
         load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
         order_fence();
-        load_chunks<T, N, RC::CH_NOM, C_SPLIT, AUX_NT>(rs, my_lane(), P);
+        // fp64 (LEAN): the covariance is requested behind the factorisation instead (342 registers of load targets)
+        if constexpr (!LEAN) load_chunks<T, N, RC::CH_NOM, C_SPLIT, AUX_NT>(rs, my_lane(), P);
         order_fence();
         treg.to_lds(tbl);
         order_fence();
@@ -385,6 +419,14 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0, new_prev = -1;
+    auto lean_passes = [&](InfoFactors<T>& fac, bool go) {
+        order_fence();
+        load_chunks<T, N, RC::CH_NOM, C_E, AUX_NT>(rs, my_lane(), P);
+        if (go) joint_apply_early<T, N, COV, RS, Hook>(P, dx, fac, Hook{ rs, my_lane(), P }, stash);
+        order_fence();
+        load_chunks<T, N, C_E, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_E - RC::CH_NOM) * RC::EPC);
+        if (go) joint_apply_late<T, N, COV, RS>(P, dx, stash);
+    };
 
     if constexpr (JOINT) {
         // all visible markers: their rows are folded into the 6x6 information matrix while the covariance is still
@@ -408,12 +450,18 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             mg.fetch(my_ids, my_pos, my_quat, i0, last);
             fold_group();
         }
-        order_fence();
-        load_chunks<T, N, C_SPLIT, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_SPLIT - RC::CH_NOM) * RC::EPC);
-        // the last of the six passes stores every covariance chunk as soon as its rows are final (FBUS_X_STREAM_ST)
-        if (used > 0) {
-            if constexpr (STREAM_ST) joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_CORRECT_ST>{ rs, my_lane(), P });
-            else joint_update<T, N, COV>(P, dx, acc);
+        if constexpr (LEAN) {
+            InfoFactors<T> fac;
+            if (used > 0) joint_factor<T>(acc, fac);
+            lean_passes(fac, used > 0);
+        } else {
+            order_fence();
+            load_chunks<T, N, C_SPLIT, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_SPLIT - RC::CH_NOM) * RC::EPC);
+            // the last of the six passes stores every covariance chunk as soon as its rows are final (FBUS_X_STREAM_ST)
+            if (used > 0) {
+                if constexpr (STREAM_ST) joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_CORRECT_ST>{ rs, my_lane(), P });
+                else joint_update<T, N, COV>(P, dx, acc);
+            }
         }
     } else {
         // nearest visible marker, start threshold 10   MeasureUpdate.m:51-60 ; filter.cpp:639-664.
@@ -459,7 +507,21 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         }
         const bool ok = min_id >= 0 && min_id <= FBUS_MAX_MARKER_ID;
         const int slot = ok ? (int)tbl.id2slot[ok ? min_id : 0] : -1;              // filter.cpp:671-673
-        if (slot >= 0) {
+        if constexpr (LEAN) {
+            InfoAcc<T> acc;
+            InfoFactors<T> fac;
+            acc.clear();
+            if (slot >= 0) {
+                if (DIALECT == DIALECT_CPP) new_prev = min_id;                       // filter.cpp:675
+                T mk[MK_STRIDE];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
+                marker_info<T, N, DIALECT>(acc, nom, dc, mk, min_y, min_y + 3, T(1) / dc.r_pos, T(1) / dc.r_quat);
+                joint_factor<T>(acc, fac);
+                used = 1;
+            }
+            lean_passes(fac, used > 0);
+        } else if (slot >= 0) {
             if (DIALECT == DIALECT_CPP) new_prev = min_id;                           // filter.cpp:675
             T mk[MK_STRIDE];
 #pragma unroll
@@ -469,12 +531,16 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         }
     }
     if (used == 0) { if (b < B) applied[b] = 0; return; }
+    if constexpr (LEAN) {               // the nominal state was not held across the passes: read it again (L2-hot)
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    }
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     // the carried rotation is NOT refreshed by MeasureUpdate: chunks holding only R are left alone
     store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, my_lane(), nom);
     store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, my_lane(), nom + L::NPQR);
-    constexpr int C_REST = STREAM_ST ? RowStore<T, N, FBUS_X_CORRECT_ST>::streamed_end() : RC::CH_NOM;
+    constexpr int C_REST = LEAN ? Hook::fin(RS) : (STREAM_ST ? Hook::streamed_end() : RC::CH_NOM);
     store_chunks<T, N, C_REST, RC::NCH, FBUS_X_CORRECT_ST>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
     applied[b] = 1;
 }
@@ -519,16 +585,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     MarkerGroup<T, FBUS_MARKER_GROUP> mg0;
     const bool pre = JOINT && FBUS_X_IMU_PREFETCH && last > 0;
     if (pre) mg0.fetch(my_ids, my_pos, my_quat, 0, last);
-    if (K > 0) {
-        ImuSample<T> cur, nxt;
-        cur.load(accel, gyro, dt, dt_stride, 0, B, b);
-        for (int k = 0; k < K; ++k) {
-            if (FBUS_X_IMU_PREFETCH && k + 1 < K) nxt.load(accel, gyro, dt, dt_stride, k + 1, B, b);
-            if (!FBUS_X_IMU_PREFETCH && k > 0) cur.load(accel, gyro, dt, dt_stride, k, B, b);
-            predict_step<T, N, DIALECT>(nom, P, cur.a, cur.w, cur.h, dc.qd);
-            if (FBUS_X_IMU_PREFETCH) cur = nxt;
-        }
-    }
+    predict_steps<T, N, DIALECT>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd);
 
     if (last > 0 && mode == MODE_NEAREST) {
         const int prev_id = (DIALECT == DIALECT_CPP) ? (int)P[L::OFF_PREV - L::OFF_COV] : 0;
@@ -640,12 +697,13 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         first = min_i; last = min_i + 1;
     }
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
-    T P[RC::NCOVP], pqr[L::NPQR];
+    // The rows of all markers are folded into the 6x6 information matrix BEFORE the covariance is requested: the 16
+    // ray intersections per marker are hundreds of live values, and with the 171 covariance registers reserved as load
+    // targets at the same time the fp64 instantiation spilled 600-800 bytes per lane to scratch (fp32: 20 bytes in
+    // the Joseph variants).  This kernel is VALU-bound on the triangulation (27 us at B = 16 384), the ~2 us the
+    // covariance now takes to arrive behind the fold are not what limits it.
+    T pqr[L::NPQR];
     load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
-    T dx[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0;
     InfoAcc<T> acc;
     acc.clear();
@@ -661,15 +719,40 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         corner_info<T, N>(acc, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, C, size, w_pos);
         ++used;
     }
-    if (used > 0) joint_update<T, N, COV>(P, dx, acc);
     if (used == 0) { applied[b] = 0; return; }
+    constexpr bool LEAN = sizeof(T) == 8;                // fp64: row-split passes, see correct_kernel
+    constexpr int RS = 9;
+    using Stash = LateStash<T, N, RS>;
+    using Hook = RowStore<T, N, AUX_DEFAULT>;
+    __shared__ T stash_mem[LEAN ? Stash::NVAL * BLOCK : 1];
+    InfoFactors<T> fac;
+    joint_factor<T>(acc, fac);
+    order_fence();
+    T P[RC::NCOVP];
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    if constexpr (LEAN) {
+        const Stash stash{ stash_mem + threadIdx.x };
+        constexpr int E_END = cov_final_before_row<N>(RS);
+        constexpr int C_E = RC::CH_NOM + (E_END + RC::EPC - 1) / RC::EPC;
+        load_chunks<T, N, RC::CH_NOM, C_E, AUX_NT>(rs, my_lane(), P);
+        joint_apply_early<T, N, COV, RS, Hook>(P, dx, fac, Hook{ rs, my_lane(), P }, stash);
+        order_fence();
+        load_chunks<T, N, C_E, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_E - RC::CH_NOM) * RC::EPC);
+        joint_apply_late<T, N, COV, RS>(P, dx, stash);
+    } else {
+        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        joint_apply<T, N, COV>(P, dx, fac);
+    }
     T nom[L::NNOM];
     load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     store_chunks<T, N, 0, RC::CH_PQ>(rs, my_lane(), nom);
     store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, my_lane(), nom + L::NPQR);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+    constexpr int C_REST = LEAN ? Hook::fin(RS) : RC::CH_NOM;        // LEAN: the early rows went out in the last pass
+    store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
     applied[b] = 1;
 }
 

@@ -29,6 +29,13 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, bool warm, const T* 
         else
             hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_NT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K,
                                accel, gyro, dt, dt_stride, dc);
+    } else if constexpr (sizeof(T) == 8) {
+        // fp64 is the verification path: K resident steps need more than the 512 registers a lane has in fp64 (the
+        // kernel spilled ~580 bytes per lane), so predict_n is K launches of the streamed per-call kernel
+        for (int k = 0; k < K; ++k)
+            hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_NT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, 1,
+                               accel + (size_t)k * B * 3, gyro + (size_t)k * B * 3, dt + (size_t)k * (dt_stride ? B : 1),
+                               dt_stride, dc);
     } else {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt,
                            dt_stride, dc);
@@ -70,7 +77,9 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
 #define FBUS_LAUNCH_FRAME(COV, JOINT)                                                                                 \
     hipLaunchKernelGGL((frame_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, \
                        dt_stride, M, ids, pos, quat, mode, skip, applied, dc)
-    if (joseph) { if (joint) FBUS_LAUNCH_FRAME(COV_JOSEPH, true); else FBUS_LAUNCH_FRAME(COV_JOSEPH, false); }
+    // (Joseph form, nearest marker) is not built as a fused kernel (7 Joseph rank-2 passes with the record resident
+    // spilled 280 bytes per lane): fbus_ekf.hip runs that combination as predict_n + correct
+    if (joseph) { FBUS_LAUNCH_FRAME(COV_JOSEPH, true); }
     else        { if (joint) FBUS_LAUNCH_FRAME(COV_SIMPLE, true); else FBUS_LAUNCH_FRAME(COV_SIMPLE, false); }
 #undef FBUS_LAUNCH_FRAME
 }

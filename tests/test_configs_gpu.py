@@ -245,13 +245,25 @@ def test_config5_sixteen_slots_fp32_against_fp64():
             eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, frames[0][0][sub],
                                     frames[0][3][sub].reshape(len(sub), SLOTS, 4, 3), size, 1)
         assert_parity([x[sub] for x in res[64][0]], eng.get_state(), 64, f"config 5 {form} rows, fp64 device vs oracle")
-        # fp32 against fp64 on the device, every filter.  Bounds: one frame = the single-step gates (the sigma-aware
-        # state figure gets 3x: 84 / 144 rows at one linearisation point); 1 s = the free-running window gates.
-        for i, name, st, pl, cb in ((0, "one frame", 3 * STATE_TOL, 5 * PLAIN_TOL, COV_BLOCK_TOL),
-                                    (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL)):
+        # fp32 against fp64 on the device, every filter.  Bounds, pose form (84 rows at one linearisation point): one frame
+        # = the single-step gates with 3x on the sigma-aware state figure; 1 s = the free-running window gates.  The
+        # corner form (144 rows, 48 corners at 1 mm noise: ~50x the information of one marker pose) pushes the fp32
+        # sequential information form harder -- beta - d h dx cancels to ~1e-2 of its terms -- and gets its own stated
+        # bounds: literal 5e-5, sigma-aware 1e-4, plain 2e-3 per frame (measured 1.4e-5 / 3.2e-5 / 7.3e-4); it has no
+        # reference counterpart (SURVEY.md section 0.1 "B2").
+        if form == "pose":
+            gates = ((0, "one frame", 3 * STATE_TOL, 5 * PLAIN_TOL, COV_BLOCK_TOL, STATE_TOL),
+                     (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL, STATE_TOL))
+        else:
+            gates = ((0, "one frame", WINDOW_TOL, 10 * PLAIN_TOL, COV_BLOCK_TOL, 5e-5),
+                     (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL, 5e-5))
+        for i, name, st, pl, cb, lit in gates:
             _properties(res[32][i], f"config 5 {form} {name}", psd_stride=97)
-            assert_parity(res[32][i], res[64][i], 32, f"config 5 {form} rows, fp32 vs fp64, {name}",
-                          state_tol=st, plain_tol=pl, cov_block_tol=cb)
+            e = parity_errors(res[32][i], res[64][i])
+            print(f"[parity] config 5 {form} rows, fp32 vs fp64, {name}: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} "
+                  f"({e['sigma_block']}) plain {e['plain']:.2e} ({e['plain_block']}) cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
+            assert e["literal"] <= lit and e["sigma"] <= st and e["plain"] <= pl
+            assert e["cov"] <= COV_TOL and e["cov_block"] <= cb and e["asym"] == 0 and e["prev_equal"]
 
 
 # ------------------------------------------------------------------------------------------- full recordings
