@@ -51,6 +51,12 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_STREAM_ST
 #define FBUS_X_STREAM_ST 1      // stacked correct / fused frame: the last rank-1 pass stores each chunk when its rows are final
 #endif
+#ifndef FBUS_X_PREDICT_ST
+#define FBUS_X_PREDICT_ST AUX_NT       // store policy of the streamed per-call predict
+#endif
+#ifndef FBUS_X_CORRECT_LD
+#define FBUS_X_CORRECT_LD AUX_NT       // load policy of the covariance in the correct kernels
+#endif
 #ifndef FBUS_X_FRAME_WAVES
 #define FBUS_X_FRAME_WAVES 1    // __launch_bounds__ waves per SIMD of the fused frame kernel (2 = at most 256 registers)
 #endif
@@ -58,7 +64,7 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #define FBUS_X_CORRECT_WAVES 1
 #endif
 #ifndef FBUS_X_IMU_PREFETCH
-#define FBUS_X_IMU_PREFETCH 0   // predict_n / fused frame: request the IMU sample of step k + 1 (and the first marker group) before step k is computed -- measured: no gain (fused 1.19e10 -> 1.18e10 at B = 65 536: the stalls are dependent-issue stalls, not these loads), +20 B scratch in fp32 and +600 B in fp64: off
+#define FBUS_X_IMU_PREFETCH 1   // predict_n / fused frame: the IMU sample of step k + 1 is requested in the middle of step k
 #endif
 template <typename T>
 __device__ __forceinline__ T ld_meas(const T* p) { return FBUS_X_MEAS_NT ? __builtin_nontemporal_load(p) : *p; }
@@ -248,18 +254,30 @@ struct ImuSample {
 };
 
 // K ImuUpdates with the record resident in registers (predict_n, fused frame)
-template <typename T, int N, int DIALECT>
+struct NoMidHook { __device__ __forceinline__ void operator()() const {} };
+template <typename T, int N, int DIALECT, typename MID = NoMidHook>
 __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
-                                              int B, int b, const T* qd)
+                                              int B, int b, const T* qd, const MID& mid_last = MID())
 {
 #if FBUS_X_IMU_PREFETCH
-    if (K <= 0) return;
-    ImuSample<T> cur, nxt;
+    // The sample of step k + 1 is requested as soon as step k's kinematics have consumed sample k, i.e. ~700 VALU
+    // instructions (the three covariance stages) before it is needed.  Requesting it at the top of the iteration into a
+    // second buffer does not work: the compiler's s_waitcnt placement then drains vmcnt to 0 right behind the new
+    // loads (to release the previous sample across the loop back-edge) and the full latency stays exposed -- that is
+    // what the first version of this prefetch measured (no gain).
+    if (K <= 0) { mid_last(); return; }
+    ImuSample<T> cur;
     cur.load(accel, gyro, dt, dt_stride, 0, B, b);
     for (int k = 0; k < K; ++k) {
-        if (k + 1 < K) nxt.load(accel, gyro, dt, dt_stride, k + 1, B, b);    // requested before step k is computed
-        predict_step<T, N, DIALECT>(nom, P, cur.a, cur.w, cur.h, qd);
-        cur = nxt;
+        PredictCoef<T> c;
+        predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < K) cur.load(accel, gyro, dt, dt_stride, k + 1, B, b);
+        else mid_last();                           // last step: the caller's loads for what follows the predicts
+        __builtin_amdgcn_sched_barrier(0);
+        cov_stage_p<T, N>(P, c);
+        cov_stage_v<T, N>(P, c, qd);
+        cov_stage_th<T, N>(P, c, qd);
     }
 #else
     for (int k = 0; k < K; ++k) {
@@ -269,6 +287,7 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
         const T h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
         predict_step<T, N, DIALECT>(nom, P, a, w, h, qd);
     }
+    mid_last();
 #endif
 }
 
@@ -287,13 +306,17 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
 // ba, bg, g and the covariance elements among ba, bg, g (off-diagonal) are not written by ImuUpdate: their chunks
 // stay as they are in HBM (N = 18: 33 of the 43 covariance chunks are stored).
 //
+// ST = cache policy of the record stores, LD = cache policy of the record loads.  A batch whose records do not fit the
+// 256 MB Infinity Cache (> 160 MB of records: B >= ~200 000 in fp32) runs with the default policy on both: measured at
+// 262 144 filters 65.4 us (nt / nt) -> 59.8 (default loads) -> 55.7 us (default loads and stores) = 6.75 TB/s moved; at
+// 131 072 and below the non-temporal forms win (records stay resident in the Infinity Cache between launches).
 // LD = cache policy of the record loads.  Non-temporal in a run of predicts (each line is read once per launch); the
 // FIRST predict after a correct reads with the default policy: correct stores with the default policy, its lines are
 // still in the XCD L2s, and nt loads of such lines were measured slow (first predict after a correct 15.8 us with nt
 // loads, 14.2 us with default loads, and the following launches reach their steady 12.6 us two launches earlier:
 // -5 us per camera frame; default-policy STORES there, or default loads for a second launch, lose again --
 // tools/exp_gap_after_correct.py under rocprofv3, reduced by tools/trace_positions.py).
-template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT>
+template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST>
 __global__ void __launch_bounds__(BLOCK)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
                const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
@@ -323,7 +346,7 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
         const size_t o = (size_t)b * 3;
         const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
         const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
-        constexpr int LDP = LD, STP = AUX_NT;
+        constexpr int LDP = LD, STP = ST;
         const T h = dt_stride ? ld_once(dt + b) : dt[0];
         load_chunks<T, N, 0, CN, LDP>(rs, my_lane(), nom);
         load_chunks<T, N, C_DG0, C_DG1, LDP>(rs, my_lane(), P + (C_DG0 - CN) * EPC);
@@ -408,7 +431,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
         order_fence();
         // fp64 (LEAN): the covariance is requested behind the factorisation instead (342 registers of load targets)
-        if constexpr (!LEAN) load_chunks<T, N, RC::CH_NOM, C_SPLIT, AUX_NT>(rs, my_lane(), P);
+        if constexpr (!LEAN) load_chunks<T, N, RC::CH_NOM, C_SPLIT, FBUS_X_CORRECT_LD>(rs, my_lane(), P);
         order_fence();
         treg.to_lds(tbl);
         order_fence();
@@ -456,7 +479,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             lean_passes(fac, used > 0);
         } else {
             order_fence();
-            load_chunks<T, N, C_SPLIT, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_SPLIT - RC::CH_NOM) * RC::EPC);
+            load_chunks<T, N, C_SPLIT, RC::NCH, FBUS_X_CORRECT_LD>(rs, my_lane(), P + (C_SPLIT - RC::CH_NOM) * RC::EPC);
             // the last of the six passes stores every covariance chunk as soon as its rows are final (FBUS_X_STREAM_ST)
             if (used > 0) {
                 if constexpr (STREAM_ST) joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_CORRECT_ST>{ rs, my_lane(), P });
@@ -580,11 +603,6 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     const int* my_ids = ids + (size_t)b * M;
     const T* my_pos = pos + (size_t)b * M * 3;
     const T* my_quat = quat + (size_t)b * M * 4;
-    // stacked mode: the measurements of the first marker group are requested before the predicts run (they do not
-    // depend on them), so the fold behind the last predict starts without a round trip to memory
-    MarkerGroup<T, FBUS_MARKER_GROUP> mg0;
-    const bool pre = JOINT && FBUS_X_IMU_PREFETCH && last > 0;
-    if (pre) mg0.fetch(my_ids, my_pos, my_quat, 0, last);
     predict_steps<T, N, DIALECT>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd);
 
     if (last > 0 && mode == MODE_NEAREST) {
@@ -622,7 +640,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     if (joint) acc.clear();
     for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
         MarkerGroup<T, FBUS_MARKER_GROUP> mg;
-        if (pre && i0 == 0) mg = mg0; else mg.fetch(my_ids, my_pos, my_quat, i0, last);
+        mg.fetch(my_ids, my_pos, my_quat, i0, last);
         mg.resolve(tbl);
 #pragma unroll
         for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {

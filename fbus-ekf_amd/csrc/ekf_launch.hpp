@@ -12,10 +12,10 @@
 
 namespace fbus {
 
-// K == 1: the streamed per-call kernel (`warm` = the records were last stored with the default cache policy);
-// K > 1: predict_n, K samples per launch with the record resident in registers
+// K == 1: the streamed per-call kernel (`policy`: 0 = nt loads and stores, 1 = default-policy loads, 2 = default loads
+// and stores); K > 1: predict_n, K samples per launch with the record resident in registers
 template <typename T, int N, int D>
-void launch_predict_k(hipStream_t s, T* recs, int B, int K, bool warm, const T* accel, const T* gyro, const T* dt,
+void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T* accel, const T* gyro, const T* dt,
                       int dt_stride, const DevConst<T>& dc);
 
 template <typename T, int N, int D>

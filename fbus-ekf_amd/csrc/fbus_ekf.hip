@@ -101,6 +101,7 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
 // ---------------------------------------------------------------------------------
 struct fbus_ekf {
     bool records_warm = false;        // the last kernel stored the records with the default cache policy (they sit in L2)
+    int predict_ld = 0;               // record-load policy of the per-call predict: 0 auto (see launch_predict_t), 1 always nt, 2 always default
     int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
     fbus_params prm{};
     HostConst hc;
@@ -228,9 +229,15 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
     const int ev = timing_begin(h, K == 1 ? FBUS_KERNEL_PREDICT : FBUS_KERNEL_PREDICT_N);
     // the first predict after a kernel that stored the records with the default cache policy (correct, fused frame)
     // reads them with the default policy too; the others stream them non-temporally (see predict_kernel)
-    const bool warm = h->records_warm;
+    // ... and a batch whose records do not fit the Infinity Cache runs with the default policy on loads AND stores:
+    // measured at 262 144 filters (210 MB of records) 65.4 us nt / nt -> 59.8 us default loads -> 55.7 us default loads
+    // and stores; at 131 072 (105 MB) and below the nt forms win (gpurun_out/r02_ld_policy.log, r02_ab4.log)
+    const bool big = h->rec_bytes > ((size_t)160 << 20);
+    int policy = (big ? 2 : (h->records_warm ? 1 : 0));
+    if (h->predict_ld == 1) policy = 0;
+    if (h->predict_ld == 2) policy = big ? 2 : 1;
     h->records_warm = false;
-    launch_predict_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, warm, (const T*)accel, (const T*)gyro, (const T*)dt,
+    launch_predict_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, policy, (const T*)accel, (const T*)gyro, (const T*)dt,
                               dt_per_filter ? 1 : 0, make_dc<T>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
@@ -566,6 +573,8 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (!h) return FBUS_ERR_NOMEM;
     h->B = batch;
     h->Bs = (batch + 63) / 64 * 64;
+    if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
+        h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
     h->device = device;
     h->dtype = dtype;
     h->N = nstate;

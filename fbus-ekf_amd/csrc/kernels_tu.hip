@@ -16,19 +16,20 @@ namespace fbus {
 
 #if FBUS_TU_FAMILY == 1
 template <typename T, int N, int D>
-void launch_predict_k(hipStream_t s, T* recs, int B, int K, bool warm, const T* accel, const T* gyro, const T* dt,
+void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T* accel, const T* gyro, const T* dt,
                       int dt_stride, const DevConst<T>& dc)
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
-    // the first predict after a kernel that stored the records with the default cache policy (correct, fused frame)
-    // reads them with the default policy too; the others stream them non-temporally (see predict_kernel)
+    // policy 0: nt loads and stores; 1: default-policy loads (first predict behind a kernel that stored the records with
+    // the default policy); 2: default loads and stores (records do not fit the Infinity Cache) -- see predict_kernel
     if (K == 1) {
-        if (warm)
-            hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_DEFAULT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K,
-                               accel, gyro, dt, dt_stride, dc);
-        else
-            hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_NT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K,
-                               accel, gyro, dt, dt_stride, dc);
+#define FBUS_LAUNCH_PREDICT(LD, ST)                                                                                     \
+    hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD, ST>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, \
+                       dt_stride, dc)
+        if (policy == 2) FBUS_LAUNCH_PREDICT(AUX_DEFAULT, AUX_DEFAULT);      // records larger than the Infinity Cache
+        else if (policy == 1) FBUS_LAUNCH_PREDICT(AUX_DEFAULT, AUX_NT);      // first predict behind a default-policy writer
+        else FBUS_LAUNCH_PREDICT(AUX_NT, AUX_NT);
+#undef FBUS_LAUNCH_PREDICT
     } else if constexpr (sizeof(T) == 8) {
         // fp64 is the verification path: K resident steps need more than the 512 registers a lane has in fp64 (the
         // kernel spilled ~580 bytes per lane), so predict_n is K launches of the streamed per-call kernel
@@ -42,7 +43,7 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, bool warm, const T* 
     }
 }
 #define FBUS_INST(D)                                                                                                  \
-    template void launch_predict_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, bool, const FBUS_TU_T*, \
+    template void launch_predict_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, int, const FBUS_TU_T*,  \
                                                             const FBUS_TU_T*, const FBUS_TU_T*, int,                  \
                                                             const DevConst<FBUS_TU_T>&);
 

@@ -3,9 +3,9 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_sq_${1:-a}
 mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p1 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --kernel-timing off > $OUT/p1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --kernel-timing off > $OUT/p2.log 2>&1
-python3 - <<'PY'
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p1 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hbm-leg --kernel-timing off > $OUT/p1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-hbm-leg --kernel-timing off > $OUT/p2.log 2>&1
+timeout 120 python3 - <<'PY'
 import csv, glob, collections, sys, os
 out = os.environ.get("OUTDIR", "")
 for sub in ("p1", "p2"):

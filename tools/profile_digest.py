@@ -41,7 +41,9 @@ for name in sorted(set(fetch) | set(write)):
         continue
     fb = 2.0 * 1024.0 * fetch[name][0] / fetch[name][1] if name in fetch else float("nan")
     wb = 1024.0 * write[name][0] / write[name][1] if name in write else float("nan")
-    print(f"{name:<46} fetch {fb/1e6:9.2f} MB  write {wb/1e6:9.2f} MB  total {(fb+wb)/1e6:9.2f} MB per launch")
+    us = out.get(name, {}).get("avg_us")
+    rate = f"  -> {(fb + wb) / us / 1e6:6.2f} TB/s = {(fb + wb) / us / 1e6 / 8.0:5.3f} of 8 TB/s over the kernel-trace average" if us else ""
+    print(f"{name:<46} fetch {fb/1e6:9.2f} MB  write {wb/1e6:9.2f} MB  total {(fb+wb)/1e6:9.2f} MB per launch{rate}")
     out.setdefault(name, {}).update({"fetch_bytes": fb, "write_bytes": wb})
 for log in ("trace.log", "pmc_fetch.log", "pmc_write.log"):
     p = os.path.join(root, log)
@@ -50,5 +52,15 @@ for log in ("trace.log", "pmc_fetch.log", "pmc_write.log"):
         if lines:
             d = json.loads(lines[-1])
             print(f"\n{log}: value {d['value']:.4g} {d['unit']}  ms/step {d['ms_per_step']:.4f}  predict avg (HIP events) "
-                  f"{d['roofline']['avg_launch_us']:.2f} us  frac {d['roofline']['frac']:.3f}")
+                  f"{d['roofline']['avg_launch_us']:.2f} us  frac (bytes moved) {d['roofline']['frac']:.3f}  correct {d['correct_kernel']['avg_launch_us']:.2f} us "
+                  f"frac {d['correct_kernel']['frac']:.3f}")
+# the configuration the profile was taken on (bench.py quotes `traffic` from a digest only when it matches its own run)
+cfg = {"batch": 65536, "dialect": "matlab", "markers": 4, "mode": "stacked", "args": sys.argv[2] if len(sys.argv) > 2 else ""}
+a = cfg["args"].split()
+for i, t in enumerate(a):
+    if t == "--batch": cfg["batch"] = int(a[i + 1])
+    if t == "--dialect": cfg["dialect"] = a[i + 1]
+    if t == "--markers": cfg["markers"] = int(a[i + 1])
+    if t == "--mode": cfg["mode"] = a[i + 1]
+out["_config"] = cfg
 json.dump(out, open(os.path.join(root, "digest.json"), "w"), indent=1)
