@@ -940,6 +940,44 @@ __global__ void imu_ema_kernel(int B, int Tn, T* __restrict__ accel, T* __restri
     }
 }
 
+// The L0 helpers one by one (unit-test hook behind fbus_ekf_l0_eval): exactly the inline functions the kernels use.
+template <typename T>
+__global__ void l0_eval_kernel(int op, int n, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op == FBUS_L0_QUAT_MUL) {
+        quat_mul(a + 4 * i, b + 4 * i, out + 4 * i);
+    } else if (op == FBUS_L0_QUAT_TO_ROTMAT_M) {
+        quat_to_rotmat_m(a + 4 * i, out + 9 * i);
+    } else if (op == FBUS_L0_QUAT_TO_ROTMAT_E) {
+        quat_to_rotmat_e(a + 4 * i, out + 9 * i);
+    } else if (op == FBUS_L0_QUAT_NORMALIZE) {
+        T q[4] = { a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3] };
+        quat_normalize(q);
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = q[k];
+    } else if (op == FBUS_L0_EXPM_SO3_NEG) {
+        // F(theta, theta) of the Matlab dialect through predict_nominal itself (zero biases, identity attitude)
+        T nom[Lay<18>::NNOM] = {};
+        nom[Lay<18>::OFF_Q] = T(1); nom[Lay<18>::OFF_R] = T(1); nom[Lay<18>::OFF_R + 4] = T(1); nom[Lay<18>::OFF_R + 8] = T(1);
+        const T acc[3] = { T(0), T(0), T(0) };
+        PredictCoef<T> k;
+        predict_nominal<T, 18, DIALECT_MATLAB>(nom, acc, a + 3 * i, b[i], k);
+        for (int j = 0; j < 9; ++j) out[9 * i + j] = k.Th[j];
+    } else if (op == FBUS_L0_DTHETA_TO_QUAT) {
+        T rec[Lay<18>::NNOM] = {};
+        rec[Lay<18>::OFF_Q] = T(1);
+        T dx[18] = {};
+        dx[6] = a[3 * i]; dx[7] = a[3 * i + 1]; dx[8] = a[3 * i + 2];
+        inject<T, 18>(rec, dx);                           // q = 1 (x) dq(dtheta), normalised
+        for (int k2 = 0; k2 < 4; ++k2) out[4 * i + k2] = rec[Lay<18>::OFF_Q + k2];
+    } else if (op == FBUS_L0_SINCOS_HALF) {
+        T s_, c_, sh, ch;
+        fb_sincos_x_halfx(a[i], s_, c_, sh, ch);
+        out[4 * i] = s_; out[4 * i + 1] = c_; out[4 * i + 2] = sh; out[4 * i + 3] = ch;
+    }
+}
+
 // AoS (API arrays) <-> records.  Not on the hot path.
 template <typename T, int N>
 __global__ void pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ nominal,

@@ -1118,4 +1118,28 @@ int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* la
     return FBUS_OK;
 }
 
+int fbus_ekf_l0_eval(fbus_ekf_t h, int op, int n, const void* a, const void* b, void* out)
+{
+    DeviceGuard guard_(h);
+    static const int wa[] = { 4, 4, 4, 4, 3, 3, 1 }, wb[] = { 4, 0, 0, 0, 1, 0, 0 }, wo[] = { 4, 9, 9, 4, 9, 4, 4 };
+    if (!h || op < 0 || op > FBUS_L0_SINCOS_HALF || n < 1 || !a || !out || (wb[op] && !b)) return FBUS_ERR_INVALID;
+    const size_t es = esize(h);
+    const void *da, *db = nullptr;
+    int rc;
+    if ((rc = stage_in(h, 0, a, (size_t)n * wa[op] * es, &da)) != FBUS_OK) return rc;
+    if (wb[op] && (rc = stage_in(h, 1, b, (size_t)n * wb[op] * es, &db)) != FBUS_OK) return rc;
+    if ((rc = ensure_stage(h, 2, (size_t)n * wo[op] * es)) != FBUS_OK) return rc;
+    const int grid = (n + 255) / 256;
+    if (h->dtype == 32)
+        hipLaunchKernelGGL((l0_eval_kernel<float>), dim3(grid), dim3(256), 0, h->stream, op, n, (const float*)da,
+                           (const float*)db, (float*)h->stage[2]);
+    else
+        hipLaunchKernelGGL((l0_eval_kernel<double>), dim3(grid), dim3(256), 0, h->stream, op, n, (const double*)da,
+                           (const double*)db, (double*)h->stage[2]);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out, h->stage[2], (size_t)n * wo[op] * es, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
 }  // extern "C"

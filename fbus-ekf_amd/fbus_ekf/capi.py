@@ -14,6 +14,7 @@ KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE, KERNEL_FRA
 KERNEL_CORRECT_CORNERS = 5
 VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D = 0, 1, 2
 POSE_INIT, POSE_RESET = 0, 1
+L0_QUAT_MUL, L0_QUAT_TO_ROTMAT_M, L0_QUAT_TO_ROTMAT_E, L0_QUAT_NORMALIZE, L0_EXPM_SO3_NEG, L0_DTHETA_TO_QUAT, L0_SINCOS_HALF = range(7)
 MAX_MARKERS, MAX_VISIBLE = 32, 16
 STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
 
@@ -116,6 +117,7 @@ def load_library():
         "fbus_ekf_graph_end": ([H, C.POINTER(C.c_int)], C.c_int),
         "fbus_ekf_graph_launch": ([H, C.c_int], C.c_int),
         "fbus_ekf_graph_destroy": ([H, C.c_int], C.c_int),
+        "fbus_ekf_l0_eval": ([H, C.c_int, C.c_int, vp, vp, vp], C.c_int),
         "fbus_ekf_timing_enable": ([H, C.c_int], C.c_int),
         "fbus_ekf_timing_reset": ([H], C.c_int),
         "fbus_ekf_timing_read": ([H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),

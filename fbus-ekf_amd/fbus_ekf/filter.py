@@ -317,6 +317,17 @@ class BatchedFilter:
         self._check(rc, "marker_pose")
         return (pos, quat, c3) if want_corners else (pos, quat)
 
+    # ---- L0 helpers one by one (unit-test hook) -------------------------------------------
+    def l0_eval(self, op, a, b=None):
+        """one of the device inline helpers (capi.L0_*) on n rows of host input; see include/fbus_ekf.h"""
+        wa, wb, wo = (4, 4, 4, 4, 3, 3, 1)[op], (4, 0, 0, 0, 1, 0, 0)[op], (4, 9, 9, 4, 9, 4, 4)[op]
+        a = np.ascontiguousarray(a, self.np_dtype).reshape(-1, wa)
+        n = a.shape[0]
+        b = None if not wb else self._host(b, (n, wb))
+        out = np.empty((n, wo), self.np_dtype)
+        self._check(self._lib.fbus_ekf_l0_eval(self._h, op, n, self._p(a), self._p(b), self._p(out)), "l0_eval")
+        return out
+
     # ---- HIP graphs ------------------------------------------------------------------------
     def graph_capture(self, fn):
         """Runs fn() (device-array calls on this filter only) under stream capture; returns a graph id."""

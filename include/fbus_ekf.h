@@ -263,6 +263,22 @@ int fbus_ekf_timing_enable(fbus_ekf_t h, int on);
 int fbus_ekf_timing_reset(fbus_ekf_t h);
 int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* launches);
 
+/* ---- L0 helpers on the device (unit-test hook) -------------------------------- */
+/* Evaluates ONE of the device inline helpers the kernels are built from for n independent inputs -- what
+ * matlab/quaternion_*.m, vector_to_crossmat.m, axisangle_to_quaternion.m and C++/include/matrix_math.hpp:26-99
+ * compute -- so that each helper can be tested against the oracle's restatement on its own, not only through
+ * predict/correct.  a, b, out: HOST arrays of the handle's scalar type, n rows each.
+ *   FBUS_L0_QUAT_MUL         a (n,4) (x) b (n,4) -> out (n,4)     quaternion_add.m:22-28 / Eigen Quaterniond::operator*
+ *   FBUS_L0_QUAT_TO_ROTMAT_M a (n,4)             -> out (n,9)     quaternion_to_rotmat.m:22-33
+ *   FBUS_L0_QUAT_TO_ROTMAT_E a (n,4)             -> out (n,9)     Eigen toRotationMatrix (filter.cpp:542,562,564)
+ *   FBUS_L0_QUAT_NORMALIZE   a (n,4)             -> out (n,4)     quaternion_normalize.m:22-24
+ *   FBUS_L0_EXPM_SO3_NEG     a (n,3) = w, b (n,1) = dt -> out (n,9) = expm(-[w]x dt)   ImuUpdate.m:68 (closed form of predict_nominal)
+ *   FBUS_L0_DTHETA_TO_QUAT   a (n,3) = dtheta    -> out (n,4)     axisangle_to_quaternion.m:22-29 as used by the injection (MeasureUpdate.m:94)
+ *   FBUS_L0_SINCOS_HALF      a (n,1) = x         -> out (n,4) = sin x, cos x, sin x/2, cos x/2 (the polynomial / library switch) */
+enum { FBUS_L0_QUAT_MUL = 0, FBUS_L0_QUAT_TO_ROTMAT_M = 1, FBUS_L0_QUAT_TO_ROTMAT_E = 2, FBUS_L0_QUAT_NORMALIZE = 3,
+       FBUS_L0_EXPM_SO3_NEG = 4, FBUS_L0_DTHETA_TO_QUAT = 5, FBUS_L0_SINCOS_HALF = 6 };
+int fbus_ekf_l0_eval(fbus_ekf_t h, int op, int n, const void* a, const void* b, void* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,6 +233,23 @@ class Oracle:
         return applied, out7
 
 
+# ---- L0 helpers of the oracle (matlab/quaternion_*.m, axisangle_to_quaternion.m ; matrix_math.hpp:26-99) ----
+def l0(name, *args, out):
+    """calls fbo_<name>(args..., out) with double arrays; out = number of doubles returned"""
+    lib = load()
+    fn = getattr(lib, "fbo_" + name)
+    fn.restype = None
+    res = np.zeros(out)
+    cargs = []
+    for x in args:
+        if np.isscalar(x):
+            cargs.append(C.c_double(float(x)))
+        else:
+            cargs.append(_dp(np.ascontiguousarray(x, np.float64)))
+    fn(*cargs, _dp(res))
+    return res
+
+
 def init_gravity_bias(accel, gyro):
     """accel, gyro (T, 3) of ONE filter -> g, bg"""
     lib = load()
