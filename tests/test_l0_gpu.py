@@ -65,5 +65,8 @@ def test_l0_eval_rejects_bad_arguments():
     with BatchedFilter(1, capi.default_params(0)) as flt:
         with pytest.raises(capi.FbusError):
             flt._check(flt._lib.fbus_ekf_l0_eval(flt._h, 99, 1, None, None, None), "l0_eval")
-        with pytest.raises(capi.FbusError):
-            flt.l0_eval(capi.L0_QUAT_MUL, np.zeros((2, 4)), None)          # quat_mul needs b
+        with pytest.raises(ValueError):
+            flt.l0_eval(capi.L0_QUAT_MUL, np.zeros((2, 4)), None)          # quat_mul needs b: the mirror refuses
+        a = np.zeros((2, 4), np.float32)
+        rc = flt._lib.fbus_ekf_l0_eval(flt._h, capi.L0_QUAT_MUL, 2, a.ctypes.data, None, a.ctypes.data)
+        assert rc != 0                                                       # ... and so does the C ABI
