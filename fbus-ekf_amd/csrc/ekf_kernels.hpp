@@ -774,6 +774,151 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     applied[b] = 1;
 }
 
+// Pixel rows of one marker into the information accumulator (north-star extension, no reference counterpart):
+// for each of the four corners the predicted position X in the left camera frame (the geometry of corner_info), its
+// flat-port projection into the left (and right) camera with the closed-form 2 x 3 Jacobian, and 2 (4) rows
+// (d pi/dX) [ -R_IL R' | R_IL [R'(c_w - p)]x ] with the pixel residuals.
+template <typename T, int N>
+__device__ __forceinline__ void pixel_info(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc, const VisConst<T>& vc,
+                                           const T* __restrict__ mk, const T* yl, const T* yr, T size, T w_pix)
+{
+    using L = Lay<N>;
+    const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
+    T Rm[9];
+    {
+        const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
+        quat_to_rotmat_m(Qm, Rm);
+    }
+    T Hpp[9];                                            // -R_IL R': the same for every corner
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Hpp[3 * i + j] = -(dc.R_IL[3 * i] * R[3 * j] + dc.R_IL[3 * i + 1] * R[3 * j + 1] + dc.R_IL[3 * i + 2] * R[3 * j + 2]);
+    T RP[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) RP[i] = R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2];
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const T cx = (k >= 2) ? size : T(0), cy = (k == 1 || k == 2) ? size : T(0);
+        T u[3], d[3], ru[3], t[3], X[3], Hpt[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            u[i] = mk[i] + Rm[3 * i] * cx + Rm[3 * i + 1] * cy - p[i];
+            d[i] = u[i] - RP[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            t[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
+            ru[i] = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
+            X[i] = l0 * t[0] + l1 * t[1] + l2 * t[2];
+            Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
+            Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
+            Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
+        }
+        // refraction frame of the left camera: the triangulation's axis flip undone (vision.cpp:597-599)
+        const T XL[3] = { -X[0], -X[1], X[2] };
+        auto rows = [&](const T* Xr, const T* y, const T* Mx /* d Xr / d X, 3 x 3 */) {
+            if (!(dot3(Xr, vc.nrm) > vc.d_air + vc.d_glass)) return;          // behind the port: no rows
+            T uv[2], J[6];
+            refraction_project(vc, Xr, uv, J);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                T jx[3], hA[3], hB[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) jx[c] = J[3 * q] * Mx[c] + J[3 * q + 1] * Mx[3 + c] + J[3 * q + 2] * Mx[6 + c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    hA[c] = jx[0] * Hpp[c] + jx[1] * Hpp[3 + c] + jx[2] * Hpp[6 + c];
+                    hB[c] = jx[0] * Hpt[c] + jx[1] * Hpt[3 + c] + jx[2] * Hpt[6 + c];
+                }
+                acc.add6(hA, hB, y[q] - uv[q], w_pix);
+            }
+        };
+        const T F[9] = { T(-1), T(0), T(0), T(0), T(-1), T(0), T(0), T(0), T(1) };
+        const T ylk[2] = { yl[2 * k], yl[2 * k + 1] };          // yl / yr point into global memory: no indexed local arrays
+        rows(XL, ylk, F);
+        if (yr) {
+            const T yrk[2] = { yr[2 * k], yr[2 * k + 1] };
+            const T dl[3] = { XL[0] - vc.P_LR[0], XL[1] - vc.P_LR[1], XL[2] - vc.P_LR[2] };
+            T XR[3], MR[9];
+            m3v(vc.R_RL_inv, dl, XR);                                           // X_L = R_RL X_R + P_LR  (vision.cpp:555-556)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { MR[3 * i] = -vc.R_RL_inv[3 * i]; MR[3 * i + 1] = -vc.R_RL_inv[3 * i + 1]; MR[3 * i + 2] = vc.R_RL_inv[3 * i + 2]; }
+            rows(XR, yrk, MR);
+        }
+    }
+}
+
+// correct() from corner pixels: all visible markers, 2 (left camera) or 4 (stereo) reprojection rows per corner.
+template <typename T, int N, int DIALECT, int COV>
+__global__ void __launch_bounds__(BLOCK)
+correct_pixels_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
+                      const T* __restrict__ right, T size, T r_pix, const unsigned char* __restrict__ skip,
+                      unsigned char* __restrict__ applied, DevConst<T> dc, VisConst<T> vc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    if (skip && skip[b]) { applied[b] = 0; return; }
+    const int* my_ids = ids + (size_t)b * M;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T pqr[L::NPQR];
+    load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
+    int used = 0;
+    InfoAcc<T> acc;
+    acc.clear();
+    const T w_pix = T(1) / r_pix;
+    for (int i = 0; i < M; ++i) {                     // the fold runs before the covariance is requested (see correct_corners_kernel)
+        const int id = my_ids[i];
+        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
+        const int slot = dc.id2slot[id];
+        if (slot < 0) continue;
+        pixel_info<T, N>(acc, pqr, dc, vc, dc.mk + (size_t)slot * MK_STRIDE, left + ((size_t)b * M + i) * 8,
+                         right ? right + ((size_t)b * M + i) * 8 : nullptr, size, w_pix);
+        ++used;
+    }
+    if (used == 0) { applied[b] = 0; return; }
+    constexpr bool LEAN = sizeof(T) == 8;                // fp64: row-split passes, see correct_kernel
+    constexpr int RS = 9;
+    using Stash = LateStash<T, N, RS>;
+    using Hook = RowStore<T, N, AUX_DEFAULT>;
+    __shared__ T stash_mem[LEAN ? Stash::NVAL * BLOCK : 1];
+    InfoFactors<T> fac;
+    joint_factor<T>(acc, fac);
+    order_fence();
+    T P[RC::NCOVP];
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    if constexpr (LEAN) {
+        const Stash stash{ stash_mem + threadIdx.x };
+        constexpr int E_END = cov_final_before_row<N>(RS);
+        constexpr int C_E = RC::CH_NOM + (E_END + RC::EPC - 1) / RC::EPC;
+        load_chunks<T, N, RC::CH_NOM, C_E, AUX_NT>(rs, my_lane(), P);
+        joint_apply_early<T, N, COV, RS, Hook>(P, dx, fac, Hook{ rs, my_lane(), P }, stash);
+        order_fence();
+        load_chunks<T, N, C_E, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_E - RC::CH_NOM) * RC::EPC);
+        joint_apply_late<T, N, COV, RS>(P, dx, stash);
+    } else {
+        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        joint_apply<T, N, COV>(P, dx, fac);
+    }
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    inject<T, N>(nom, dx);
+    store_chunks<T, N, 0, RC::CH_PQ>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, my_lane(), nom + L::NPQR);
+    constexpr int C_REST = LEAN ? Hook::fin(RS) : RC::CH_NOM;
+    store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
+    applied[b] = 1;
+}
+
 // One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
 template <typename T>
 __global__ void __launch_bounds__(256)

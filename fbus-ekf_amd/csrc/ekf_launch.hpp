@@ -32,4 +32,8 @@ void launch_corners_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
                       int geometry, int mode, bool joseph, T size, const unsigned char* skip, unsigned char* applied,
                       const DevConst<T>& dc, const VisConst<T>& vc);
 
+template <typename T, int N, int D>
+void launch_pixels_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, bool joseph, T size,
+                     T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc);
+
 }  // namespace fbus

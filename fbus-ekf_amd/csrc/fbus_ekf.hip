@@ -384,6 +384,14 @@ VisConst<T> make_vc(const fbus_ekf* h)
         vc.t_LRn[i] = (T)(PL[i] - b);
     }
     for (int i = 0; i < 9; ++i) { vc.R_RL[i] = (T)Rrl[i]; vc.R_LRn[i] = (T)Rlr[i]; }
+    {   // exact inverse of R_RL (adjugate / determinant), for the forward projection into the right camera
+        const double* m = Rrl;
+        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        const double inv[9] = { (m[4] * m[8] - m[5] * m[7]), (m[2] * m[7] - m[1] * m[8]), (m[1] * m[5] - m[2] * m[4]),
+                                (m[5] * m[6] - m[3] * m[8]), (m[0] * m[8] - m[2] * m[6]), (m[2] * m[3] - m[0] * m[5]),
+                                (m[3] * m[7] - m[4] * m[6]), (m[1] * m[6] - m[0] * m[7]), (m[0] * m[4] - m[1] * m[3]) };
+        for (int i = 0; i < 9; ++i) vc.R_RL_inv[i] = (T)(inv[i] / det);
+    }
     vc.alpha0 = (T)(p.n_air / p.n_glass);
     vc.alpha1 = (T)(p.n_glass / p.n_water);
     vc.sqrt_minus0 = p.n_air < p.n_glass;       // vision.cpp:513
@@ -444,6 +452,24 @@ int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
+}
+
+template <typename T, int N, int D>
+int launch_correct_pixels_t(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, const uint8_t* skip)
+{
+    const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
+    h->records_warm = true;
+    launch_pixels_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right,
+                             h->prm.cov_form == FBUS_COV_JOSEPH, (T)h->prm.marker_size, (T)h->prm.r_pix,
+                             (const unsigned char*)skip, h->d_applied, make_dc<T>(h), make_vc<T>(h));
+    timing_end(h, ev);
+    HIP_TRY(h, hipGetLastError());
+    return FBUS_OK;
+}
+
+int launch_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, const uint8_t* skip)
+{
+    DISPATCH(h, launch_correct_pixels_t, h, M, ids, left, right, skip);
 }
 
 int launch_correct_corners(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, int geometry,
@@ -553,6 +579,7 @@ int fbus_params_default(fbus_params* prm, int dialect)
     prm->d_air = 0.002; prm->d_glass = 0.02;
     prm->port_normal[0] = 0; prm->port_normal[1] = 0; prm->port_normal[2] = 1;
     prm->marker_size = 0.28;    // vision.hpp:114
+    prm->r_pix = 1e-6;          // (1e-3)^2 in normalised image coordinates: ~0.4 px at the recordings' focal length
     return FBUS_OK;
 }
 
@@ -840,6 +867,32 @@ int fbus_ekf_correct_corners(fbus_ekf_t h, int M, const int32_t* ids, const void
     if ((rc = stage_in(h, 3, skip, B, &ds)) != FBUS_OK) return rc;
     if ((rc = fbus_ekf_correct_corners_dev(h, M, (const int32_t*)di, dl, dr, geometry, mode, (const uint8_t*)ds)) != FBUS_OK)
         return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_correct_pixels_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right,
+                                const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || !ids || !left || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (!(h->prm.r_pix > 0)) return fail(h, FBUS_ERR_INVALID, "r_pix must be positive");
+    return launch_correct_pixels(h, M, ids, left, right, skip);
+}
+
+int fbus_ekf_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right,
+                            const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || !ids || !left || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), B = (size_t)h->B;
+    const void *di, *dl, *dr, *ds;
+    int rc;
+    if ((rc = stage_in(h, 0, ids, B * M * sizeof(int32_t), &di)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 1, left, B * M * 8 * es, &dl)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 2, right, right ? B * M * 8 * es : 0, &dr)) != FBUS_OK) return rc;
+    if ((rc = stage_in(h, 3, skip, skip ? B : 0, &ds)) != FBUS_OK) return rc;
+    if ((rc = fbus_ekf_correct_pixels_dev(h, M, (const int32_t*)di, dl, dr, (const uint8_t*)ds)) != FBUS_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FBUS_OK;
 }

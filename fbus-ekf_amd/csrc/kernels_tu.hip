@@ -105,11 +105,27 @@ void launch_corners_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
         hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
                            left, right, geometry, mode, size, skip, applied, dc, vc);
 }
+template <typename T, int N, int D>
+void launch_pixels_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, bool joseph, T size,
+                     T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc)
+{
+    const int grid = (B + BLOCK - 1) / BLOCK;
+    if (joseph)
+        hipLaunchKernelGGL((correct_pixels_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, left,
+                           right, size, r_pix, skip, applied, dc, vc);
+    else
+        hipLaunchKernelGGL((correct_pixels_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, left,
+                           right, size, r_pix, skip, applied, dc, vc);
+}
 #define FBUS_INST(D)                                                                                                  \
     template void launch_corners_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,            \
                                                             const FBUS_TU_T*, const FBUS_TU_T*, int, int, bool,       \
                                                             FBUS_TU_T, const unsigned char*, unsigned char*,          \
-                                                            const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&);
+                                                            const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&);  \
+    template void launch_pixels_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,             \
+                                                           const FBUS_TU_T*, const FBUS_TU_T*, bool, FBUS_TU_T,       \
+                                                           FBUS_TU_T, const unsigned char*, unsigned char*,           \
+                                                           const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&);
 #else
 #error "FBUS_TU_FAMILY must be 1..4"
 #endif

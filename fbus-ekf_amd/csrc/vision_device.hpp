@@ -20,6 +20,7 @@ template <typename T>
 struct VisConst {
     T R_RL[9], P_LR[3];         // right -> left: R_IL R_IR', P_LI - R_RL P_RI          (vision.cpp:476-481)
     T R_LRn[9], t_LRn[3];       // NormalTriangulation's T_L_R: R_IR R_IL', P_LI - R_LRn P_RI (:402-409)
+    T R_RL_inv[9];              // exact inverse of R_RL (the calibration's 6-digit matrices are orthonormal to 1e-5 only)
     T alpha0, alpha1;           // n_air/n_glass, n_glass/n_water
     int sqrt_minus0, sqrt_minus1;   // which branch of :513-522 / :532-541 applies
     T d_air, d_glass;
@@ -86,6 +87,56 @@ __device__ __forceinline__ void refraction_corner(const VisConst<T>& vc, T xl, T
     for (int i = 0; i < 3; ++i) {
         const T P = T(0.5) * (P1L[i] + t1 * r2L[i] + P1RL[i] + t2 * r2RL[i]);
         out[i] = (i < 2) ? -P : P;                       // :597-599
+    }
+}
+
+// Forward flat-port projection with its Jacobian (north-star extension; the reference only back-projects).
+// Xp: point in a camera's refraction frame (the frame of the rays of vision.cpp:496-552).  The ray to it stays in the
+// plane of the port normal and the point, so t = tan(theta_air) solves one monotone scalar equation
+//     rho = d_air t + d_glass tan(theta_glass) + (z - d_air - d_glass) tan(theta_water)          (Snell twice)
+// (z = depth along the normal, rho = distance from the axis), by Newton from the pin-hole start.
+// uv = normalised image point, J = d uv / d Xp (2 x 3, row-major), in closed form by implicit differentiation.
+template <typename T>
+__device__ __forceinline__ void refraction_project(const VisConst<T>& vc, const T* Xp, T* uv, T* J)
+{
+    const T* n = vc.nrm;
+    const T a0 = vc.alpha0, a1 = vc.alpha0 * vc.alpha1;           // n_air / n_glass, n_air / n_water
+    const T z = dot3(Xp, n);
+    const T lat[3] = { Xp[0] - z * n[0], Xp[1] - z * n[1], Xp[2] - z * n[2] };
+    const T rho = fb_sqrt(dot3(lat, lat));
+    const T zw = z - vc.d_air - vc.d_glass;
+    T t = rho / z, Lt = T(1), Lz = T(0);
+    constexpr int ITER = (sizeof(T) == 4) ? 6 : 9;                // quadratic convergence from a start within a few percent
+#pragma unroll 1
+    for (int it = 0; it <= ITER; ++it) {
+        const T q = T(1) / (T(1) + t * t), sq = fb_sqrt(q);
+        const T s_ = t * sq, dsdt = q * sq;                       // sin(theta_air), d sin / d t
+        const T cg2 = T(1) - a0 * a0 * s_ * s_, cw2 = T(1) - a1 * a1 * s_ * s_;
+        const T icg = T(1) / fb_sqrt(cg2), icw = T(1) / fb_sqrt(cw2);
+        const T L = vc.d_air * t + vc.d_glass * a0 * s_ * icg + zw * a1 * s_ * icw;
+        Lt = vc.d_air + (vc.d_glass * a0 * icg / cg2 + zw * a1 * icw / cw2) * dsdt;
+        Lz = a1 * s_ * icw;                                       // tan(theta_water)
+        if (it < ITER) { t -= (L - rho) / Lt; t = t < T(0) ? T(0) : t; }
+    }
+    const bool on_axis = !(rho > T(0));
+    const T irho = on_axis ? T(0) : T(1) / rho;
+    const T k = on_axis ? T(1) / Lt : t * irho;
+    const T e[3] = { lat[0] * irho, lat[1] * irho, lat[2] * irho };
+    const T D[3] = { n[0] + k * lat[0], n[1] + k * lat[1], n[2] + k * lat[2] };
+    const T iDz = T(1) / D[2];
+    uv[0] = D[0] * iDz; uv[1] = D[1] * iDz;
+    // dD/dX = e e' (1/Lt - k) - (Lz/Lt) e n' + k (I - n n')
+    const T c1 = T(1) / Lt - k, c2 = Lz / Lt;
+    T dD[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            dD[3 * i + j] = c1 * e[i] * e[j] - c2 * e[i] * n[j] + k * ((i == j ? T(1) : T(0)) - n[i] * n[j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        J[j] = (dD[j] - uv[0] * dD[6 + j]) * iDz;
+        J[3 + j] = (dD[3 + j] - uv[1] * dD[6 + j]) * iDz;
     }
 }
 

@@ -36,7 +36,7 @@ class FbusParams(C.Structure):
         ("switch_thres", C.c_double), ("max_dist", C.c_double),
         ("n_air", C.c_double), ("n_glass", C.c_double), ("n_water", C.c_double),
         ("d_air", C.c_double), ("d_glass", C.c_double), ("port_normal", C.c_double * 3),
-        ("marker_size", C.c_double),
+        ("marker_size", C.c_double), ("r_pix", C.c_double),
     ]
 
 
@@ -100,6 +100,8 @@ def load_library():
         "fbus_ekf_correct_dev": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_correct_corners": ([H, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
         "fbus_ekf_correct_corners_dev": ([H, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
+        "fbus_ekf_correct_pixels": ([H, C.c_int, ip, vp, vp, u8p], C.c_int),
+        "fbus_ekf_correct_pixels_dev": ([H, C.c_int, ip, vp, vp, u8p], C.c_int),
         "fbus_ekf_get_applied": ([H, u8p], C.c_int),
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),

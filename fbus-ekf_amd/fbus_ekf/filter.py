@@ -218,6 +218,28 @@ class BatchedFilter:
                                                 self._p(skip))
         self._check(rc, "correct_corners")
 
+    def correct_pixels(self, ids, left, right=None, skip=None):
+        """correct() from corner PIXELS (north-star extension, no reference counterpart): the flat-port reprojection of
+        the four corners of every visible marker, 2 rows per corner (left camera) or 4 (left and right).
+        left/right: (B, M, 8) normalised image points x0 y0 .. x3 y3."""
+        B = self.B
+        if _is_dev(ids):
+            M = ids.numel() // B
+            self._dev_checked(ids, B * M, "ids"); self._dev_checked(left, B * M * 8, "left")
+            if right is not None:
+                self._dev_checked(right, B * M * 8, "right")
+            if skip is not None:
+                self._dev_checked(skip, B, "skip")
+            rc = self._lib.fbus_ekf_correct_pixels_dev(self._h, M, self._p(ids), self._p(left), self._p(right), self._p(skip))
+            return self._check(rc, "correct_pixels_dev")
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        left = self._host(left, (B, M, 8))
+        right = None if right is None else self._host(right, (B, M, 8))
+        skip = None if skip is None else self._host(skip, (B,), np.uint8)
+        rc = self._lib.fbus_ekf_correct_pixels(self._h, M, self._p(ids), self._p(left), self._p(right), self._p(skip))
+        self._check(rc, "correct_pixels")
+
     def applied(self):
         out = np.empty(self.B, np.uint8)
         self._check(self._lib.fbus_ekf_get_applied(self._h, self._p(out)), "get_applied")

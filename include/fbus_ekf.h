@@ -87,6 +87,7 @@ typedef struct fbus_params {
     double  d_air, d_glass;
     double  port_normal[3];
     double  marker_size;        /* side of the square marker [m] (vision.hpp:114: 0.28); corner-row model only */
+    double  r_pix;              /* noise of one normalised image coordinate (pixel-row model only); default 1e-6 */
 } fbus_params;
 
 /* Fills prm with the reference's constants for the given dialect
@@ -262,6 +263,21 @@ enum { FBUS_KERNEL_PREDICT = 0, FBUS_KERNEL_CORRECT = 1, FBUS_KERNEL_PREDICT_N =
 int fbus_ekf_timing_enable(fbus_ekf_t h, int on);
 int fbus_ekf_timing_reset(fbus_ekf_t h);
 int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* launches);
+
+/* ---- correct() from corner PIXELS: the north star's reprojection rows ------------ */
+/* No reference counterpart (the reference has only the back-projection VISION::RefractionTriangulation,
+ * vision.cpp:472-618).  Measurement = the normalised image points of the four corners of every visible marker in the left
+ * camera (right == NULL: 2 rows per corner, 128 rows at 16 markers) or in both cameras (4 rows per corner).
+ * h = pi(X_k(x)): X_k = R_IL R'(P_m + R_m c_k - p - R P_IL) the corner in the left camera frame (the geometry of
+ * MeasureUpdate.m:67,72-73 with the corner in place of the marker origin), pi = the flat-port forward projection
+ * (air -> glass -> water, the inverse of the ray construction of vision.cpp:505-552, solved by Newton in the plane of the port
+ * normal and the point).  Per-corner Jacobian rows (2 x N) = d pi/dX (closed form) x [ -R_IL R' | R_IL [R'(c_w - p)]x ];
+ * all rows of all visible markers at one linearisation point, folded into the 6x6 information matrix.
+ * ids (B, M), left / right (B, M, 8) = x0 y0 .. x3 y3 (the column layout of corners.txt, vision.cpp:111-119). */
+int fbus_ekf_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right /* may be NULL */,
+                            const uint8_t* skip);
+int fbus_ekf_correct_pixels_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right,
+                                const uint8_t* skip);
 
 /* ---- L0 helpers on the device (unit-test hook) -------------------------------- */
 /* Evaluates ONE of the device inline helpers the kernels are built from for n independent inputs -- what

@@ -8,6 +8,7 @@
  * CPU baseline.  Each function cites the reference lines it follows.
  */
 #include "ekf_oracle.h"
+#include "vision_oracle.h"
 
 #include <math.h>
 #include <pthread.h>
@@ -725,6 +726,102 @@ int fbo_correct_corners(fbo_state* s, const fbo_params* prm, int M, const int* i
     }
     dense_update(s, prm, m, H, r, Rd);
     return 1;
+}
+
+static void load_state(fbo_state* s, int n, const double* nom, const double* rot, const double* P, int prev);
+static void store_state(const fbo_state* s, int n, double* nom, double* rot, double* P, int* prev);
+
+/* ------------------------------------------------------------------ */
+/* pixel-row measurement model: the north star's "flat-port refractive  */
+/* stereo reprojection of ArUco corners, per-corner 2 x N Jacobians".   */
+/* NO reference counterpart (the reference has no forward projection):  */
+/* parity unpinned by construction; the projection itself is pinned     */
+/* through the reference's back-projection (vision_oracle.c).           */
+/* ------------------------------------------------------------------ */
+/* Measurement = the normalised image points of the four corners of every visible marker, left camera (2 rows per
+ * corner) or both cameras (4 rows per corner).  h = pi(X_k(x)), X_k = R_IL R'(P_m + R_m c_k - p - R P_IL) the corner in the
+ * left camera frame (as fbo_correct_corners), pi = fbv_project_stereo.  H = (d pi / d X) [ -R_IL R' | R_IL [R'(c_w - p)]x ]
+ * with d pi / d X by CENTRAL DIFFERENCES of the projection (deliberately not the analytic form the device uses).
+ * All visible markers, one linearisation point, noise r_pix per row. */
+int fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_params, int M, const int* ids,
+                       const double* left /*M x 8*/, const double* right /*M x 8 or NULL*/, double size, double r_pix)
+{
+    const fbv_params* vp = (const fbv_params*)vision_params;
+    const int n = prm->nstate, rows_c = right ? 4 : 2;
+    int sel[FBO_MAX_VISIBLE], slot[FBO_MAX_VISIBLE], nsel = 0;
+    if (M > FBO_MAX_VISIBLE) M = FBO_MAX_VISIBLE;
+    for (int i = 0; i < M; ++i) {
+        if (ids[i] < 0) continue;
+        int k = find_marker(prm, ids[i]);
+        if (k < 0) continue;
+        sel[nsel] = i; slot[nsel] = k; ++nsel;
+    }
+    if (nsel == 0) return 0;
+    static __thread double H[FBO_MMAX * FBO_NMAX], r[FBO_MMAX], Rd[FBO_MMAX];
+    const double ck[4][3] = { { 0, 0, 0 }, { 0, size, 0 }, { size, size, 0 }, { size, 0, 0 } };
+    int m = 0;
+    for (int j = 0; j < nsel; ++j) {
+        double Rm[9];
+        fbo_quat_to_rotmat(prm->marker_quat[slot[j]], Rm);
+        for (int k = 0; k < 4; ++k) {
+            double cw[3], RP[3], d[3], dm[3], t[3], X[3], u[3], ux[9], Bm[9], J3[3 * FBO_NMAX];
+            mat3_vec(Rm, ck[k], cw);
+            for (int i = 0; i < 3; ++i) cw[i] += prm->marker_pos[slot[j]][i];
+            mat3_vec(s->R, prm->P_IL, RP);
+            for (int i = 0; i < 3; ++i) { dm[i] = cw[i] - s->p[i]; d[i] = dm[i] - RP[i]; }
+            mat3t_vec(s->R, d, t);
+            mat3_vec(prm->R_IL, t, X);                                   /* corner in the left camera frame */
+            mat3t_vec(s->R, dm, u);
+            fbo_skew(u, ux);
+            mat_mul(prm->R_IL, ux, Bm, 3, 3, 3);
+            memset(J3, 0, sizeof(double) * 3 * n);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double acc = 0;
+                    for (int c = 0; c < 3; ++c) acc += prm->R_IL[3 * a + c] * s->R[3 * b + c];
+                    J3[a * n + b] = -acc;
+                    J3[a * n + 6 + b] = Bm[3 * a + b];
+                }
+            double uvL[2], uvR[2], Jp[4][3];
+            if (!fbv_project_stereo(vp, X, uvL, right ? uvR : NULL)) continue;     /* behind the port: no rows */
+            const double eps = 1e-6;
+            for (int c = 0; c < 3; ++c) {
+                double Xp[3] = { X[0], X[1], X[2] }, Xm[3] = { X[0], X[1], X[2] }, aL[2], aR[2], bL[2], bR[2];
+                Xp[c] += eps; Xm[c] -= eps;
+                fbv_project_stereo(vp, Xp, aL, right ? aR : NULL);
+                fbv_project_stereo(vp, Xm, bL, right ? bR : NULL);
+                Jp[0][c] = (aL[0] - bL[0]) / (2 * eps); Jp[1][c] = (aL[1] - bL[1]) / (2 * eps);
+                if (right) { Jp[2][c] = (aR[0] - bR[0]) / (2 * eps); Jp[3][c] = (aR[1] - bR[1]) / (2 * eps); }
+            }
+            const double* yl = left + 8 * sel[j] + 2 * k;
+            const double* yr = right ? right + 8 * sel[j] + 2 * k : NULL;
+            const double res[4] = { yl[0] - uvL[0], yl[1] - uvL[1], yr ? yr[0] - uvR[0] : 0, yr ? yr[1] - uvR[1] : 0 };
+            for (int q = 0; q < rows_c; ++q) {
+                double* Hq = H + (size_t)m * n;
+                for (int c = 0; c < n; ++c) Hq[c] = Jp[q][0] * J3[c] + Jp[q][1] * J3[n + c] + Jp[q][2] * J3[2 * n + c];
+                r[m] = res[q];
+                Rd[m] = r_pix;
+                ++m;
+            }
+        }
+    }
+    if (m == 0) return 0;
+    dense_update(s, prm, m, H, r, Rd);
+    return 1;
+}
+
+void fbo_correct_pixels_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                              const void* vision_params, int M, const int* ids, const double* left, const double* right,
+                              double size, double r_pix, int* applied)
+{
+    const int n = prm->nstate;
+    for (int b = 0; b < B; ++b) {
+        fbo_state s;
+        load_state(&s, n, nominal + (size_t)b * 19, rot + (size_t)b * 9, P + (size_t)b * n * n, prev[b]);
+        applied[b] = fbo_correct_pixels(&s, prm, vision_params, M, ids + (size_t)b * M, left + (size_t)b * M * 8,
+                                        right ? right + (size_t)b * M * 8 : NULL, size, r_pix);
+        store_state(&s, n, nominal + (size_t)b * 19, rot + (size_t)b * 9, P + (size_t)b * n * n, prev + b);
+    }
 }
 
 void fbo_correct_corners_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,

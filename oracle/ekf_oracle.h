@@ -37,7 +37,7 @@ extern "C" {
 #define FBO_NMAX 18
 #define FBO_MAX_MARKERS 32      /* map entries */
 #define FBO_MAX_VISIBLE 16      /* markers per frame */
-#define FBO_MMAX (12 * FBO_MAX_VISIBLE)  /* stacked measurement rows (7 per marker pose, 12 per marker corners) */
+#define FBO_MMAX (16 * FBO_MAX_VISIBLE)  /* stacked measurement rows (7 per marker pose, 12 per marker corners, 16 per marker stereo pixels) */
 
 enum { FBO_DIALECT_MATLAB = 0, FBO_DIALECT_CPP = 1 };
 enum { FBO_MODE_NEAREST = 0,    /* reference behaviour: one 7-row update, nearest marker */
@@ -121,6 +121,14 @@ int  fbo_correct_corners(fbo_state* s, const fbo_params* prm, int M, const int* 
                          double size, int mode);
 void fbo_correct_corners_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
                                int M, const int* ids, const double* corners, double size, int mode, int* applied);
+
+/* ---- pixel-row measurement model: flat-port reprojection of the corners, 2 (left) or 4 (stereo) rows per corner;
+ *      north-star extension, no reference counterpart (parity unpinned); vision_params = const fbv_params*        ---- */
+int  fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_params, int M, const int* ids,
+                        const double* left /*Mx8*/, const double* right /*Mx8 or NULL*/, double size, double r_pix);
+void fbo_correct_pixels_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                              const void* vision_params, int M, const int* ids, const double* left, const double* right,
+                              double size, double r_pix, int* applied);
 
 /* ---- init / reset / front door ---- */
 void fbo_init_gravity_bias(int T, const double* accel, const double* gyro, double g[3], double bg[3]);

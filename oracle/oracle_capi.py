@@ -81,6 +81,12 @@ def load(native=False):
     lib.fbo_transition.argtypes = [C.POINTER(FboState), C.POINTER(FboParams), dp, dp, C.c_double, dp]
     lib.fbo_measurement.argtypes = [C.POINTER(FboState), C.POINTER(FboParams), C.c_int, dp, dp, dp, dp, dp]
     lib.fbo_predict.argtypes = [C.POINTER(FboState), C.POINTER(FboParams), dp, dp, C.c_double]
+    lib.fbo_correct_pixels_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.POINTER(FbvParams), C.c_int, ip,
+                                             dp, dp, C.c_double, C.c_double, ip]
+    lib.fbv_project_stereo.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
+    lib.fbv_project_stereo.restype = C.c_int
+    lib.fbv_refraction_project.argtypes = [C.POINTER(FbvParams), dp, dp]
+    lib.fbv_refraction_project.restype = C.c_int
     u8 = C.POINTER(C.c_ubyte)
     lib.fbo_init_gravity_bias.argtypes = [C.c_int, dp, dp, dp, dp]
     lib.fbo_pose_init_batch.argtypes = [C.c_int, dp, dp, C.POINTER(FboParams), C.c_int, ip, dp, dp, C.c_int, C.c_double,
@@ -204,6 +210,21 @@ class Oracle:
                                            _dp(corners), float(size), mode, _ip(applied))
         return applied
 
+    def correct_pixels(self, nominal, rot, P, prev, ids, left, right, size, r_pix, vision=None):
+        """pixel-row model (no reference counterpart): left / right (B, M, 8) normalised corner image points, right may be
+        None (left camera only: 2 rows per corner)"""
+        B = nominal.shape[0]
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        left = np.ascontiguousarray(left, np.float64).reshape(B, M, 8)
+        right = None if right is None else np.ascontiguousarray(right, np.float64).reshape(B, M, 8)
+        vp = vision if vision is not None else vision_params()
+        applied = np.zeros(B, np.int32)
+        self.lib.fbo_correct_pixels_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), C.byref(vp), M,
+                                          _ip(ids), _dp(left), None if right is None else _dp(right), float(size),
+                                          float(r_pix), _ip(applied))
+        return applied
+
     def schedule(self, nominal, rot, P, prev, Ks, reps, accel, gyro, dt, ids, pos, quat, mode=NEAREST):
         """reps x (frames of Ks[f] predicts + one correct) per filter inside ONE thread team (CPU baseline)."""
         B = nominal.shape[0]
@@ -281,6 +302,16 @@ def refraction_triangulate(p, left8, right8):
     lib.fbv_refraction_triangulate(C.byref(p), _dp(np.ascontiguousarray(left8, np.float64)),
                                    _dp(np.ascontiguousarray(right8, np.float64)), _dp(out))
     return out.reshape(4, 3)
+
+
+def project_stereo(p, Xcam, stereo=True):
+    """forward flat-port projection of points (n, 3) of the left camera frame -> (uvL (n,2), uvR (n,2) or None, ok (n,))"""
+    lib = load()
+    X = np.ascontiguousarray(Xcam, np.float64).reshape(-1, 3)
+    uvL, uvR, ok = np.zeros((len(X), 2)), np.zeros((len(X), 2)), np.zeros(len(X), bool)
+    for i in range(len(X)):
+        ok[i] = bool(lib.fbv_project_stereo(C.byref(p), _dp(X[i]), _dp(uvL[i]), _dp(uvR[i]) if stereo else None))
+    return uvL, (uvR if stereo else None), ok
 
 
 def marker_pose(corners12):

@@ -283,3 +283,72 @@ void fbv_marker_pose(const double corners[12], double pos[3], double quat[4], do
     rotmat_to_quat(rot, quat);
     memcpy(pos, P1, 3 * sizeof(double));
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Forward flat-port projection (NOT in the reference, which only back-projects): the normalised image point
+ * whose ray -- refracted air -> glass -> water exactly as RefractionTriangulation builds it (vision.cpp:505-552) --
+ * passes through a given point.  The ray stays in the plane spanned by the port normal and the point, so this
+ * is one monotone scalar equation in t = tan(theta_air):
+ *     rho = d_air t + d_glass tan(theta_glass) + (z - d_air - d_glass) tan(theta_water),
+ *     sin(theta_glass) = (n_air / n_glass) sin(theta_air),  sin(theta_water) = (n_air / n_water) sin(theta_air),
+ * with z the depth of the point along the normal and rho its distance from the axis; solved by Newton.
+ * Pinned through the reference's own back-projection: project -> fbv_refraction_triangulate returns the point
+ * (tests/test_oracle_cpu.py), and the recorded corners.txt pixels are recovered from their triangulated points.
+ * Xp: point in the camera's refraction frame (the frame of the rays of vision.cpp:496-552, i.e. before the axis
+ * flip of :597-599).  Returns 0 if the point is not in front of the port. */
+static double lateral_offset(const fbv_params* p, double t, double z, double* dLdt)
+{
+    const double a0 = p->n_air / p->n_glass, a1 = p->n_air / p->n_water;
+    const double s = t / sqrt(1 + t * t), dsdt = 1 / ((1 + t * t) * sqrt(1 + t * t));
+    const double cg = sqrt(1 - a0 * a0 * s * s), cw = sqrt(1 - a1 * a1 * s * s);
+    const double zw = z - p->d_air - p->d_glass;
+    if (dLdt) *dLdt = p->d_air + (p->d_glass * a0 / (cg * cg * cg) + zw * a1 / (cw * cw * cw)) * dsdt;
+    return p->d_air * t + p->d_glass * a0 * s / cg + zw * a1 * s / cw;
+}
+
+int fbv_refraction_project(const fbv_params* p, const double Xp[3], double uv[2])
+{
+    const double* n = p->normal;
+    const double z = dot3(Xp, n);
+    if (!(z > p->d_air + p->d_glass)) return 0;
+    double lat[3] = { Xp[0] - z * n[0], Xp[1] - z * n[1], Xp[2] - z * n[2] };
+    const double rho = nrm3(lat);
+    double t = rho / z;                               /* pin-hole start; the water bends the ray towards the axis */
+    for (int it = 0; it < 60; ++it) {
+        double dL, L = lateral_offset(p, t, z, &dL);
+        double step = (L - rho) / dL;
+        t -= step;
+        if (t < 0) t = 0;
+        if (fabs(step) <= 1e-16 * (1 + t)) break;
+    }
+    const double k = (rho > 0) ? t / rho : 0.0;
+    const double D[3] = { n[0] + k * lat[0], n[1] + k * lat[1], n[2] + k * lat[2] };
+    uv[0] = D[0] / D[2];
+    uv[1] = D[1] / D[2];
+    return 1;
+}
+
+/* a point given in the LEFT camera frame as the triangulation returns it (after the flip of vision.cpp:597-599)
+ * -> left and right normalised image points */
+int fbv_project_stereo(const fbv_params* p, const double Xcam[3], double uvL[2], double uvR[2])
+{
+    double R_RL[9], tmp[3], P_LR[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += p->R_IL[3 * i + k] * p->R_IR[3 * j + k];
+            R_RL[3 * i + j] = acc;
+        }
+    m3v(R_RL, p->P_RI, tmp);
+    for (int i = 0; i < 3; ++i) P_LR[i] = p->P_LI[i] - tmp[i];
+    const double XL[3] = { -Xcam[0], -Xcam[1], Xcam[2] };            /* undo :597-599 */
+    /* X_L = R_RL X_R + P_LR (vision.cpp:555-556).  The calibration files carry 6-digit rotation matrices, so R_RL is
+     * orthonormal to 1e-5 only: the exact inverse is used, not the transpose, to stay consistent with the back-projection */
+    double d[3] = { XL[0] - P_LR[0], XL[1] - P_LR[1], XL[2] - P_LR[2] }, XR[3];
+    const double c0[3] = { R_RL[0], R_RL[3], R_RL[6] }, c1[3] = { R_RL[1], R_RL[4], R_RL[7] }, c2[3] = { R_RL[2], R_RL[5], R_RL[8] };
+    const double det = det3cols(c0, c1, c2);
+    XR[0] = det3cols(d, c1, c2) / det; XR[1] = det3cols(c0, d, c2) / det; XR[2] = det3cols(c0, c1, d) / det;
+    int ok = fbv_refraction_project(p, XL, uvL);
+    if (uvR) ok = ok && fbv_refraction_project(p, XR, uvR);
+    return ok;
+}

@@ -40,6 +40,12 @@ void fbv_normal_triangulate(const fbv_params* p, const double left[8], const dou
 /* 4 corner positions -> marker position, quaternion (wxyz), rotation (row-major) */
 void fbv_marker_pose(const double corners[12], double pos[3], double quat[4], double rot[9]);
 
+/* Forward flat-port projection (not in the reference; see vision_oracle.c): point in a camera's refraction frame
+ * -> normalised image point; and a point of the left camera frame (as triangulated, flipped) -> left / right pixels.
+ * Return 0 if the point is behind the port. */
+int fbv_refraction_project(const fbv_params* p, const double Xp[3], double uv[2]);
+int fbv_project_stereo(const fbv_params* p, const double Xcam[3], double uvL[2], double uvR[2] /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,3 +322,66 @@ def test_parity_gate_passes_fp32_rounding_and_fails_on_block_mutations():
     mut[3][0] += 1
     with pytest.raises(AssertionError):
         assert_parity(mut, ref, 32, "prev id", verbose=False)
+
+
+# ---------------------------------------------------------------- forward flat-port projection (pixel-row model)
+def test_forward_projection_inverts_the_pinned_back_projection():
+    """The pixel-row measurement model needs the forward projection the reference does not have.  The oracle's is pinned
+    through the reference's own (recording-pinned) back-projection: a corner position triangulated from the water
+    recording, projected into both cameras and triangulated again, comes back to 1e-12; single rays built exactly as
+    RefractionTriangulation builds them (vision.cpp:505-552) project back onto their pixel to 1e-14."""
+    d = np.load(os.path.join(GOLD, "vision_water.npz"))
+    p = oc.vision_params()
+    worst = 0.0
+    for c in d["corners"]:
+        X = oc.refraction_triangulate(p, c[2:10], c[10:18])
+        uvL, uvR, ok = oc.project_stereo(p, X)
+        assert ok.all()
+        for k in range(4):
+            X2 = oc.refraction_triangulate(p, np.tile(uvL[k], 4), np.tile(uvR[k], 4))[0]
+            worst = max(worst, np.abs(X2 - X[k]).max())
+        # the recorded pixels themselves are recovered to the skewness of the two recorded rays (the triangulated point is
+        # their mid-point): a few 1e-3 in normalised coordinates, far below the 0.1 a wrong index of refraction gives
+        assert np.abs(uvL.ravel() - c[2:10]).max() < 1e-2 and np.abs(uvR.ravel() - c[10:18]).max() < 1e-2
+    assert worst < 1e-12
+    # a sharpness check of the same kind as the back-projection's: n_water 1.33 instead of 1.32 moves the pixels visibly
+    q = oc.vision_params()
+    q.n_water = 1.33
+    X = oc.refraction_triangulate(p, d["corners"][0][2:10], d["corners"][0][10:18])
+    assert np.abs(oc.project_stereo(q, X)[0] - oc.project_stereo(p, X)[0]).max() > 1e-4
+    # behind the port: refused
+    assert not oc.project_stereo(p, [[0.0, 0.0, 0.01]])[2][0]
+
+
+def test_pixel_rows_pull_a_displaced_state_back():
+    """oracle-level sanity of fbo_correct_pixels: with measurements generated by projecting the TRUE corners, one update from
+    a displaced state moves the position towards the truth, the posterior covariance is symmetric positive definite and smaller
+    than the prior on the observed blocks, and markers that are not in the map contribute nothing."""
+    from fbus_ekf import capi
+    from util import pixel_scene
+    B, M, size = 24, 3, 0.28
+    prm = capi.default_params(1)
+    orc = oc.Oracle(1, 18)
+    p = oc.vision_params()
+    rng = np.random.default_rng(4)
+    truth, _, ids, left, right = pixel_scene(B, M, prm, size, seed=3)
+    assert (ids[:, 0] >= 0).all() and (ids >= 0).sum() > B               # some filters see several markers
+    P = np.broadcast_to(orc.P0(), (B, 18, 18)).copy()
+    prev = np.zeros(B, np.int32)
+    nom = truth.copy()
+    nom[:, 0:3] += rng.normal(0, 0.01, (B, 3))                           # displaced prior (sigma_p = 1e-2)
+    from fbus_ekf import synth
+    rot = synth.q2R(nom[:, 6:10]).reshape(B, 9)
+    for stereo in (False, True):
+        n2, r2, P2, pv = nom.copy(), rot.copy(), P.copy(), prev.copy()
+        ok = orc.correct_pixels(n2, r2, P2, pv, ids, left, right if stereo else None, size, 1e-6, p)
+        assert ok.all()
+        before = np.linalg.norm(nom[:, 0:3] - truth[:, 0:3], axis=1)
+        after = np.linalg.norm(n2[:, 0:3] - truth[:, 0:3], axis=1)
+        assert np.median(after / before) < (0.5 if stereo else 0.8)
+        assert np.abs(P2 - np.swapaxes(P2, 1, 2)).max() < 1e-18 and np.linalg.eigvalsh(P2).min() > 0
+        assert (np.einsum("bii->bi", P2)[:, [0, 1, 2, 6, 7, 8]] < np.einsum("bii->bi", P)[:, [0, 1, 2, 6, 7, 8]]).all()
+    ids9 = np.full((B, M), 9, np.int32)
+    n2, r2, P2, pv = nom.copy(), rot.copy(), P.copy(), prev.copy()
+    assert not orc.correct_pixels(n2, r2, P2, pv, ids9, left, right, size, 1e-6, p).any()
+    assert np.array_equal(n2, nom) and np.array_equal(P2, P)

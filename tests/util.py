@@ -161,3 +161,58 @@ def assert_parity(got, ref, dtype, what, state_tol=STATE_TOL, cov_tol=COV_TOL, p
     assert e["prev_equal"], f"{what}: prev marker id"
     assert e["asym"] == 0, f"{what}: covariance not exactly symmetric"
     return e
+
+
+# ---- synthetic stereo-pixel scenes for the pixel-row measurement model (tests only) -----------------------------------
+def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None):
+    """B filters, each looking at one map marker from 0.4 - 1.0 m (pose built with replay.pose_from_marker), plus whichever
+    other map markers happen to be in front of the port; up to M visible markers per filter.  Returns
+    (nominal (B,19), rot (B,9), ids (B,M) with -1 padding, left (B,M,8), right (B,M,8)): the flat-port projections of the true
+    corners (oracle forward model) + `noise`.  `nominal` supplies v / ba / bg / g (p and q are overwritten)."""
+    import oracle_capi as oc
+    from fbus_ekf import replay, synth
+    rng = np.random.default_rng(seed)
+    p = oc.vision_params()
+    R_IL, P_IL, _ = synth.camera_constants(prm)
+    mids, mpos, mquat = synth.marker_table(prm)
+    c = np.array([[0, 0, 0], [0, size, 0], [size, size, 0], [size, 0, 0.0]])
+    nom = np.zeros((B, 19)) if nominal is None else np.array(nominal, float)
+    if nominal is None:
+        nom[:, 16] = 9.8
+    ids = np.full((B, M), -1, np.int32)
+    left, right = np.zeros((B, M, 8)), np.zeros((B, M, 8))
+    def corners_in_camera(b, k):
+        R0 = synth.q2R(nom[b, 6:10])
+        world = mpos[k] + (synth.q2R(mquat[k]) @ c.T).T
+        return (R_IL @ (R0.T @ (world - nom[b, 0:3] - R0 @ P_IL).T)).T
+
+    def visible(cam):
+        return cam[:, 2].min() > 0.25 and np.abs(cam[:, :2] / cam[:, 2:3]).max() < 1.5
+
+    for b in range(B):
+        while True:                                                            # until the chosen marker is in view
+            k0 = int(rng.integers(len(mids)))
+            yq = np.array([0.0, 1.0, 0.0, 0.0]) + rng.normal(0, 0.15, 4)
+            yq /= np.linalg.norm(yq)
+            yp = np.array([rng.normal(0, 0.08), rng.normal(0, 0.08), rng.uniform(0.6, 1.2)])
+            pp, qq, RR = replay.pose_from_marker(np.concatenate([[mids[k0]], yp, yq]), prm)
+            nom[b, 0:3], nom[b, 6:10] = pp, qq / np.linalg.norm(qq)
+            if visible(corners_in_camera(b, k0)):
+                break
+        order = [k0] + [k for k in rng.permutation(len(mids)) if k != k0]
+        m = 0
+        for k in order:
+            cam = corners_in_camera(b, k)
+            if not visible(cam):
+                continue
+            uvL, uvR, ok = oc.project_stereo(p, cam)
+            if not ok.all():
+                continue
+            ids[b, m] = mids[k]
+            left[b, m] = uvL.ravel() + (rng.normal(0, noise, 8) if noise else 0)
+            right[b, m] = uvR.ravel() + (rng.normal(0, noise, 8) if noise else 0)
+            m += 1
+            if m == M:
+                break
+    rot = synth.q2R(nom[:, 6:10]).reshape(B, 9)
+    return nom, rot, ids, left, right
