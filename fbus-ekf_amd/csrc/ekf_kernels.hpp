@@ -823,7 +823,14 @@ __device__ __forceinline__ void pixel_info(InfoAcc<T>& acc, const T* pqr, const 
         // refraction frame of the left camera: the triangulation's axis flip undone (vision.cpp:597-599)
         const T XL[3] = { -X[0], -X[1], X[2] };
         auto rows = [&](const T* Xr, const T* y, const T* Mx /* d Xr / d X, 3 x 3 */) {
-            if (!(dot3(Xr, vc.nrm) > vc.d_air + vc.d_glass)) return;          // behind the port: no rows
+            // in front of the port and inside its field of view (in water the ray cannot lean further than
+            // asin(n_air / n_water); 0.9 of that limit): otherwise the corner contributes no rows
+            {
+                const T z = dot3(Xr, vc.nrm), zw = z - vc.d_air - vc.d_glass, a1 = vc.alpha0 * vc.alpha1;
+                const T l0 = Xr[0] - z * vc.nrm[0], l1 = Xr[1] - z * vc.nrm[1], l2 = Xr[2] - z * vc.nrm[2];
+                const T lim = T(0.9) * zw * a1;
+                if (!(zw > T(0)) || !((l0 * l0 + l1 * l1 + l2 * l2) * (T(1) - a1 * a1) < lim * lim)) return;
+            }
             T uv[2], J[6];
             refraction_project(vc, Xr, uv, J);
 #pragma unroll

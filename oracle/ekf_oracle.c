@@ -782,21 +782,28 @@ int fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_p
                     J3[a * n + b] = -acc;
                     J3[a * n + 6 + b] = Bm[3 * a + b];
                 }
+            /* each camera on its own: a corner outside one camera's view still gives the other camera's rows */
             double uvL[2], uvR[2], Jp[4][3];
-            if (!fbv_project_stereo(vp, X, uvL, right ? uvR : NULL)) continue;     /* behind the port: no rows */
+            const int okL = fbv_project_camera(vp, X, 0, uvL);
+            const int okR = right ? fbv_project_camera(vp, X, 1, uvR) : 0;
             const double eps = 1e-6;
             for (int c = 0; c < 3; ++c) {
-                double Xp[3] = { X[0], X[1], X[2] }, Xm[3] = { X[0], X[1], X[2] }, aL[2], aR[2], bL[2], bR[2];
+                double Xp[3] = { X[0], X[1], X[2] }, Xm[3] = { X[0], X[1], X[2] }, a[2], b[2];
                 Xp[c] += eps; Xm[c] -= eps;
-                fbv_project_stereo(vp, Xp, aL, right ? aR : NULL);
-                fbv_project_stereo(vp, Xm, bL, right ? bR : NULL);
-                Jp[0][c] = (aL[0] - bL[0]) / (2 * eps); Jp[1][c] = (aL[1] - bL[1]) / (2 * eps);
-                if (right) { Jp[2][c] = (aR[0] - bR[0]) / (2 * eps); Jp[3][c] = (aR[1] - bR[1]) / (2 * eps); }
+                if (okL) {
+                    fbv_project_camera(vp, Xp, 0, a); fbv_project_camera(vp, Xm, 0, b);
+                    Jp[0][c] = (a[0] - b[0]) / (2 * eps); Jp[1][c] = (a[1] - b[1]) / (2 * eps);
+                }
+                if (okR) {
+                    fbv_project_camera(vp, Xp, 1, a); fbv_project_camera(vp, Xm, 1, b);
+                    Jp[2][c] = (a[0] - b[0]) / (2 * eps); Jp[3][c] = (a[1] - b[1]) / (2 * eps);
+                }
             }
             const double* yl = left + 8 * sel[j] + 2 * k;
             const double* yr = right ? right + 8 * sel[j] + 2 * k : NULL;
             const double res[4] = { yl[0] - uvL[0], yl[1] - uvL[1], yr ? yr[0] - uvR[0] : 0, yr ? yr[1] - uvR[1] : 0 };
-            for (int q = 0; q < rows_c; ++q) {
+            for (int q = 0; q < 4; ++q) {
+                if ((q < 2 && !okL) || (q >= 2 && !okR)) continue;
                 double* Hq = H + (size_t)m * n;
                 for (int c = 0; c < n; ++c) Hq[c] = Jp[q][0] * J3[c] + Jp[q][1] * J3[n + c] + Jp[q][2] * J3[2 * n + c];
                 r[m] = res[q];
@@ -805,7 +812,8 @@ int fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_p
             }
         }
     }
-    if (m == 0) return 0;
+    (void)rows_c;
+    if (m == 0) return 1;                  /* markers of the map were seen, none of their corners is in view: a no-op update */
     dense_update(s, prm, m, H, r, Rd);
     return 1;
 }

@@ -313,6 +313,12 @@ int fbv_refraction_project(const fbv_params* p, const double Xp[3], double uv[2]
     if (!(z > p->d_air + p->d_glass)) return 0;
     double lat[3] = { Xp[0] - z * n[0], Xp[1] - z * n[1], Xp[2] - z * n[2] };
     const double rho = nrm3(lat);
+    /* field of view of the flat port: in water the ray cannot lean further than asin(n_air / n_water) (49.3 deg) however
+     * steep it leaves the camera; points beyond 0.9 of that limit are treated as not visible (no rows) */
+    {
+        const double a1 = p->n_air / p->n_water;
+        if (!(rho < 0.9 * (z - p->d_air - p->d_glass) * a1 / sqrt(1 - a1 * a1))) return 0;
+    }
     double t = rho / z;                               /* pin-hole start; the water bends the ray towards the axis */
     for (int it = 0; it < 60; ++it) {
         double dL, L = lateral_offset(p, t, z, &dL);
@@ -329,9 +335,11 @@ int fbv_refraction_project(const fbv_params* p, const double Xp[3], double uv[2]
 }
 
 /* a point given in the LEFT camera frame as the triangulation returns it (after the flip of vision.cpp:597-599)
- * -> left and right normalised image points */
-int fbv_project_stereo(const fbv_params* p, const double Xcam[3], double uvL[2], double uvR[2])
+ * -> normalised image point of ONE camera (which = 0 left, 1 right) */
+int fbv_project_camera(const fbv_params* p, const double Xcam[3], int which, double uv[2])
 {
+    const double XL[3] = { -Xcam[0], -Xcam[1], Xcam[2] };            /* undo :597-599 */
+    if (which == 0) return fbv_refraction_project(p, XL, uv);
     double R_RL[9], tmp[3], P_LR[3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
@@ -341,14 +349,19 @@ int fbv_project_stereo(const fbv_params* p, const double Xcam[3], double uvL[2],
         }
     m3v(R_RL, p->P_RI, tmp);
     for (int i = 0; i < 3; ++i) P_LR[i] = p->P_LI[i] - tmp[i];
-    const double XL[3] = { -Xcam[0], -Xcam[1], Xcam[2] };            /* undo :597-599 */
     /* X_L = R_RL X_R + P_LR (vision.cpp:555-556).  The calibration files carry 6-digit rotation matrices, so R_RL is
      * orthonormal to 1e-5 only: the exact inverse is used, not the transpose, to stay consistent with the back-projection */
     double d[3] = { XL[0] - P_LR[0], XL[1] - P_LR[1], XL[2] - P_LR[2] }, XR[3];
     const double c0[3] = { R_RL[0], R_RL[3], R_RL[6] }, c1[3] = { R_RL[1], R_RL[4], R_RL[7] }, c2[3] = { R_RL[2], R_RL[5], R_RL[8] };
     const double det = det3cols(c0, c1, c2);
     XR[0] = det3cols(d, c1, c2) / det; XR[1] = det3cols(c0, d, c2) / det; XR[2] = det3cols(c0, c1, d) / det;
-    int ok = fbv_refraction_project(p, XL, uvL);
-    if (uvR) ok = ok && fbv_refraction_project(p, XR, uvR);
+    return fbv_refraction_project(p, XR, uv);
+}
+
+/* both cameras; returns 1 only if the point is in view of every camera asked for */
+int fbv_project_stereo(const fbv_params* p, const double Xcam[3], double uvL[2], double uvR[2])
+{
+    int ok = fbv_project_camera(p, Xcam, 0, uvL);
+    if (uvR) ok = fbv_project_camera(p, Xcam, 1, uvR) && ok;
     return ok;
 }

@@ -164,7 +164,7 @@ def assert_parity(got, ref, dtype, what, state_tol=STATE_TOL, cov_tol=COV_TOL, p
 
 
 # ---- synthetic stereo-pixel scenes for the pixel-row measurement model (tests only) -----------------------------------
-def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None):
+def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None, depth=(0.6, 1.2)):
     """B filters, each looking at one map marker from 0.4 - 1.0 m (pose built with replay.pose_from_marker), plus whichever
     other map markers happen to be in front of the port; up to M visible markers per filter.  Returns
     (nominal (B,19), rot (B,9), ids (B,M) with -1 padding, left (B,M,8), right (B,M,8)): the flat-port projections of the true
@@ -187,17 +187,18 @@ def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None):
         return (R_IL @ (R0.T @ (world - nom[b, 0:3] - R0 @ P_IL).T)).T
 
     def visible(cam):
-        return cam[:, 2].min() > 0.25 and np.abs(cam[:, :2] / cam[:, 2:3]).max() < 1.5
+        return cam[:, 2].min() > 0.25 and (np.linalg.norm(cam[:, :2], axis=1) / cam[:, 2]).max() < 0.8   # well inside the port's view
 
     for b in range(B):
         while True:                                                            # until the chosen marker is in view
             k0 = int(rng.integers(len(mids)))
             yq = np.array([0.0, 1.0, 0.0, 0.0]) + rng.normal(0, 0.15, 4)
             yq /= np.linalg.norm(yq)
-            yp = np.array([rng.normal(0, 0.08), rng.normal(0, 0.08), rng.uniform(0.6, 1.2)])
+            yp = np.array([rng.normal(0, 0.08), rng.normal(0, 0.08), rng.uniform(*depth)])
             pp, qq, RR = replay.pose_from_marker(np.concatenate([[mids[k0]], yp, yq]), prm)
             nom[b, 0:3], nom[b, 6:10] = pp, qq / np.linalg.norm(qq)
-            if visible(corners_in_camera(b, k0)):
+            cam0 = corners_in_camera(b, k0)
+            if visible(cam0) and oc.project_stereo(p, cam0)[2].all():
                 break
         order = [k0] + [k for k in rng.permutation(len(mids)) if k != k0]
         m = 0
