@@ -85,7 +85,7 @@ public:
     { check(fbus_ekf_frame_dev(h_, K, accel, gyro, dt, 0, M, ids, pos, quat, int(mode), nullptr), "frame_dev"); }
 
     // correct() from corner pixels (north-star extension): left / right (B, M, 8) normalised image points, right may be null
-    void correct_pixels(int M, const int32_t* ids, const T* left, const T* right = nullptr, const uint8_t* skip = nullptr)
+    void correct_pixels(int M, const int32_t* ids, const Real* left, const Real* right = nullptr, const uint8_t* skip = nullptr)
     { check(fbus_ekf_correct_pixels(h_, M, ids, left, right, skip), "correct_pixels"); }
 
     std::vector<uint8_t> applied() const
