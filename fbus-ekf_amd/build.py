@@ -63,10 +63,12 @@ def _stale(obj, src):
 
 
 def needs_build():
+    """the shared object is older than a source (the objects are a build cache: they do not travel with the library)"""
     if not os.path.exists(OUT):
         return True
-    return any(_stale(os.path.join(OBJDIR, name + ".o"), src) for name, src, _ in units()) or \
-        any(os.path.getmtime(os.path.join(OBJDIR, name + ".o")) > os.path.getmtime(OUT) for name, _, _ in units())
+    t = os.path.getmtime(OUT)
+    srcs = {src for _, src, _ in units()} | set(HEADERS) | {os.path.abspath(__file__)}
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in srcs)
 
 
 def build(force=False, verbose=False, only=None, jobs=None):
