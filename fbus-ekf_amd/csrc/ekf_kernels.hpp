@@ -57,6 +57,12 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_CORRECT_LD
 #define FBUS_X_CORRECT_LD AUX_NT       // load policy of the covariance in the correct kernels
 #endif
+#ifndef FBUS_X_CORRECT_STAGGER_BIT
+#define FBUS_X_CORRECT_STAGGER_BIT 3
+#endif
+#ifndef FBUS_X_CORRECT_STAGGER
+#define FBUS_X_CORRECT_STAGGER 0   // experiment: every other wave of an XCD sleeps this many x 3.9 us before it requests its record
+#endif
 #ifndef FBUS_X_FRAME_WAVES
 #define FBUS_X_FRAME_WAVES 1    // __launch_bounds__ waves per SIMD of the fused frame kernel (2 = at most 256 registers)
 #endif
@@ -400,6 +406,12 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     T P[RC::NCOVP], nom[L::NNOM];
     __shared__ MarkerLDS<T> tbl;
     MarkerGroup<T, G> mg;
+    if (FBUS_X_CORRECT_STAGGER > 0 && ((blockIdx.x >> FBUS_X_CORRECT_STAGGER_BIT) & 1)) {
+#pragma unroll
+        for (int i = 0; i < FBUS_X_CORRECT_STAGGER / 4; ++i) __builtin_amdgcn_s_sleep(127);
+        if (FBUS_X_CORRECT_STAGGER % 4) __builtin_amdgcn_s_sleep(32 * (FBUS_X_CORRECT_STAGGER % 4) - 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // the stacked path asks for the predict-invariant covariance tail behind the fold: fewer registers are tied up
     // while the rows are built, and the first scalar update only needs it for its last rows
     constexpr int C_SPLIT = JOINT ? FBUS_X_SPLIT : RC::NCH;

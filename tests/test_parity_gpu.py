@@ -636,3 +636,71 @@ def test_parity_gate_goes_red_on_a_mutated_result():
     mut[2][:, 0, 1] *= 1.0 + 1e-6                                                          # asymmetry
     with pytest.raises(AssertionError):
         assert_parity(mut, ref, 32, "asymmetric", verbose=False)
+
+
+def test_frame_entry_points_validate_before_they_launch():
+    """a rejected frame call must not leave the state advanced by its K predicts (both entry points check K, M, the pointers
+    and the mode up front), and the Python mirror refuses wrongly sized device arrays"""
+    import ctypes as C
+    import torch
+    B, K, M = 256, 3, 2
+    prm, nom, rot, P, prev = _batch(B, 0, 18)
+    acc, gyr = _imu(0, B, 0, K, nom)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_acc, d_gyr, d_dt = f32(acc), f32(gyr), f32(np.full(K, DT[0]))
+    d_ids, d_pos, d_quat = torch.from_numpy(ids).to(dev), f32(pos), f32(quat)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    with BatchedFilter(B, prm) as flt:
+        flt.set_state(nom, rot, P, prev)
+        before = flt.get_state()
+        lib, h = flt._lib, flt._h
+        for fn in (lib.fbus_ekf_frame_dev, lib.fbus_ekf_frame_fused_dev):
+            assert fn(h, K, None, p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1      # NULL accel
+            assert fn(h, K, p(d_acc), p(d_gyr), p(d_dt), 0, 17, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1  # M > FBUS_MAX_VISIBLE
+            assert fn(h, K, p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), None, p(d_quat), 1, None) == 1       # NULL pos
+            assert fn(h, K, p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 7, None) == 4   # unknown mode
+            assert fn(h, -1, p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1
+        flt.sync()
+        after = flt.get_state()
+        assert all(np.array_equal(x, y) for x, y in zip(before, after))         # nothing was launched
+        with pytest.raises(ValueError):
+            flt.frame(d_acc, d_gyr[:2], d_dt, d_ids, d_pos, d_quat, 1)            # gyro of the wrong size
+        with pytest.raises(ValueError):
+            flt.frame(d_acc, d_gyr, d_dt, d_ids, d_pos[:, :1], d_quat, 1)         # pos of the wrong size / not contiguous
+        flt.frame(d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, 1)                    # the valid call still works
+        flt.sync()
+        assert not np.array_equal(flt.get_state()[0], before[0])
+
+
+def test_streams_are_ordered_by_wait_and_signal():
+    """the handle's own stream is non-blocking: inputs produced on torch's stream are ordered in with wait_stream, results are
+    handed back with signal_stream, and set_stream(torch stream) shares the stream outright (handle 0 = the legacy default stream)"""
+    import torch
+    B = 4096
+    prm, nom, rot, P, prev = _batch(B, 0, 18)
+    acc, gyr = _imu(0, B, 0, 1, nom)
+    dev = torch.device("cuda:0")
+    eng = OracleEngine(B, 0, 18)
+    eng.set_state(nom, rot, P, prev)
+    eng.predict(acc[0], gyr[0], DT)
+    a64 = torch.from_numpy(acc[0]).to(dev); g64 = torch.from_numpy(gyr[0]).to(dev)
+    d_dt = torch.full((1,), float(DT[0]), dtype=torch.float32, device=dev)
+    for share in (False, True):
+        with BatchedFilter(B, prm) as flt:
+            flt.set_state(nom, rot, P, prev)
+            if share:
+                flt.set_stream(torch.cuda.current_stream())           # handle value 0: the legacy default stream
+            big = torch.randn(4096, 4096, device=dev)
+            for _ in range(4):
+                big = big @ big * 1e-3                                # keeps torch's stream busy ahead of the casts
+            d_acc, d_gyr = a64.to(torch.float32), g64.to(torch.float32)   # produced on torch's stream, behind the matmuls
+            if not share:
+                flt.wait_stream(torch.cuda.current_stream())
+            flt.predict(d_acc, d_gyr, d_dt)
+            if not share:
+                flt.signal_stream(torch.cuda.current_stream())
+            torch.cuda.current_stream().synchronize()                 # NOT a device-wide sync: only torch's stream
+            got = flt.get_state()
+        assert state_rel_err(got[0], eng.nominal, eng.P)[0] <= STATE_TOL and cov_rel_err_blockwise(got[2], eng.P) <= COV_BLOCK_TOL
