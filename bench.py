@@ -318,7 +318,10 @@ def main():
     if not shared and local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but the box has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)                        # before the process group: RCCL binds to the current device
-    if world > 1:
+    # FBUS_BENCH_FORCE_RCCL=1: create the RCCL process group even with ONE rank, so that a 1-GPU box runs every collective of
+    # the N > 1 path (barrier, all-reduce, all-gather of the records) through RCCL itself (tests/test_bench_frontdoor.py)
+    force_pg = os.environ.get("FBUS_BENCH_FORCE_RCCL") == "1"
+    if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")

@@ -24,7 +24,7 @@ def weak_range(per_rank, rank):
 def gather_records(local, dist=None, world=1):
     """All-gathers equally sized 1-D record tensors; returns the list of per-rank tensors
     (a single-element list without a process group)."""
-    if dist is None or world == 1:
+    if dist is None:
         return [local]
     import torch
     out = [torch.empty_like(local) for _ in range(world)]
@@ -35,7 +35,7 @@ def gather_records(local, dist=None, world=1):
 def gather_records_ragged(local, dist=None, world=1, device="cpu"):
     """All-gather of 1-D record tensors whose lengths may differ by a tile (strong scaling with a total that is not
     a multiple of 64 x world): padded to the longest shard for the collective, trimmed afterwards."""
-    if dist is None or world == 1:
+    if dist is None:
         return [local]
     import torch
     n = torch.tensor([local.numel()], dtype=torch.int64, device=device)
@@ -53,7 +53,7 @@ def gather_records_ragged(local, dist=None, world=1, device="cpu"):
 
 
 def sum_over_ranks(value, dist=None, world=1, device="cpu"):
-    if dist is None or world == 1:
+    if dist is None:
         return float(value)
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
@@ -62,7 +62,7 @@ def sum_over_ranks(value, dist=None, world=1, device="cpu"):
 
 
 def max_over_ranks(value, dist=None, world=1, device="cpu"):
-    if dist is None or world == 1:
+    if dist is None:
         return float(value)
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)

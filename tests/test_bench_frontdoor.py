@@ -118,3 +118,12 @@ def test_two_rank_rehearsal_weak_and_strong_scaling():
     assert strong["gathered_bytes"] == 8192 * 800 and strong["state_finite"]
     # value counts the filters of ALL ranks
     assert strong["value"] == pytest.approx(8192 * 23 * 3 / (strong["ms_per_step"] * 3e-3), rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_single_rank_through_rccl_itself():
+    """one rank, but with the RCCL process group created (FBUS_BENCH_FORCE_RCCL=1): the barrier, the max / sum all-reduces and the
+    all-gather of the packed records that the N > 1 path issues all run through RCCL on this GPU"""
+    out = _run_bench(["--batch", "4096"], _env(FBUS_BENCH_FORCE_RCCL="1", MASTER_PORT="29547"))
+    assert out["n_gpus"] == 1 and out["config"]["collective_backend"] == "nccl" and out["config"]["ranks_seen"] == 1
+    assert out["gathered_bytes"] == 4096 * 800 and out["state_finite"] and out["gather_ms"] > 0
