@@ -18,8 +18,9 @@
       waterdata/dataset-06: imu.txt, image.txt; GPL-3.0, (c) the FBUS-EKF authors) -- inputs only,
       float64, compressed -- for the full-length replay tests (the oracle runs beside
       the device in the test; no expected outputs are stored).  fusion.txt's gyro-bias
-      columns (the only part of the recorded C++ output that survives the revision
-      change) ride along as a loose sanity band.
+      columns and its pose columns ride along: the recorded C++ output comes from an older
+      revision with its own world frame, so only frame-independent
+      quantities can be compared -- the initial gyro bias and the RELATIVE motion of the IMU.
 
 The EKF vectors are NOT reference outputs (the reference cannot run here): they pin
 the two restatements and the HIP kernels to each other ("parity unpinned").
@@ -177,7 +178,9 @@ def recordings():
     for tag, d in (("land", "landdata/dataset-02"), ("water", "waterdata/dataset-06")):
         out[f"{tag}_imu"] = np.loadtxt(f"{REF}/{d}/imu.txt")
         out[f"{tag}_image"] = np.loadtxt(f"{REF}/{d}/image.txt")
-        out[f"{tag}_fusion_bg"] = np.loadtxt(f"{REF}/{d}/fusion.txt")[:, [0, 14, 15, 16]]
+        fus = np.loadtxt(f"{REF}/{d}/fusion.txt")
+        out[f"{tag}_fusion_bg"] = fus[:, [0, 14, 15, 16]]
+        out[f"{tag}_fusion_pose"] = fus[:, 0:8]          # t, p(3), q(wxyz): the recorded fused trajectory (older revision)
     np.savez_compressed(os.path.join(HERE, "recordings.npz"), **out)
 
 

@@ -217,3 +217,34 @@ def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None, depth=(0.6, 1.
                 break
     rot = synth.q2R(nom[:, 6:10]).reshape(B, 9)
     return nom, rot, ids, left, right
+
+
+# ---- the reference's recorded fused trajectory (older revision, own world frame): frame-independent comparison ----------
+def relative_motion_gap(states, fusion_pose, stride=5, skip=40):
+    """frame-independent comparison of two trajectories: T(t0)^-1 T(t) of each; returns (max position gap [m], max rotation gap
+    [deg], largest excursion of the recorded trajectory [m], (min, max) ratio of the travelled distances beyond 0.2 m)"""
+    from fbus_ekf import synth
+
+    def T(p, q):
+        M = np.eye(4); M[:3, :3] = synth.q2R(np.asarray(q, float)); M[:3, 3] = p
+        return M
+    tf = fusion_pose[:, 0]
+    T0o = T0f = None
+    dp = dr = exc = 0.0
+    ratio = []
+    for k in range(skip, len(states), stride):
+        j = int(np.argmin(np.abs(tf - states[k, 0])))
+        if abs(tf[j] - states[k, 0]) > 0.03:
+            continue
+        To, Tf = T(states[k, 1:4], states[k, 7:11]), T(fusion_pose[j, 1:4], fusion_pose[j, 4:8])
+        if T0o is None:
+            T0o, T0f = To, Tf
+        Ro, Rf = np.linalg.inv(T0o) @ To, np.linalg.inv(T0f) @ Tf
+        dp = max(dp, np.linalg.norm(Ro[:3, 3] - Rf[:3, 3]))
+        dr = max(dr, np.degrees(np.arccos(np.clip((np.trace(Ro[:3, :3].T @ Rf[:3, :3]) - 1) / 2, -1, 1))))
+        exc = max(exc, np.linalg.norm(Rf[:3, 3]))
+        if np.linalg.norm(Rf[:3, 3]) > 0.2:
+            ratio.append(np.linalg.norm(Ro[:3, 3]) / np.linalg.norm(Rf[:3, 3]))
+    return dp, dr, exc, (min(ratio), max(ratio))
+
+
