@@ -13,8 +13,12 @@
  * in this image and ships no known-answer test for ImuUpdate/MeasureUpdate;
  * its recorded fusion.txt comes from an older revision and does not
  * reproduce.  What pins this file instead: an independently written numpy twin
- * (oracle/ekf_oracle_np.py) that agrees to <=1e-12, algebraic invariants, and
- * the loose gyro-bias band of fusion.txt.  The neighbouring vision chain
+ * (oracle/ekf_oracle_np.py) that agrees to <=1e-12; finite-difference checks of the
+ * two Jacobians against the oracle's own non-linear functions
+ * (tests/test_oracle_jacobians_cpu.py, via fbo_transition / fbo_measurement);
+ * algebraic invariants; and two loose bands of the recorded fusion.txt -- the
+ * initial gyro bias and the RELATIVE motion of the IMU over the land recording
+ * (0.1 m / 6 deg over a 0.85 m excursion; tests/test_oracle_cpu.py).  The neighbouring vision chain
  * (oracle/vision_oracle.c) IS pinned by the reference's recorded
  * corners.txt -> image.txt data.
  *
