@@ -433,12 +433,16 @@ def main():
             el2 = timed(torch, w2.step, steps2, warm2, before_timing=lambda: (w2.flt.timing_reset(), w2.flt._keep.clear()))
             p_ms, p_n = w2.flt.timing_read(capi.KERNEL_PREDICT)
             c_ms, c_n = w2.flt.timing_read(capi.KERNEL_CORRECT)
+            w2.flt.timing_enable(False)
+            w2.reset_state()
+            elf = timed(torch, lambda i: w2.step(i, fused=True), steps2, warm2, before_timing=lambda: w2.flt._keep.clear())
             tr2, src2 = pmc_traffic(HBM_LEG_BATCH, args, 1)
             roof2, corr2 = roofline_block(w2, p_ms, p_n, c_ms, c_n, tr2, src2)
             roof2.pop("note")
             roof2.update({"batch": HBM_LEG_BATCH, "records_MB": HBM_LEG_BATCH * 800 / 1e6, "steps": steps2,
                           "value": HBM_LEG_BATCH * STEPS_PER_BENCH_STEP * steps2 / el2, "unit_value": "EKF steps/s",
                           "correct_kernel": corr2,
+                          "fused_frame_value": HBM_LEG_BATCH * STEPS_PER_BENCH_STEP * steps2 / elf,
                           "note": "same bench pattern at 262 144 filters on one GPU: 210 MB of records + the per-step inputs "
                                   "exceed what stays resident in the 256 MB Infinity Cache between launches, so this is the "
                                   "HBM streaming rate (the guide's float4-copy ceiling is 6.29 TB/s = 0.79 of the 8 TB/s spec)"})
