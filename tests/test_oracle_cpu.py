@@ -405,3 +405,17 @@ def test_land_replay_follows_the_recorded_fused_trajectory(dialect):
     dp, dr, exc, ratio = relative_motion_gap(states, d["land_fusion_pose"])
     print(f"land, dialect {dialect}: relative-motion gap to fusion.txt {dp:.3f} m / {dr:.1f} deg over a {exc:.2f} m excursion, distance ratio {ratio[0]:.2f}..{ratio[1]:.2f}")
     assert exc > 0.8 and dp < 0.15 and dr < 8.0 and 0.8 < ratio[0] and ratio[1] < 1.15
+
+
+def test_water_replay_follows_the_recorded_fused_trajectory():
+    """the same frame-independent comparison on the underwater recording (waterdata/dataset-06, 44 s, 0.6 m excursion), C++
+    dialect (the one that uses the quaternion residual, as the program that recorded fusion.txt did): within 0.2 m / 10 deg"""
+    from fbus_ekf import capi, replay
+    from replay_ref import OracleEngine
+    from util import relative_motion_gap
+    d = np.load(os.path.join(GOLD, "recordings.npz"))
+    eng = OracleEngine(1, 1, 18)
+    states, _ = replay.replay(eng, d["water_imu"], d["water_image"], capi.default_params(1))
+    dp, dr, exc, ratio = relative_motion_gap(states, d["water_fusion_pose"])
+    print(f"water, C++ dialect: relative-motion gap to fusion.txt {dp:.3f} m / {dr:.1f} deg over a {exc:.2f} m excursion, distance ratio {ratio[0]:.2f}..{ratio[1]:.2f}")
+    assert exc > 0.5 and dp < 0.2 and dr < 10.0 and 0.7 < ratio[0] and ratio[1] < 1.15
