@@ -694,15 +694,46 @@ __device__ __forceinline__ void scalar_update(T* P, T* dx, const T* hA, const T*
 #undef PS
 }
 
+// What the rows of EVERY marker share at one linearisation point: H(1:3,1:3) = -R_IL R', R P_IL, the constant-times-Lq(q)
+// factor of the quaternion Jacobian and Q_IL (x) q*.  Built once per correct step; with M markers per frame the rows of
+// the second and later markers are ~75 instructions shorter each (the compiler does not merge them across the per-marker
+// branches by itself).  The same operations in the same order as before: results are bit for bit unchanged.
+template <typename T, int N>
+struct MarkerCommon {
+    T Hpp[9], RP[3], M1[12], tq[4];
+    __device__ __forceinline__ void build(const T* pqr, const DevConst<T>& dc)
+    {
+        using L = Lay<N>;
+        const T* q = pqr + L::OFF_Q; const T* R = pqr + L::OFF_R;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Hpp[3 * i + j] = -(l0 * R[3 * j] + l1 * R[3 * j + 1] + l2 * R[3 * j + 2]);
+            RP[i] = R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2];
+        }
+        const T qc[4] = { q[0], -q[1], -q[2], -q[3] };
+        quat_mul(dc.Q_IL, qc, tq);
+        const T w = q[0], x = q[1], y = q[2], z = q[3];
+        const T LL[12] = { -x, -y, -z,   w, -z, y,   z, w, -x,   -y, x, w };   // Lq(q)(:,2:4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                M1[3 * i + j] = dc.CL[4 * i] * LL[j] + dc.CL[4 * i + 1] * LL[3 + j] + dc.CL[4 * i + 2] * LL[6 + j] + dc.CL[4 * i + 3] * LL[9 + j];
+    }
+};
+
 // The 7 rows of one marker (map slot constants mk), linearised at the record's nominal state (which is not
-// modified until inject()): Jacobian blocks Hpp = H(1:3, p), Hpt = H(1:3, theta), Hq = H(4:7, theta) (all other
+// modified until inject()): Jacobian blocks Hpp = H(1:3, p) (in mc), Hpt = H(1:3, theta), Hq = H(4:7, theta) (all other
 // columns are zero) and the residuals rp (position rows), rq (quaternion rows).
 template <typename T, int N, int DIALECT>
-__device__ __forceinline__ void marker_rows(const T* pqr, const DevConst<T>& dc, const T* __restrict__ mk, const T* yp,
-                                            const T* yq, T (&Hpp)[9], T (&Hpt)[9], T (&rp)[3], T (&Hq)[12], T (&rq)[4])
+__device__ __forceinline__ void marker_rows(const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc,
+                                            const T* __restrict__ mk, const T* yp, const T* yq, T (&Hpt)[9], T (&rp)[3],
+                                            T (&Hq)[12], T (&rq)[4])
 {
     using L = Lay<N>;
-    const T* p = pqr + L::OFF_P3; const T* q = pqr + L::OFF_Q; const T* R = pqr + L::OFF_R;
+    const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
     T Pm[3], Qm[4];
 #pragma unroll
     for (int i = 0; i < 3; ++i) Pm[i] = mk[i];
@@ -714,7 +745,7 @@ __device__ __forceinline__ void marker_rows(const T* pqr, const DevConst<T>& dc,
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         u[i] = Pm[i] - p[i];
-        d[i] = u[i] - (R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2]);
+        d[i] = u[i] - mc.RP[i];
     }
     T ru[3];
 #pragma unroll
@@ -725,17 +756,13 @@ __device__ __forceinline__ void marker_rows(const T* pqr, const DevConst<T>& dc,
 #pragma unroll
     for (int i = 0; i < 3; ++i) hp[i] = dc.R_IL[3 * i] * t[0] + dc.R_IL[3 * i + 1] * t[1] + dc.R_IL[3 * i + 2] * t[2];
     // hq = Q_IL (x) q* (x) Qm                  MeasureUpdate.m:68 ; filter.cpp:686
-    const T qc[4] = { q[0], -q[1], -q[2], -q[3] };
-    T tmp[4], hq[4];
-    quat_mul(dc.Q_IL, qc, tmp);
-    quat_mul(tmp, Qm, hq);
+    T hq[4];
+    quat_mul(mc.tq, Qm, hq);
 
-    // H(1:3,1:3) = -R_IL R' ; H(1:3,7:9) = R_IL [R'(Pm-p)]x      MeasureUpdate.m:72-73 ; filter.cpp:691-692
+    // H(1:3,1:3) = -R_IL R' (mc.Hpp) ; H(1:3,7:9) = R_IL [R'(Pm-p)]x      MeasureUpdate.m:72-73 ; filter.cpp:691-692
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Hpp[3 * i + j] = -(l0 * R[3 * j] + l1 * R[3 * j + 1] + l2 * R[3 * j + 2]);
         Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
         Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
         Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
@@ -744,16 +771,9 @@ __device__ __forceinline__ void marker_rows(const T* pqr, const DevConst<T>& dc,
     for (int k = 0; k < 3; ++k) rp[k] = yp[k] - hp[k];
 
     // H(4:7,7:9) = Rq(Qm) [Lq(Q_IL) L2] [Lq(q) L1]   MeasureUpdate.m:74-75 ; filter.cpp:693-694
-    // evaluated right to left: M1 = CL * Lq(q)(:,2:4) with the wave-uniform constant CL, then Rq(Qm) * M1 -- only
+    // evaluated right to left: M1 = CL * Lq(q)(:,2:4) with the wave-uniform constant CL (mc.M1), then Rq(Qm) * M1 -- only
     // the marker's quaternion is read per marker (a per-marker 4x4 table cost 16 dependent loads: correct -7 %)
-    const T w = q[0], x = q[1], y = q[2], z = q[3];
-    const T LL[12] = { -x, -y, -z,   w, -z, y,   z, w, -x,   -y, x, w };   // Lq(q)(:,2:4)
-    T M1[12];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            M1[3 * i + j] = dc.CL[4 * i] * LL[j] + dc.CL[4 * i + 1] * LL[3 + j] + dc.CL[4 * i + 2] * LL[6 + j] + dc.CL[4 * i + 3] * LL[9 + j];
+    const T (&M1)[12] = mc.M1;
     const T RqM[16] = { Qm[0], -Qm[1], -Qm[2], -Qm[3],   Qm[1], Qm[0], Qm[3], -Qm[2],
                         Qm[2], -Qm[3], Qm[0], Qm[1],     Qm[3], Qm[2], -Qm[1], Qm[0] };
     // sign unification                          MeasureUpdate.m:77-81 ; filter.cpp:698-706
@@ -778,14 +798,14 @@ __device__ __forceinline__ void marker_rows(const T* pqr, const DevConst<T>& dc,
 // One marker applied row by row (the reference's 7-row update, algebraically K = P H'(H P H' + R)^-1 with the
 // diagonal R): 7 sequential scalar updates at one linearisation point.
 template <typename T, int N, int DIALECT, int COV>
-__device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const DevConst<T>& dc,
+__device__ __forceinline__ void marker_update(T* P, T* dx, const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc,
                                               const T* __restrict__ mk, const T* yp, const T* yq)
 {
-    T Hpp[9], Hpt[9], rp[3], Hq[12], rq[4];
-    marker_rows<T, N, DIALECT>(pqr, dc, mk, yp, yq, Hpp, Hpt, rp, Hq, rq);
+    T Hpt[9], rp[3], Hq[12], rq[4];
+    marker_rows<T, N, DIALECT>(pqr, dc, mc, mk, yp, yq, Hpt, rp, Hq, rq);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-        scalar_update<T, N, true, COV>(P, dx, Hpp + 3 * k, Hpt + 3 * k, rp[k], dc.r_pos);
+        scalar_update<T, N, true, COV>(P, dx, mc.Hpp + 3 * k, Hpt + 3 * k, rp[k], dc.r_pos);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         scalar_update<T, N, false, COV>(P, dx, Hq + 3 * k, Hq + 3 * k, rq[k], dc.r_quat);
@@ -842,13 +862,13 @@ struct InfoAcc {
 
 // the 7 rows of one marker into the accumulator
 template <typename T, int N, int DIALECT>
-__device__ __forceinline__ void marker_info(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc,
+__device__ __forceinline__ void marker_info(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc,
                                             const T* __restrict__ mk, const T* yp, const T* yq, T w_pos, T w_quat)
 {
-    T Hpp[9], Hpt[9], rp[3], Hq[12], rq[4];
-    marker_rows<T, N, DIALECT>(pqr, dc, mk, yp, yq, Hpp, Hpt, rp, Hq, rq);
+    T Hpt[9], rp[3], Hq[12], rq[4];
+    marker_rows<T, N, DIALECT>(pqr, dc, mc, mk, yp, yq, Hpt, rp, Hq, rq);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) acc.add6(Hpp + 3 * k, Hpt + 3 * k, rp[k], w_pos);
+    for (int k = 0; k < 3; ++k) acc.add6(mc.Hpp + 3 * k, Hpt + 3 * k, rp[k], w_pos);
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc.add3(Hq + 3 * k, rq[k], w_quat);
 }

@@ -469,12 +469,14 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         InfoAcc<T> acc;
         acc.clear();
         const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+        MarkerCommon<T, N> mc;
+        mc.build(nom, dc);
         auto fold_group = [&]() {
             mg.resolve(tbl);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (mg.slot[g] < 0) continue;
-                marker_info<T, N, DIALECT>(acc, nom, dc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
                 ++used;
             }
         };
@@ -551,7 +553,9 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
                 T mk[MK_STRIDE];
 #pragma unroll
                 for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
-                marker_info<T, N, DIALECT>(acc, nom, dc, mk, min_y, min_y + 3, T(1) / dc.r_pos, T(1) / dc.r_quat);
+                MarkerCommon<T, N> mc;
+                mc.build(nom, dc);
+                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mk, min_y, min_y + 3, T(1) / dc.r_pos, T(1) / dc.r_quat);
                 joint_factor<T>(acc, fac);
                 used = 1;
             }
@@ -561,7 +565,9 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             T mk[MK_STRIDE];
 #pragma unroll
             for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
-            marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mk, min_y, min_y + 3);
+            MarkerCommon<T, N> mc;
+            mc.build(nom, dc);
+            marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mk, min_y, min_y + 3);
             used = 1;
         }
     }
@@ -650,6 +656,8 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     constexpr bool joint = JOINT;
     const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
     if (joint) acc.clear();
+    MarkerCommon<T, N> mc;
+    mc.build(nom, dc);
     for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
         MarkerGroup<T, FBUS_MARKER_GROUP> mg;
         mg.fetch(my_ids, my_pos, my_quat, i0, last);
@@ -657,8 +665,8 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
 #pragma unroll
         for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
             if (mg.slot[g] < 0) continue;
-            if constexpr (joint) marker_info<T, N, DIALECT>(acc, nom, dc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
-            else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mg.mk[g], mg.yp[g], mg.yq[g]);
+            if constexpr (joint) marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+            else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
             ++used;
         }
     }
