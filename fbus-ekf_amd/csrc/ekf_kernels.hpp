@@ -387,7 +387,7 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
 // then runs while the covariance is still on its way in.  Lanes that are skipped or past B run along with no markers
 // and leave before the stores: an early exit in front of the loads would let the compiler sink loads into the live
 // branch, behind the covariance stream.
-template <typename T, int N, int DIALECT, int COV, bool JOINT>
+template <typename T, int N, int DIALECT, int COV, bool JOINT, bool SPLIT = (sizeof(T) == 8)>
 __global__ void __launch_bounds__(BLOCK, FBUS_X_CORRECT_WAVES)
 correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
                const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
@@ -422,7 +422,11 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     // terms from the LDS stash.  The nominal state is read a second time behind the passes instead of being held
     // across them, and the reference mode (one marker, 7 rows) goes through the same information form as the stacked
     // mode (6 passes, the same posterior) instead of holding the 37 Jacobian entries of its 7 rows live.
-    constexpr bool LEAN = sizeof(T) == 8;
+    // fp32 (SPLIT chosen by the launcher for launches of >= 2048 waves): the same form needs 194 registers instead of
+    // 355, so two waves share a SIMD and overlap each other's load / pass / store phases: 44.4 -> 41.1 us at 131 072
+    // filters, 73.0 -> 71.9 us at 262 144; with one wave per SIMD (65 536 filters) it is slower, 21.9 -> 25.4 us
+    // (the covariance is requested behind the fold instead of under it) -- gpurun_out/r02_ab8.log.
+    constexpr bool LEAN = SPLIT;
     constexpr int RS = 9;
     using Stash = LateStash<T, N, RS>;
     using Hook = RowStore<T, N, FBUS_X_CORRECT_ST>;

@@ -5,6 +5,7 @@
 //   3 fused frame (K predicts + correct in one launch)
 //   4 correct from stereo corners
 // gfx950 only.
+#include <cstdlib>
 #include "ekf_kernels.hpp"
 #include "ekf_launch.hpp"
 
@@ -48,6 +49,11 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
                                                             const DevConst<FBUS_TU_T>&);
 
 #elif FBUS_TU_FAMILY == 2
+static int correct_split_min_b()
+{
+    static const int v = [] { const char* e = getenv("FBUS_CORRECT_SPLIT_MIN_B"); return e ? atoi(e) : 2048 * BLOCK; }();
+    return v;
+}
 template <typename T, int N, int D>
 void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode,
                       bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
@@ -57,6 +63,13 @@ void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
 #define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                              \
     hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, pos, quat, \
                        mode, skip, applied, dc)
+    // fp32, stacked, simple form: from 2048 waves on (two per SIMD) the row-split instantiation (194 registers) is the
+    // faster one -- see the LEAN comment in correct_kernel; FBUS_CORRECT_SPLIT_MIN_B moves the threshold (A/B runs)
+    if (sizeof(T) == 4 && joint && !joseph && B >= correct_split_min_b()) {
+        hipLaunchKernelGGL((correct_kernel<T, N, D, COV_SIMPLE, true, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
+                           pos, quat, mode, skip, applied, dc);
+        return;
+    }
     if (joseph) { if (joint) FBUS_LAUNCH_CORRECT(COV_JOSEPH, true); else FBUS_LAUNCH_CORRECT(COV_JOSEPH, false); }
     else        { if (joint) FBUS_LAUNCH_CORRECT(COV_SIMPLE, true); else FBUS_LAUNCH_CORRECT(COV_SIMPLE, false); }
 #undef FBUS_LAUNCH_CORRECT

@@ -412,6 +412,41 @@ def test_full_batch_properties_and_shard_equality():
     assert state_rel_err_plain(full[0][sub], eng.nominal)[0] <= PLAIN_TOL
 
 
+@pytest.mark.parametrize("dialect", [0, 1])
+@pytest.mark.parametrize("n", [18, 15])
+def test_row_split_correct_of_large_launches(dialect, n):
+    """fp32 stacked correct from 2048 waves on (B >= 131 072) runs as the row-split instantiation (two waves per SIMD,
+    kernels_tu.hip): parity with the oracle on a strided subset, and the same posterior as the one-wave kernel that the two
+    half batches get (different evaluation order of the same six rank-1 passes, so fp32-close, not bit-equal)."""
+    B, M = 131072, 4
+    prm = _params(dialect)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), n)
+    nom, rot, P = _r32(nom), _r32(rot), _r32(P)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    ids[5] = -1
+    ids[70, 1:] = -1
+
+    def run(lo, hi):
+        with BatchedFilter(hi - lo, prm, nstate=n) as flt:
+            flt.set_state(nom[lo:hi], rot[lo:hi], P[lo:hi], prev[lo:hi])
+            flt.correct(ids[lo:hi], pos[lo:hi], quat[lo:hi], 1)
+            return flt.get_state(), np.asarray(flt.applied())
+
+    full, app = run(0, B)
+    halves = [run(0, B // 2), run(B // 2, B)]
+    assert np.array_equal(app, np.concatenate([h[1] for h in halves])) and app[5] == 0 and app[70] == 1
+    sub = np.unique(np.concatenate([np.arange(0, B, 1021), [5, 70, B - 1]]))
+    eng = OracleEngine(len(sub), dialect, n)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    eng.correct(ids[sub], pos[sub], quat[sub], 1)
+    assert_parity([a[sub] for a in full], eng.get_state(), 32, f"row-split correct d{dialect} n{n}")
+    one_wave = [np.concatenate([halves[0][0][k], halves[1][0][k]]) for k in range(4)]
+    e = parity_errors(full, one_wave)
+    print(f"[split vs one-wave kernel] sigma {e['sigma']:.2e} plain {e['plain']:.2e} cov block {e['cov_block']:.2e}")
+    assert e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL and e["asym"] == 0
+    assert np.abs(full[2] - np.swapaxes(full[2], 1, 2)).max() == 0
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("dialect", [0, 1])
 def test_fused_frame_equals_per_call_launches(dialect, mode):
