@@ -2,11 +2,15 @@
 """bench.py -- EKF steps/s of the batched predict/correct hot path on N MI355X.
 
 Workload (BASELINE.json / BASELINE.md section 2.1): 200 Hz IMU + 30 Hz stereo, 4 markers
-per frame, fp32, N = 18 parity layout, Matlab dialect.  One bench "step" = 0.1 s of
-simulated time for the whole batch = 20 predict launches + 3 correct launches in the
-7/7/6 pattern = 23 EKF steps per filter, every launch through the per-call C ABI (the
-state makes a full HBM round trip per EKF step).  Inputs are generated on the host with
-the seeded synthetic generator and are resident in HBM before the timed region starts.
+per frame, fp32, N = 18 parity layout, Matlab dialect.  One bench "step" = 1 s of
+simulated time for the whole batch = 30 camera frames = ten times the 7/7/6 pattern =
+200 predict launches + 30 correct launches = 230 EKF steps per filter, every launch
+through the per-call C ABI (the state makes a full HBM round trip per EKF step).  (Rounds
+1 and 2a used 0.1 s per step; with `--steps 20` the timed region was then 6 ms, short
+enough for the bracketing synchronisations to cost 3 % and for the driver's GPU-busy
+sampler to miss it.  The metric is per EKF step and does not depend on the choice.)
+Inputs are generated on the host with the seeded synthetic generator and are resident
+in HBM before the timed region starts.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]            weak scaling: 65 536 filters per GPU
   python bench.py --gpus N --total-batch 262144                  strong scaling: BASELINE config 4, the same
@@ -39,7 +43,9 @@ sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 PATTERN = (7, 7, 6)                 # predicts between corrects: 200 Hz IMU / 30 Hz stereo
-STEPS_PER_BENCH_STEP = sum(PATTERN) + len(PATTERN)      # 23 EKF steps per filter
+STEPS_PER_PATTERN = sum(PATTERN) + len(PATTERN)         # 23 EKF steps per filter in 0.1 s
+PATTERNS_PER_STEP = 10              # one bench step = 1 s of sensor time = 30 camera frames
+STEPS_PER_BENCH_STEP = STEPS_PER_PATTERN * PATTERNS_PER_STEP      # 230 EKF steps per filter
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # packed record round trip + inputs (what the per-call API implies)
 PREDICT_BYTES_API = 2 * 796 + 28
@@ -49,15 +55,15 @@ CORRECT_BYTES_API = lambda M: 2 * 796 + 32 * M
 #   correct: reads 50 chunks + 32 B per marker slot, writes 2 (p q) + 3 (v ba bg g) + 43 (covariance + prev id) + 1 B flag
 PREDICT_BYTES_MOVED = 50 * 16 + 28 + 38 * 16
 CORRECT_BYTES_MOVED = lambda M: 50 * 16 + 32 * M + 48 * 16 + 1
-POOL = 4                            # distinct bench steps of input data resident in HBM, cycled
+POOL = 4                            # distinct 0.1 s input patterns (IMU samples + marker frames) resident in HBM, cycled
 HBM_LEG_BATCH = 262144              # the HBM-roofline claim needs B >= 262 144 per GPU
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536, help="filters per GPU (weak scaling)")
     ap.add_argument("--total-batch", type=int, default=0,
                     help="strong scaling: this many filters in total, cut into contiguous 64-aligned shards over the "
@@ -69,7 +75,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 262 144-filter HBM-resident roofline leg")
     ap.add_argument("--graphs", action="store_true",
-                    help="replay each bench step (23 launches) from a captured HIP graph (launch-bound small batches); "
+                    help="replay each 0.1 s pattern (23 launches) from a captured HIP graph (launch-bound small batches); "
                          "the per-kernel HIP-event timing then comes from a short eager pass after the timed region")
     ap.add_argument("--kernel-timing", choices=["on", "off"], default="on",
                     help="bracket runs of launches with HIP events inside the timed region (feeds `roofline`)")
@@ -181,15 +187,15 @@ def cpu_baseline(args, seconds):
             dt = np.full(sum(PATTERN), 0.005)
             t0 = time.perf_counter()                             # one thread team runs the whole schedule
             orc.schedule(nom, rot, P, prev, PATTERN, reps, acc, gyr, dt, ids, pos, quat, mode)
-            return Bs * STEPS_PER_BENCH_STEP * reps / (time.perf_counter() - t0)
+            return Bs * STEPS_PER_PATTERN * reps / (time.perf_counter() - t0)
 
         probe = run(256, 1, 1)                                   # steps/s of one thread, short probe
-        Bs1 = int(min(8192, max(256, probe * min(secs, 4.0) * 0.3 / STEPS_PER_BENCH_STEP)))
+        Bs1 = int(min(8192, max(256, probe * min(secs, 4.0) * 0.3 / STEPS_PER_PATTERN)))
         one = run(Bs1, 1, 1)
         BsN = 256 * cores                                        # 256 filters per thread, reps sized for ~`secs`
-        reps = int(max(1, min(2000, one * cores * 0.6 * secs / (BsN * STEPS_PER_BENCH_STEP))))
+        reps = int(max(1, min(2000, one * cores * 0.6 * secs / (BsN * STEPS_PER_PATTERN))))
         allc = run(BsN, cores, reps)
-        return allc, one, f"{BsN} filters x {reps} bench steps (20 predict + 3 correct each, M={args.markers})"
+        return allc, one, f"{BsN} filters x {reps} patterns of 0.1 s (20 predict + 3 correct each, M={args.markers})"
 
     ref_v, ref_1, ref_s = leg(capi.DIALECT_CPP, capi.MODE_NEAREST, seconds * 0.5)
     d = capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP
@@ -209,7 +215,7 @@ def cpu_baseline(args, seconds):
 
 
 class Workload:
-    """device-resident inputs of `pool` distinct bench steps for the filters [lo, hi) + the filter handle"""
+    """device-resident inputs of `pool` distinct 0.1 s patterns for the filters [lo, hi) + the filter handle"""
 
     def __init__(self, torch, dev, local_rank, lo, hi, args, pool, with_cov=True):
         from fbus_ekf import BatchedFilter, capi, synth
@@ -245,28 +251,59 @@ class Workload:
         if P is None:
             self.flt.reset_cov()                                  # P0 diagonal written by the device (no 680 MB host array)
 
-    def step(self, i, fused=False):
-        acc, gyr, frames = self.pool[i % len(self.pool)]
+    def pattern(self, j, fused=False):
+        """0.1 s of sensor time: 7 / 7 / 6 IMU samples, a camera frame behind each run"""
+        acc, gyr, frames = self.pool[j % len(self.pool)]
         k = 0
         for f, K in enumerate(PATTERN):
             ids, pos, quat = frames[f]
             self.flt.frame(acc[k:k + K], gyr[k:k + K], self.d_dt[:K], ids, pos, quat, self.mode, fused=fused)
             k += K
 
+    def step(self, i, fused=False):
+        """one bench step: 1 s of sensor time"""
+        for r in range(PATTERNS_PER_STEP):
+            self.pattern(i * PATTERNS_PER_STEP + r, fused)
+
 
 def timed(torch, fn, steps, warmup, barrier=lambda: None, before_timing=lambda: None):
+    """W warm-up steps, then exactly K steps between barrier + synchronize on both sides.  Python's cyclic garbage collector
+    is switched off for the duration (as `timeit` does): with torch imported a full collection takes 40-60 ms, and it fired
+    in the middle of a 62 ms timed region (always at the 16th step: FBUS_BENCH_DEBUG_HOST_TIMES=1 shows the submitting
+    thread standing still while the GPU runs dry).  Nothing the steps allocate is cyclic."""
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        return _timed(torch, fn, steps, warmup, barrier, before_timing)
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _timed(torch, fn, steps, warmup, barrier, before_timing):
     for i in range(warmup):
         fn(i)
     torch.cuda.synchronize()
     before_timing()
     barrier()
     torch.cuda.synchronize()
+    marks = [] if os.environ.get("FBUS_BENCH_DEBUG_HOST_TIMES") == "1" else None
     t0 = time.perf_counter()
     for i in range(steps):
         fn(warmup + i)
+        if marks is not None:
+            marks.append(time.perf_counter() - t0)
+    if marks is not None:
+        marks.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     barrier()
-    return time.perf_counter() - t0
+    el = time.perf_counter() - t0
+    if marks is not None:       # host-side submission time of each step (ms) and when the GPU was done
+        sys.stderr.write("host submit ms per step: " + " ".join(f"{(b - a) * 1e3:.2f}" for a, b in zip([0.0] + marks, marks[:-1])) +
+                         f" | submitted at {marks[-1] * 1e3:.2f} ms, GPU done at {el * 1e3:.2f} ms\n")
+    return el
 
 
 def roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src):
@@ -345,14 +382,17 @@ def main():
 
     w = Workload(torch, dev, local_rank, lo, hi, args, POOL, with_cov=(hi - lo) <= 131072)
     flt = w.flt
-    frames_timed = args.steps * len(PATTERN)
+    frames_timed = args.steps * len(PATTERN) * PATTERNS_PER_STEP
     # HIP-event brackets on every stride-th camera frame (a pair costs ~8 us of stream time: <= 1.5 % of the timed region)
     stride = max(6, min(16, frames_timed // 10))
     flt.timing_enable(args.kernel_timing == "on", stride=stride)
     bench_step = w.step
     if args.graphs:
-        graph_ids = [flt.graph_capture(lambda j=j: w.step(j)) for j in range(POOL)]
-        bench_step = lambda i: flt.graph_launch(graph_ids[i % POOL])
+        graph_ids = [flt.graph_capture(lambda j=j: w.pattern(j)) for j in range(POOL)]
+
+        def bench_step(i):
+            for r in range(PATTERNS_PER_STEP):
+                flt.graph_launch(graph_ids[(i * PATTERNS_PER_STEP + r) % POOL])
 
     def clear():
         flt.timing_reset()
@@ -364,7 +404,7 @@ def main():
     if args.graphs and args.kernel_timing == "on":          # events cannot live inside a graph: short eager pass
         flt.timing_reset()
         for i in range(4):
-            w.step(i)
+            w.pattern(i)
         torch.cuda.synchronize()
     pred_ms, pred_n = flt.timing_read(capi.KERNEL_PREDICT)
     corr_ms, corr_n = flt.timing_read(capi.KERNEL_CORRECT)
@@ -402,7 +442,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.total_batch} filters in total, sharded over {world} GPU(s) "
                                     f"({w.B} on rank 0)" if strong else f"batch {w.B} filters/GPU") +
-                                   f", 200 Hz IMU + 30 Hz stereo (7/7/6 predicts per correct), "
+                                   f", 200 Hz IMU + 30 Hz stereo (7/7/6 predicts per correct, 1 s of sensor time per bench step), "
                                    f"{w.M} markers/frame, N=18, {args.dialect} dialect, correct mode {args.mode}, "
                                    "per-call API (one launch per EKF step)" + (", replayed from HIP graphs" if args.graphs else ""),
                        "batch_per_gpu": w.B, "total_filters": total_filters, "markers": w.M,
@@ -428,7 +468,7 @@ def main():
         if world == 1 and not args.no_hbm_leg and not strong and args.batch < HBM_LEG_BATCH:
             torch.cuda.empty_cache()
             w2 = Workload(torch, dev, local_rank, 0, HBM_LEG_BATCH, args, 1, with_cov=False)
-            steps2, warm2 = max(5, min(args.steps, 20)), 3
+            steps2, warm2 = max(2, min(args.steps, 6)), 1
             w2.flt.timing_enable(True, stride=2)
             el2 = timed(torch, w2.step, steps2, warm2, before_timing=lambda: (w2.flt.timing_reset(), w2.flt._keep.clear()))
             p_ms, p_n = w2.flt.timing_read(capi.KERNEL_PREDICT)

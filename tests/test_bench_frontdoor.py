@@ -117,7 +117,7 @@ def test_two_rank_rehearsal_weak_and_strong_scaling():
     assert strong["config"]["total_filters"] == 8192 and strong["config"]["batch_per_gpu"] == 4096
     assert strong["gathered_bytes"] == 8192 * 800 and strong["state_finite"]
     # value counts the filters of ALL ranks
-    assert strong["value"] == pytest.approx(8192 * 23 * 3 / (strong["ms_per_step"] * 3e-3), rel=1e-6)
+    assert strong["value"] == pytest.approx(8192 * 230 * 3 / (strong["ms_per_step"] * 3e-3), rel=1e-6)
 
 
 @pytest.mark.gpu

@@ -3,7 +3,7 @@
 # after `--`, never a wrapper).  Writes raw output under gpurun_out/prof_$TAG and a digest
 # gpurun_out/prof_$TAG/summary.txt + digest.json (copy those into profiles/).
 #   tools/profile_gpu.sh r02_b65536  "--batch 65536 --steps 20 --warmup 5"
-#   tools/profile_gpu.sh r02_b262144 "--batch 262144 --steps 8 --warmup 3"
+#   tools/profile_gpu.sh r02_b262144 "--batch 262144 --steps 4 --warmup 1"
 TAG=${1:-r02_b65536}
 ARGS=${2:-"--batch 65536 --steps 20 --warmup 5"}
 ARGS="$ARGS --no-cpu-baseline --no-hbm-leg"
