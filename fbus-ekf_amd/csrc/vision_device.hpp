@@ -93,9 +93,39 @@ __device__ __forceinline__ void refraction_corner(const VisConst<T>& vc, T xl, T
 // Forward flat-port projection with its Jacobian (north-star extension; the reference only back-projects).
 // Xp: point in a camera's refraction frame (the frame of the rays of vision.cpp:496-552).  The ray to it stays in the
 // plane of the port normal and the point, so t = tan(theta_air) solves one monotone scalar equation
-//     rho = d_air t + d_glass tan(theta_glass) + (z - d_air - d_glass) tan(theta_water)          (Snell twice)
-// (z = depth along the normal, rho = distance from the axis), by Newton from the pin-hole start.
+//     rho = L(t) = d_air t + d_glass tan(theta_glass) + (z - d_air - d_glass) tan(theta_water)          (Snell twice)
+// (z = depth along the normal, rho = distance from the axis).  L is increasing and concave in t, so Newton from the
+// paraxial start t0 = rho / (d_air + a0 d_glass + a1 (z - d_air - d_glass)) <= t* climbs monotonically to the root and
+// converges quadratically; the loop leaves when no lane of the wave moved by more than a relative NEWTON_TOL (a step
+// that small leaves an error of its square), which takes 2-3 steps inside a camera's field of view and is capped at
+// NEWTON_MAX towards the 0.9-of-critical-angle rim that pixel_info admits.  One more evaluation at the root gives
+// dL/dt and tan(theta_water) for the Jacobian.
 // uv = normalised image point, J = d uv / d Xp (2 x 3, row-major), in closed form by implicit differentiation.
+// fp32 evaluates L with v_rsq_f32 / v_rcp_f32 (1 ulp, a quarter-rate instruction each) instead of IEEE divisions and
+// square roots (10-15 instructions each): (1 + t^2)^-1/2, cos^-1 of the glass and water angles, and the cubes of
+// those for dL/dt.  This is what the pixel-row correct spends its time in (59-118 projections per filter).
+template <typename T> struct PortRay { T L, Lt, Lz; };
+
+__device__ __forceinline__ float fb_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double fb_rsq(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float fb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fb_rcp(double x) { return 1.0 / x; }
+
+template <typename T>
+__device__ __forceinline__ PortRay<T> port_ray(const VisConst<T>& vc, T a0, T a1, T zw, T t)
+{
+    const T r = fb_rsq(T(1) + t * t);                                // cos(theta_air)
+    const T s_ = t * r, dsdt = r * r * r;                            // sin(theta_air), d sin / d t
+    const T s2 = s_ * s_;
+    const T icg = fb_rsq(T(1) - a0 * a0 * s2), icw = fb_rsq(T(1) - a1 * a1 * s2);      // 1 / cos(theta_glass), 1 / cos(theta_water)
+    const T g = vc.d_glass * a0 * icg, w = zw * a1 * icw;
+    PortRay<T> o;
+    o.L = vc.d_air * t + s_ * (g + w);
+    o.Lt = vc.d_air + (g * icg * icg + w * icw * icw) * dsdt;
+    o.Lz = a1 * s_ * icw;                                            // tan(theta_water)
+    return o;
+}
+
 template <typename T>
 __device__ __forceinline__ void refraction_project(const VisConst<T>& vc, const T* Xp, T* uv, T* J)
 {
@@ -105,19 +135,18 @@ __device__ __forceinline__ void refraction_project(const VisConst<T>& vc, const 
     const T lat[3] = { Xp[0] - z * n[0], Xp[1] - z * n[1], Xp[2] - z * n[2] };
     const T rho = fb_sqrt(dot3(lat, lat));
     const T zw = z - vc.d_air - vc.d_glass;
-    T t = rho / z, Lt = T(1), Lz = T(0);
-    constexpr int ITER = (sizeof(T) == 4) ? 6 : 9;                // quadratic convergence from a start within a few percent
+    T t = rho / (vc.d_air + a0 * vc.d_glass + a1 * zw);
+    constexpr int NEWTON_MAX = (sizeof(T) == 4) ? 7 : 10;
+    constexpr T NEWTON_TOL = (sizeof(T) == 4) ? T(3e-4) : T(1e-8);
 #pragma unroll 1
-    for (int it = 0; it <= ITER; ++it) {
-        const T q = T(1) / (T(1) + t * t), sq = fb_sqrt(q);
-        const T s_ = t * sq, dsdt = q * sq;                       // sin(theta_air), d sin / d t
-        const T cg2 = T(1) - a0 * a0 * s_ * s_, cw2 = T(1) - a1 * a1 * s_ * s_;
-        const T icg = T(1) / fb_sqrt(cg2), icw = T(1) / fb_sqrt(cw2);
-        const T L = vc.d_air * t + vc.d_glass * a0 * s_ * icg + zw * a1 * s_ * icw;
-        Lt = vc.d_air + (vc.d_glass * a0 * icg / cg2 + zw * a1 * icw / cw2) * dsdt;
-        Lz = a1 * s_ * icw;                                       // tan(theta_water)
-        if (it < ITER) { t -= (L - rho) / Lt; t = t < T(0) ? T(0) : t; }
+    for (int it = 0; it < NEWTON_MAX; ++it) {
+        const PortRay<T> f = port_ray(vc, a0, a1, zw, t);
+        const T dt = (rho - f.L) * fb_rcp(f.Lt);
+        t = fmax(t + dt, T(0));
+        if (!__any(fb_abs(dt) > NEWTON_TOL * t)) break;
     }
+    const PortRay<T> f = port_ray(vc, a0, a1, zw, t);
+    const T Lt = f.Lt, Lz = f.Lz;
     const bool on_axis = !(rho > T(0));
     const T irho = on_axis ? T(0) : T(1) / rho;
     const T k = on_axis ? T(1) / Lt : t * irho;
