@@ -259,11 +259,69 @@ struct ImuSample {
     }
 };
 
+// LDS parking for the multi-step predict loop (two waves per SIMD = at most 256 registers).  Inside the loop the whole
+// record is live (172 + 28) beside a step's own 28 coefficients, 36 + 9 products of the v stage and the prefetched IMU
+// sample: ~330 registers.  But rows p of the covariance (storage [0, E_P): final when stage p has run, not touched by
+// stages v and theta) are only needed by stage p, and the nominal state only by predict_nominal.  They wait in LDS in
+// between: 13 + NOMCH ds_write_b128 / ds_read_b128 per step (conflict-free: lane-consecutive 16-byte slots) against
+// ~1400 VALU instructions.
+struct NoStepPark {
+    template <typename T> __device__ __forceinline__ void rows_out(const T*) const {}
+    template <typename T> __device__ __forceinline__ void rows_in(T*) const {}
+    template <typename T> __device__ __forceinline__ void nom_out(const T*) const {}
+    template <typename T> __device__ __forceinline__ void nom_in(T*) const {}
+};
+template <typename T, int N, int NOMCH>
+struct StepPark {
+    using RC = Rec<T, N>;
+    static constexpr int EPC = RC::EPC;
+    static constexpr int E_P = cov_final_before_row<N>(3);               // rows p = storage [0, E_P) (+ odd-row diagonals kept in registers)
+    static constexpr int PCH = (E_P + EPC - 1) / EPC;
+    static constexpr int NCHUNK = PCH + NOMCH;
+    static_assert(NOMCH * EPC <= Lay<N>::NNOM, "nominal chunks");
+    u32x4* mem;                                                          // [NCHUNK][BLOCK], this lane's column
+    __device__ __forceinline__ void put(int c, const T* src, int n) const
+    {
+        u32x4 v = { 0u, 0u, 0u, 0u };
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) if (k < n) e[k] = src[k];
+        mem[c * BLOCK] = v;
+    }
+    __device__ __forceinline__ void get(int c, T* dst, int n) const
+    {
+        const u32x4 v = mem[c * BLOCK];
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) if (k < n) dst[k] = e[k];
+    }
+    __device__ __forceinline__ void rows_out(const T* P) const
+    {
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) put(c, P + c * EPC, E_P - c * EPC);
+    }
+    __device__ __forceinline__ void rows_in(T* P) const
+    {
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) get(c, P + c * EPC, E_P - c * EPC);
+    }
+    __device__ __forceinline__ void nom_out(const T* nom) const
+    {
+#pragma unroll
+        for (int c = 0; c < NOMCH; ++c) put(PCH + c, nom + c * EPC, EPC);
+    }
+    __device__ __forceinline__ void nom_in(T* nom) const
+    {
+#pragma unroll
+        for (int c = 0; c < NOMCH; ++c) get(PCH + c, nom + c * EPC, EPC);
+    }
+};
+
 // K ImuUpdates with the record resident in registers (predict_n, fused frame)
 struct NoMidHook { __device__ __forceinline__ void operator()() const {} };
-template <typename T, int N, int DIALECT, typename MID = NoMidHook>
+template <typename T, int N, int DIALECT, typename MID = NoMidHook, typename PARK = NoStepPark>
 __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
-                                              int B, int b, const T* qd, const MID& mid_last = MID())
+                                              int B, int b, const T* qd, const MID& mid_last = MID(), const PARK& park = PARK())
 {
 #if FBUS_X_IMU_PREFETCH
     // The sample of step k + 1 is requested as soon as step k's kinematics have consumed sample k, i.e. ~700 VALU
@@ -274,17 +332,26 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
     if (K <= 0) { mid_last(); return; }
     ImuSample<T> cur;
     cur.load(accel, gyro, dt, dt_stride, 0, B, b);
+    constexpr bool PARKED = !std::is_same<PARK, NoStepPark>::value;
+    if constexpr (PARKED) { park.rows_out(P); park.nom_out(nom); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll 1
     for (int k = 0; k < K; ++k) {
         PredictCoef<T> c;
+        if constexpr (PARKED) { park.nom_in(nom); }
         predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, c);
+        if constexpr (PARKED) { park.nom_out(nom); }
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < K) cur.load(accel, gyro, dt, dt_stride, k + 1, B, b);
         else mid_last();                           // last step: the caller's loads for what follows the predicts
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PARKED) { park.rows_in(P); }
         cov_stage_p<T, N>(P, c);
+        if constexpr (PARKED) { park.rows_out(P); __builtin_amdgcn_sched_barrier(0); }
         cov_stage_v<T, N>(P, c, qd);
         cov_stage_th<T, N>(P, c, qd);
+        if constexpr (PARKED) { __builtin_amdgcn_sched_barrier(0); }
     }
+    if constexpr (PARKED) { park.rows_in(P); park.nom_in(nom); }
 #else
     for (int k = 0; k < K; ++k) {
         const size_t o = ((size_t)k * B + b) * 3;
@@ -322,8 +389,15 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
 // loads, 14.2 us with default loads, and the following launches reach their steady 12.6 us two launches earlier:
 // -5 us per camera frame; default-policy STORES there, or default loads for a second launch, lose again --
 // tools/exp_gap_after_correct.py under rocprofv3, reduced by tools/trace_positions.py).
-template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST>
-__global__ void __launch_bounds__(BLOCK)
+// PARK (MULTI, fp32): the K-step loop with rows p of the covariance and PARK_NOM_CHUNKS chunks of the nominal state parked
+// in LDS between their uses (StepPark): 246 registers instead of 335, no scratch, 17 KiB of LDS -- two waves per SIMD.
+// The launcher picks it from 2048 waves on: predict_n K = 7 at 131 072 filters 64.5 -> 53.4 us, at 262 144 filters
+// 122.1 -> 97.6 us (91 % of the VALU bound of its 1600 instructions per step); with one wave per SIMD (65 536 filters) the
+// parking is pure overhead, 31.4 -> 32.4 us.  Parking rows p alone leaves 16-32 bytes of scratch, all 7 nominal chunks
+// cost 20 KiB of LDS for nothing (gpurun_out/r02_park.log).
+constexpr int PARK_NOM_CHUNKS = 4;
+template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST, bool PARK = false>
+__global__ void __launch_bounds__(BLOCK, PARK ? 2 : 1)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
                const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
 {
@@ -336,6 +410,12 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     if (MULTI) {
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        if constexpr (PARK) {
+            using Park = StepPark<T, N, PARK_NOM_CHUNKS>;
+            __shared__ u32x4 park_mem[Park::NCHUNK * BLOCK];
+            predict_steps<T, N, DIALECT, NoMidHook, Park>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd, NoMidHook(),
+                                                          Park{ park_mem + threadIdx.x });
+        } else
         predict_steps<T, N, DIALECT>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd);
         store_chunks<T, N, 0, RC::CH_KIN>(rs, my_lane(), nom);
         store_chunks<T, N, CN, RC::CH_VAR_END>(rs, my_lane(), P);
@@ -691,6 +771,108 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     constexpr int C_REST = RowStore<T, N, AUX_DEFAULT>::streamed_end();
     if (!streamed) store_chunks<T, N, RC::CH_NOM, C_REST>(rs, my_lane(), P);
     store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
+}
+
+// The fused frame for launches of >= 2048 waves: at most 256 registers, two waves per SIMD (stacked mode, simple form).
+// frame_kernel holds the record in 383 registers and is VALU-bound with one wave per SIMD at 57 % issue utilisation;
+// from 131 072 filters on a second wave per SIMD fills its stalls.  What makes the 256 registers possible:
+//   * the predict loop parks rows p of the covariance and 16 of the 28 nominal values in LDS between their uses (StepPark);
+//   * behind the loop the late covariance rows (storage rows 9..17, final as predicted) go out to their record at once --
+//     they come back from L2 for the late half of the update, exactly as in the row-split correct_kernel -- and the head
+//     of the early rows waits in LDS while the marker rows are folded and the 6x6 information matrix is factorised;
+//   * the six rank-1 passes then run in the row-split form (joint_apply_early / joint_apply_late), their stash in the
+//     same LDS area (17 KiB per wave + the 3 KiB marker map = 20 KiB: eight workgroups per CU).
+// Same device functions as K predict launches + one correct launch; per filter the order of operations is that of the
+// row-split correct_kernel.
+template <typename T, int N, int DIALECT>
+__global__ void __launch_bounds__(BLOCK, 2)
+frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
+              const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+              const T* __restrict__ quat, const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied,
+              DevConst<T> dc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    constexpr int RS = 9, EPC = RC::EPC, CN = RC::CH_NOM;
+    using Park = StepPark<T, N, PARK_NOM_CHUNKS>;
+    using Stash = LateStash<T, N, RS>;
+    using Hook = RowStore<T, N, AUX_DEFAULT>;
+    static_assert(Stash::NVAL * sizeof(T) <= Park::NCHUNK * 16, "the stash of the passes reuses the parking area");
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ MarkerLDS<T> tbl;
+    __shared__ u32x4 lds_mem[Park::NCHUNK * BLOCK];
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T nom[L::NNOM], P[RC::NCOVP];
+    {
+        MarkerTableRegs<T> treg;
+        treg.load(dc);
+        order_fence();
+        load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        order_fence();
+        treg.to_lds(tbl);
+        order_fence();
+    }
+    if (b >= B) return;
+    const int last = (M > 0 && !(skip && skip[b])) ? M : 0;
+    const int* my_ids = ids + (size_t)b * M;
+    const T* my_pos = pos + (size_t)b * M * 3;
+    const T* my_quat = quat + (size_t)b * M * 4;
+    const Park park{ lds_mem + threadIdx.x };
+    predict_steps<T, N, DIALECT, NoMidHook, Park>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd, NoMidHook(), park);
+    order_fence();
+    // the late rows are final as predicted: out to the record now (they return from L2 for joint_apply_late)
+    constexpr int E_END = cov_final_before_row<N>(RS);
+    constexpr int C_E = CN + (E_END + EPC - 1) / EPC;                    // early chunks: [CN, C_E)
+    store_chunks<T, N, C_E, RC::NCH>(rs, my_lane(), P + (C_E - CN) * EPC);
+    int used = 0;
+    InfoFactors<T> fac;
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    if (last > 0) {
+        // the head of the early rows waits in LDS while the rows of the markers are built and folded
+#pragma unroll
+        for (int c = 0; c < Park::NCHUNK; ++c) park.put(c, P + c * EPC, EPC);
+        order_fence();
+        InfoAcc<T> acc;
+        acc.clear();
+        const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+        MarkerCommon<T, N> mc;
+        mc.build(nom, dc);
+        for (int i0 = 0; i0 < last; i0 += FBUS_MARKER_GROUP) {
+            MarkerGroup<T, FBUS_MARKER_GROUP> mg;
+            mg.fetch(my_ids, my_pos, my_quat, i0, last);
+            mg.resolve(tbl);
+#pragma unroll
+            for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
+                if (mg.slot[g] < 0) continue;
+                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                ++used;
+            }
+        }
+        if (used > 0) joint_factor<T>(acc, fac);
+        order_fence();
+#pragma unroll
+        for (int c = 0; c < Park::NCHUNK; ++c) park.get(c, P + c * EPC, EPC);
+        order_fence();
+    }
+    if (M > 0) applied[b] = used > 0 ? 1 : 0;
+    if (used > 0) {
+        const Stash stash{ reinterpret_cast<T*>(lds_mem) + threadIdx.x };
+        joint_apply_early<T, N, COV_SIMPLE, RS, Hook>(P, dx, fac, Hook{ rs, my_lane(), P }, stash);   // the last pass streams rows 0..8 out
+        order_fence();
+        load_chunks<T, N, C_E, RC::NCH>(rs, my_lane(), P + (C_E - CN) * EPC);
+        joint_apply_late<T, N, COV_SIMPLE, RS>(P, dx, stash);
+        inject<T, N>(nom, dx);
+        store_chunks<T, N, 0, CN>(rs, my_lane(), nom);
+        constexpr int C_REST = Hook::fin(RS);
+        store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - CN) * EPC);
+    } else {
+        // no marker for this filter: the predicted record as it is (its late chunks are out already)
+        store_chunks<T, N, 0, CN>(rs, my_lane(), nom);
+        store_chunks<T, N, CN, C_E>(rs, my_lane(), P);
+    }
 }
 
 // correct() from stereo corners: triangulation + 12 corner rows per marker (north-star extension).

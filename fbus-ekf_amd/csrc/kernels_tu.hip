@@ -15,6 +15,15 @@
 
 namespace fbus {
 
+// From this many filters on a launch has >= 2048 waves, two per SIMD, and the instantiations written for at most 256
+// registers (row-split correct, parked predict_n / frame) are the faster ones; below it every SIMD holds one wave
+// whatever the register count, and the one-wave forms win.  FBUS_TWO_WAVE_MIN_B moves the threshold (A/B runs, tests).
+static int two_wave_min_b()
+{
+    static const int v = [] { const char* e = getenv("FBUS_TWO_WAVE_MIN_B"); return e ? atoi(e) : 2048 * BLOCK; }();
+    return v;
+}
+
 #if FBUS_TU_FAMILY == 1
 template <typename T, int N, int D>
 void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T* accel, const T* gyro, const T* dt,
@@ -38,6 +47,9 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
             hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_NT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, 1,
                                accel + (size_t)k * B * 3, gyro + (size_t)k * B * 3, dt + (size_t)k * (dt_stride ? B : 1),
                                dt_stride, dc);
+    } else if (B >= two_wave_min_b()) {
+        hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
+                           K, accel, gyro, dt, dt_stride, dc);
     } else {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt,
                            dt_stride, dc);
@@ -49,11 +61,6 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
                                                             const DevConst<FBUS_TU_T>&);
 
 #elif FBUS_TU_FAMILY == 2
-static int correct_split_min_b()
-{
-    static const int v = [] { const char* e = getenv("FBUS_CORRECT_SPLIT_MIN_B"); return e ? atoi(e) : 2048 * BLOCK; }();
-    return v;
-}
 template <typename T, int N, int D>
 void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode,
                       bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
@@ -64,8 +71,8 @@ void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
     hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, pos, quat, \
                        mode, skip, applied, dc)
     // fp32, stacked, simple form: from 2048 waves on (two per SIMD) the row-split instantiation (194 registers) is the
-    // faster one -- see the LEAN comment in correct_kernel; FBUS_CORRECT_SPLIT_MIN_B moves the threshold (A/B runs)
-    if (sizeof(T) == 4 && joint && !joseph && B >= correct_split_min_b()) {
+    // faster one -- see the LEAN comment in correct_kernel
+    if (sizeof(T) == 4 && joint && !joseph && B >= two_wave_min_b()) {
         hipLaunchKernelGGL((correct_kernel<T, N, D, COV_SIMPLE, true, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
                            pos, quat, mode, skip, applied, dc);
         return;
@@ -93,6 +100,12 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
                        dt_stride, M, ids, pos, quat, mode, skip, applied, dc)
     // (Joseph form, nearest marker) is not built as a fused kernel (7 Joseph rank-2 passes with the record resident
     // spilled 280 bytes per lane): fbus_ekf.hip runs that combination as predict_n + correct
+    // stacked mode, simple form, >= 2048 waves: the two-waves-per-SIMD kernel (see frame2_kernel)
+    if (joint && !joseph && B >= two_wave_min_b()) {
+        hipLaunchKernelGGL((frame2_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, dt_stride, M, ids,
+                           pos, quat, skip, applied, dc);
+        return;
+    }
     if (joseph) { FBUS_LAUNCH_FRAME(COV_JOSEPH, true); }
     else        { if (joint) FBUS_LAUNCH_FRAME(COV_SIMPLE, true); else FBUS_LAUNCH_FRAME(COV_SIMPLE, false); }
 #undef FBUS_LAUNCH_FRAME

@@ -447,6 +447,59 @@ def test_row_split_correct_of_large_launches(dialect, n):
     assert np.abs(full[2] - np.swapaxes(full[2], 1, 2)).max() == 0
 
 
+@pytest.mark.parametrize("dialect", [0, 1])
+@pytest.mark.parametrize("n", [18, 15])
+def test_two_wave_frame_and_predict_n_of_large_launches(dialect, n):
+    """from 2048 waves on the fused frame (stacked) and predict_n run as the 256-register kernels (frame2_kernel, parked
+    predict loop: rows p and part of the nominal state wait in LDS between their uses): parity with the oracle on a strided
+    subset and fp32-closeness to the one-wave kernels that the two half batches get"""
+    import torch
+    B, M, K = 131072, 4, 5
+    prm = _params(dialect)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), n)
+    nom, rot, P = _r32(nom), _r32(rot), _r32(P)
+    acc, gyr = _imu(0, B, 0, K, nom)
+    ids, pos, quat = _markers(0, B, 0, M, nom, prm)
+    ids[5] = -1                                                 # a filter that sees nothing: predicted record only
+    skip = np.zeros(B, np.uint8); skip[9] = 1                   # ... and one whose camera frame is masked
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_acc, d_gyr, d_dt = f32(acc), f32(gyr), f32(np.full(K, DT[0]))
+    d_ids, d_pos, d_quat, d_skip = torch.from_numpy(ids).to(dev), f32(pos), f32(quat), torch.from_numpy(skip).to(dev)
+
+    def run(lo, hi, what):
+        with BatchedFilter(hi - lo, prm, nstate=n) as flt:
+            flt.set_state(nom[lo:hi], rot[lo:hi], P[lo:hi], prev[lo:hi])
+            a, g = d_acc[:, lo:hi].contiguous(), d_gyr[:, lo:hi].contiguous()
+            if what == "frame":
+                flt.frame(a, g, d_dt, d_ids[lo:hi].contiguous(), d_pos[lo:hi].contiguous(), d_quat[lo:hi].contiguous(), 1,
+                          skip=d_skip[lo:hi].contiguous(), fused=True)
+            else:
+                flt.predict_n(a, g, d_dt, K)
+            flt.sync()
+            return flt.get_state(), (np.asarray(flt.applied()) if what == "frame" else None)
+
+    sub = np.unique(np.concatenate([np.arange(0, B, 1021), [5, 9, B - 1]]))
+    for what in ("predict_n", "frame"):
+        full, app = run(0, B, what)
+        halves = [run(0, B // 2, what), run(B // 2, B, what)]
+        eng = OracleEngine(len(sub), dialect, n)
+        eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+        for k in range(K):
+            eng.predict(acc[k][sub], gyr[k][sub], DT)
+        if what == "frame":
+            assert np.array_equal(app, np.concatenate([h[1] for h in halves])) and app[5] == 0 and app[9] == 0 and app[0] == 1
+            ids_o = ids.copy(); ids_o[skip == 1] = -1           # a masked frame is a frame without markers
+            eng.correct(ids_o[sub], pos[sub], quat[sub], 1)
+        # a window of K + 1 fp32 steps: the window bound, as in the fused-frame and free-running tests
+        assert_parity([a[sub] for a in full], eng.get_state(), 32, f"two-wave {what} d{dialect} n{n}", state_tol=WINDOW_TOL,
+                      plain_tol=PLAIN_WINDOW_TOL)
+        one_wave = [np.concatenate([halves[0][0][k], halves[1][0][k]]) for k in range(4)]
+        e = parity_errors(full, one_wave)
+        print(f"[two-wave vs one-wave {what}] sigma {e['sigma']:.2e} plain {e['plain']:.2e} cov block {e['cov_block']:.2e}")
+        assert e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL and e["asym"] == 0
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("dialect", [0, 1])
 def test_fused_frame_equals_per_call_launches(dialect, mode):
