@@ -500,6 +500,23 @@ def test_two_wave_frame_and_predict_n_of_large_launches(dialect, n):
         assert e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL and e["asym"] == 0
 
 
+def test_two_wave_kernels_on_small_and_ragged_batches():
+    """The launchers pick the 256-register kernels (row-split correct, parked predict_n, frame2_kernel) from 2048 waves on.
+    With FBUS_TWO_WAVE_MIN_B=0 (read once per process, hence the child pytest) they take every launch, so the tests written
+    for partial tiles, skip masks, invisible markers, 16 marker slots, graph replay and long runs exercise THEM."""
+    import subprocess
+    import sys
+    if os.environ.get("FBUS_TWO_WAVE_MIN_B") == "0":
+        pytest.skip("already inside the forced run")
+    env = dict(os.environ, FBUS_TWO_WAVE_MIN_B="0")
+    sel = ("fused_frame or skip_mask or predict_n_equals or sixteen_marker or one_stacked or graph_replay or long_run or "
+           "correct_single_step or free_running")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", sel],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("dialect", [0, 1])
 def test_fused_frame_equals_per_call_launches(dialect, mode):
