@@ -886,62 +886,100 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     using L = Lay<N>;
     using RC = Rec<T, N>;
     const int b = blockIdx.x * BLOCK + threadIdx.x;
-    if (b >= B) return;
-    if (skip && skip[b]) { applied[b] = 0; return; }
-    const int* my_ids = ids + (size_t)b * M;
-    const int lw = (geometry == VIS_CORNERS3D) ? 12 : 8;
-    auto corner = [&](int i, int c, T* out) {          // corner c of marker slot i in the left camera frame
-        const T* l = left + ((size_t)b * M + i) * lw;
-        if (geometry == VIS_CORNERS3D) { out[0] = l[3 * c]; out[1] = l[3 * c + 1]; out[2] = l[3 * c + 2]; return; }
-        const T* r = right + ((size_t)b * M + i) * 8;
-        if (geometry == VIS_REFRACTIVE) refraction_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], out);
-        else pinhole_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], out);
-    };
-    int first = 0, last = M, new_prev = -1;
-    if (mode == MODE_NEAREST) {
-        int prev_id = 0;
-        if (DIALECT == DIALECT_CPP) prev_id = (int)recs[elem_index<T, N>(b, L::OFF_PREV)];
-        int min_i = -1, prev_i = -1;
-        T min_d = T(10), prev_d = T(0);
-        for (int i = 0; i < M; ++i) {
-            const int id = my_ids[i];
-            if (id < 0) continue;
-            T c0[3];
-            corner(i, 0, c0);
-            const T dist = fb_sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
-            if (dist < min_d) { min_d = dist; min_i = i; }
-            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
-        }
-        if (min_i < 0) { applied[b] = 0; return; }
-        if (DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
-        const int id = my_ids[min_i];
-        const int slot = (id <= FBUS_MAX_MARKER_ID) ? dc.id2slot[id] : -1;
-        if (slot < 0) { applied[b] = 0; return; }
-        if (DIALECT == DIALECT_CPP) new_prev = id;
-        first = min_i; last = min_i + 1;
-    }
+    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
+    const int bc = b < B ? b : 0;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
-    // The rows of all markers are folded into the 6x6 information matrix BEFORE the covariance is requested: the 16
-    // ray intersections per marker are hundreds of live values, and with the 171 covariance registers reserved as load
-    // targets at the same time the fp64 instantiation spilled 600-800 bytes per lane to scratch (fp32: 20 bytes in
-    // the Joseph variants).  This kernel is VALU-bound on the triangulation (27 us at B = 16 384), the ~2 us the
-    // covariance now takes to arrive behind the fold are not what limits it.
+    // One wave per SIMD (config 3: 16 384 filters are ONE wave per CU): every dependent global load costs its whole latency.
+    // The marker map is looked up in LDS (as in correct_kernel; every lane carries a piece of it, so dead lanes run along
+    // until it is written), and the id and the 16 (12) corner coordinates of marker i + 1 are requested before marker i is
+    // triangulated and folded.  (B = 16 384, M = 4, refractive, stacked: 26.6 -> 25.6 us; 65 536 x 16 markers: 82.4 -> 76.0 us --
+    // the kernel is bound by the ~2600 VALU instructions per marker of the triangulation and the 12 row folds.)
+    __shared__ MarkerLDS<T> tbl;
+    struct Meas { int id; T l[12], r[8]; };
+    const bool c3d = geometry == VIS_CORNERS3D;
+    const int lw = c3d ? 12 : 8;
+    auto fetch = [&](int i, Meas& m) __attribute__((always_inline)) {
+        const size_t o = (size_t)bc * M + i;
+        m.id = ids[o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m.l[j] = ld_meas(left + o * lw + j);
+#pragma unroll
+        for (int j = 8; j < 12; ++j) m.l[j] = c3d ? ld_meas(left + o * lw + j) : T(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m.r[j] = c3d ? T(0) : ld_meas(right + o * 8 + j);
+    };
+    auto corner = [&](const Meas& m, int c, T* out) __attribute__((always_inline)) {   // corner c (a constant after unrolling) in the left camera frame
+        if (geometry == VIS_CORNERS3D) { out[0] = m.l[3 * c]; out[1] = m.l[3 * c + 1]; out[2] = m.l[3 * c + 2]; return; }
+        if (geometry == VIS_REFRACTIVE) refraction_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
+        else pinhole_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
+    };
+    Meas cur, nxt;
     T pqr[L::NPQR];
-    load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
-    int used = 0;
+    T prev_raw = T(0);
+    {
+        MarkerTableRegs<T> treg;
+        treg.load(dc);
+        order_fence();
+        if (M > 0) fetch(0, cur);
+        if (mode == MODE_NEAREST && DIALECT == DIALECT_CPP) prev_raw = recs[elem_index<T, N>(bc, L::OFF_PREV)];
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
+        order_fence();
+        treg.to_lds(tbl);
+        order_fence();
+    }
+    if (!live) { if (b < B) applied[b] = 0; return; }
+    int used = 0, new_prev = -1;
     InfoAcc<T> acc;
     acc.clear();
     const T w_pos = T(1) / dc.r_pos;
-    for (int i = first; i < last; ++i) {
-        const int id = my_ids[i];
-        if (id < 0 || id > FBUS_MAX_MARKER_ID) continue;
-        const int slot = dc.id2slot[id];
-        if (slot < 0) continue;
+    // The rows of all markers are folded into the 6x6 information matrix BEFORE the covariance is requested: the 16
+    // ray intersections per marker are hundreds of live values, and with the 171 covariance registers reserved as load
+    // targets at the same time the fp64 instantiation spilled 600-800 bytes per lane to scratch (fp32: 20 bytes in
+    // the Joseph variants).
+    auto fold_marker = [&](const Meas& m) __attribute__((always_inline)) {
+        const bool ok = m.id >= 0 && m.id <= FBUS_MAX_MARKER_ID;
+        const int slot = ok ? (int)tbl.id2slot[ok ? m.id : 0] : -1;
+        if (slot < 0) return false;
+        T mk[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
         T C[12];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) corner(i, c, C + 3 * c);
-        corner_info<T, N>(acc, pqr, dc, dc.mk + (size_t)slot * MK_STRIDE, C, size, w_pos);
-        ++used;
+        for (int c = 0; c < 4; ++c) corner(m, c, C + 3 * c);
+        corner_info<T, N>(acc, pqr, dc, mk, C, size, w_pos);
+        return true;
+    };
+    if (mode == MODE_NEAREST) {
+        // nearest visible marker by its first corner, C++ dialect: hysteresis against the previous one (filter.cpp:639-664)
+        const int prev_id = (int)prev_raw;
+        int min_i = -1, prev_i = -1;
+        T min_d = T(10), prev_d = T(0);
+#pragma unroll 1
+        for (int i = 0; i < M; ++i) {
+            fetch(i + 1 < M ? i + 1 : M - 1, nxt);          // always a fresh load (no conditional merge of the two records)
+            if (cur.id >= 0) {
+                T c0[3];
+                corner(cur, 0, c0);
+                const T dist = fb_sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+                if (dist < min_d) { min_d = dist; min_i = i; }
+                if (DIALECT == DIALECT_CPP && cur.id == prev_id) { prev_d = dist; prev_i = i; }
+            }
+            cur = nxt;
+        }
+        if (min_i < 0) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP && prev_i >= 0 && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
+        fetch(min_i, cur);                              // the chosen marker once more (a copy kept per candidate lived in scratch)
+        if (!fold_marker(cur)) { applied[b] = 0; return; }
+        if (DIALECT == DIALECT_CPP) new_prev = cur.id;
+        used = 1;
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < M; ++i) {
+            fetch(i + 1 < M ? i + 1 : M - 1, nxt);          // always a fresh load (no conditional merge of the two records)
+            if (fold_marker(cur)) ++used;
+            cur = nxt;
+        }
     }
     if (used == 0) { applied[b] = 0; return; }
     constexpr bool LEAN = sizeof(T) == 8;                // fp64: row-split passes, see correct_kernel
@@ -1089,7 +1127,7 @@ correct_pixels_kernel(T* __restrict__ recs, int B, int M, const int* __restrict_
     // constants are two dependent lookups per marker.  So the marker map goes to LDS with the first loads (as in
     // correct_kernel: every lane carries a piece, which is why dead lanes run along until the map is written), and the id
     // and the 8 + 8 image coordinates of marker i + 1 are requested before marker i is folded.
-    // (114.9 -> ... us at 65 536 filters x 14.7 markers, left camera.)
+    // (114.9 -> 104-107 us at 65 536 filters x 14.7 markers, left camera.)
     __shared__ MarkerLDS<T> tbl;
     struct Meas { int id; T l[8], r[8]; };
     auto fetch = [&](int i, Meas& m) {
@@ -1118,8 +1156,7 @@ correct_pixels_kernel(T* __restrict__ recs, int B, int M, const int* __restrict_
     const T w_pix = T(1) / r_pix;
 #pragma unroll 1
     for (int i = 0; i < M; ++i) {                     // the fold runs before the covariance is requested (see correct_corners_kernel)
-        nxt = cur;
-        if (i + 1 < M) fetch(i + 1, nxt);
+        fetch(i + 1 < M ? i + 1 : M - 1, nxt);              // always a fresh load (no conditional merge of the two records)
         const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
         const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
         if (slot >= 0) {
