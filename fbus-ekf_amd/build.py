@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Builds fbus-ekf_amd/lib/libfbus_ekf.so (HIP, gfx950) in-tree with hipcc.
 
-The library is 15 translation units compiled in parallel and linked into one shared object:
+The library is 17 translation units compiled in parallel and linked into one shared object:
   fbus_ekf.hip                          handle, C ABI, the small kernels (pack/unpack, init, EMA, marker pose)
-  kernels_tu.hip x 14                   one kernel family (predict / correct / fused frame / corners) for one
+  kernels_tu.hip x 16                   one kernel family (predict / correct / fused frame / corners / frame window) for one
                                         (float|double, N = 18|15), both dialects: -DFBUS_TU_T/N/FAMILY
 Objects live in fbus-ekf_amd/lib/obj/ (git-ignored) and are rebuilt when a source they include is newer.
   python build.py [--force] [--only f32_18_correct,...] [--jobs N]
@@ -21,7 +21,7 @@ HEADERS = [os.path.join(CSRC, h) for h in ("ekf_kernels.hpp", "ekf_device.hpp", 
 OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so")   # FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds
 OBJDIR = os.environ.get("FBUS_OBJDIR") or os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("FBUS_OUT") else
                                                        "obj_" + os.path.splitext(os.path.basename(OUT))[0])
-FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4}
+FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4, "frames": 5}
 # Per-family scheduler choice (measured in one run, B = 65 536, tools/ab_bench.sh, gpurun_out/r02_ab2.log): the
 # max-ILP strategy of the AMDGPU machine scheduler shortens the per-call kernels, where one wave per SIMD has nothing
 # but its own independent instructions to cover dependent-issue stalls (predict 13.4 -> 13.05 us, stacked correct
@@ -29,7 +29,7 @@ FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4}
 # v_accvgpr traffic), which therefore keeps the default strategy.
 FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "correct": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-                "frame": [], "corners": []}
+                "frame": [], "corners": [], "frames": []}
 TYPES = {"f32": "float", "f64": "double"}
 
 
@@ -46,8 +46,8 @@ def units():
     for tn, t in TYPES.items():
         for n in (18, 15):
             for fam, code in FAMILIES.items():
-                if fam == "frame" and tn == "f64":
-                    continue                    # no fused fp64 kernel: fbus_ekf.hip runs predict_n + correct instead
+                if fam in ("frame", "frames") and tn == "f64":
+                    continue                    # no fused fp64 kernels: fbus_ekf.hip runs predict_n + correct instead
                 out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
                             [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"] +
                             # fp32 only: the fp64 kernels sit at the 512-register limit and spill more under max-ILP
@@ -88,7 +88,7 @@ def build(force=False, verbose=False, only=None, jobs=None):
         if force or _stale(obj, src) or (only and any(o in name for o in only)):
             todo.append((name, [hipcc()] + flags + defs + ["-c", src, "-o", obj]))
     # the fp64 / fused-frame units take longest: start them first
-    todo.sort(key=lambda u: (("f64" in u[0]) * 2 + ("frame" in u[0]) + ("correct" in u[0])), reverse=True)
+    todo.sort(key=lambda u: (("f64" in u[0]) * 2 + ("frame" in u[0]) + ("correct" in u[0])), reverse=True)  # "frame" matches "frames" too
     jobs = jobs or int(os.environ.get("FBUS_JOBS", "0")) or min(8, os.cpu_count() or 1)
 
     def run(u):

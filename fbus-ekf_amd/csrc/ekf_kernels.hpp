@@ -773,6 +773,110 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
 }
 
+// A WINDOW of camera frames in one launch (offline replay: the frame loop of FBUS_EKF.m:151-210 / FilterThreadFunction,
+// filter.cpp:229-235, over a recorded stretch): F times { K_f ImuUpdates, one MeasureUpdate } with the record resident in
+// registers from the first load to the last store.  frame_kernel pays the record's way in and out once per frame -- at one
+// wave per SIMD ~15 of its 38 us are that head and tail, during which the wave cannot compute; here they are paid once per
+// window.  Same device functions, same order of operations per filter as F fused frames (bit-identical results).
+struct FrameCounts { unsigned char k[FBUS_MAX_WINDOW_FRAMES]; };      // IMU samples in front of each frame
+template <typename T, int N, int DIALECT, int COV, bool JOINT>
+__global__ void __launch_bounds__(BLOCK)
+frames_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __restrict__ accel, const T* __restrict__ gyro,
+              const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+              const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
+              unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ MarkerLDS<T> tbl;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T nom[L::NNOM], P[RC::NCOVP];
+    {
+        MarkerTableRegs<T> treg;
+        treg.load(dc);
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_NOM, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
+        order_fence();
+        treg.to_lds(tbl);
+        order_fence();
+    }
+    if (b >= B) return;
+    int k0 = 0, last_used = 0;
+#pragma unroll 1
+    for (int f = 0; f < F; ++f) {
+        const int K = kc.k[f];
+        predict_steps<T, N, DIALECT>(nom, P, K, accel + (size_t)k0 * B * 3, gyro + (size_t)k0 * B * 3,
+                                     dt + (size_t)k0 * (dt_stride ? B : 1), dt_stride, B, b, dc.qd);
+        k0 += K;
+        const size_t fo = (size_t)f * B + b;
+        int first = 0, last = (M > 0 && !(skip && skip[fo])) ? M : 0;
+        int new_prev = -1;
+        const int* my_ids = ids + fo * M;
+        const T* my_pos = pos + fo * M * 3;
+        const T* my_quat = quat + fo * M * 4;
+        if (last > 0 && mode == MODE_NEAREST) {
+            const int prev_id = (DIALECT == DIALECT_CPP) ? (int)P[L::OFF_PREV - L::OFF_COV] : 0;
+            int min_i = -1, prev_i = -1;
+            T min_d = T(10), prev_d = T(0);
+            for (int i = 0; i < M; ++i) {
+                const int id = my_ids[i];
+                if (id < 0) continue;
+                const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
+                const T dist = fb_sqrt(x * x + y * y + z * z);
+                if (dist < min_d) { min_d = dist; min_i = i; }
+                if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+            }
+            if (min_i >= 0 && DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0))
+                min_i = prev_i;
+            int slot = -1, id = -1;
+            if (min_i >= 0) {
+                id = my_ids[min_i];
+                slot = (id >= 0 && id <= FBUS_MAX_MARKER_ID) ? (int)tbl.id2slot[id] : -1;
+            }
+            if (slot < 0) { first = last = 0; }
+            else {
+                if (DIALECT == DIALECT_CPP) new_prev = id;
+                first = min_i; last = min_i + 1;
+            }
+        }
+        T dx[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) dx[i] = T(0);
+        int used = 0;
+        InfoAcc<T> acc;
+        const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+        if (JOINT) acc.clear();
+        MarkerCommon<T, N> mc;
+        mc.build(nom, dc);
+        for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
+            MarkerGroup<T, FBUS_MARKER_GROUP> mg;
+            mg.fetch(my_ids, my_pos, my_quat, i0, last);
+            mg.resolve(tbl);
+#pragma unroll
+            for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
+                if (mg.slot[g] < 0) continue;
+                if constexpr (JOINT) marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
+                ++used;
+            }
+        }
+        if constexpr (JOINT) {
+            if (used > 0) joint_update<T, N, COV>(P, dx, acc);
+        }
+        if (used > 0) {
+            inject<T, N>(nom, dx);
+            if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+        }
+        last_used = used;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (M > 0 && F > 0) applied[b] = last_used > 0 ? 1 : 0;
+    store_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+}
+
 // The fused frame for launches of >= 2048 waves: at most 256 registers, two waves per SIMD (stacked mode, simple form).
 // frame_kernel holds the record in 383 registers and is VALU-bound with one wave per SIMD at 57 % issue utilisation;
 // from 131 072 filters on a second wave per SIMD fills its stalls.  What makes the 256 registers possible:

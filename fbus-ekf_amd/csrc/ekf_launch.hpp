@@ -27,6 +27,12 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
                     int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
                     const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
 
+// a window of F frames in one launch (fp32; not (Joseph, nearest)); kcount: F host bytes
+template <typename T, int N, int D>
+void launch_frames_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro,
+                     const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
+                     const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
+
 template <typename T, int N, int D>
 void launch_corners_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right,
                       int geometry, int mode, bool joseph, T size, const unsigned char* skip, unsigned char* applied,

@@ -315,6 +315,29 @@ int launch_frame(fbus_ekf_t h, int K, const void* accel, const void* gyro, const
     DISPATCH(h, launch_frame_t, h, K, accel, gyro, dt, per, M, ids, pos, quat, mode, skip);
 }
 
+template <typename T, int N, int D>
+int launch_frames_t(fbus_ekf_t h, int F, const unsigned char* kc, const void* accel, const void* gyro, const void* dt,
+                    int dt_per_filter, int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
+{
+    if constexpr (sizeof(T) == 4) {
+        const int ev = timing_begin(h, FBUS_KERNEL_FRAME, F);
+        h->records_warm = true;
+        launch_frames_k<T, N, D>(h->stream, (T*)h->recs, h->B, F, kc, (const T*)accel, (const T*)gyro, (const T*)dt,
+                                 dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+                                 h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+        timing_end(h, ev);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return FBUS_OK;
+}
+
+int launch_frames(fbus_ekf_t h, int F, const unsigned char* kc, const void* a, const void* g, const void* dt, int per, int M,
+                  const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
+{
+    DISPATCH(h, launch_frames_t, h, F, kc, a, g, dt, per, M, ids, pos, quat, mode, skip);
+}
+
+
 template <typename T, int N>
 int pack_t(fbus_ekf_t h, const void* nom, const void* rot, const void* P, const int32_t* prev)
 {
@@ -915,6 +938,42 @@ int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void*
     if (M > 0 && (!ids || !pos || !quat)) return FBUS_ERR_INVALID;
     if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     return launch_frame(h, K, accel, gyro, dt, dt_per_filter, M, ids, pos, quat, mode, skip);
+}
+
+int fbus_ekf_frames_fused_dev(fbus_ekf_t h, int nframes, const int32_t* kcount, const void* accel, const void* gyro,
+                              const void* dt, int dt_per_filter, int M, const int32_t* ids, const void* pos,
+                              const void* quat, int mode, const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || nframes < 0 || nframes > FBUS_MAX_WINDOW_FRAMES || M < 0 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (nframes > 0 && !kcount) return FBUS_ERR_INVALID;
+    if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    unsigned char kc[FBUS_MAX_WINDOW_FRAMES];
+    size_t total = 0;
+    for (int f = 0; f < nframes; ++f) {
+        if (kcount[f] < 0 || kcount[f] > 255) return FBUS_ERR_INVALID;
+        kc[f] = (unsigned char)kcount[f];
+        total += (size_t)kcount[f];
+    }
+    if (total > 0 && (!accel || !gyro || !dt)) return FBUS_ERR_INVALID;
+    if (M > 0 && nframes > 0 && (!ids || !pos || !quat)) return FBUS_ERR_INVALID;
+    if (nframes == 0) return FBUS_OK;
+    // no resident-record kernel for fp64 and for (Joseph, nearest) -- see launch_frame_t: those windows run frame by frame,
+    // the same arithmetic
+    const bool resident = h->dtype == 32 && !(h->prm.cov_form == FBUS_COV_JOSEPH && mode != FBUS_MODE_STACKED);
+    if (resident) return launch_frames(h, nframes, kc, accel, gyro, dt, dt_per_filter, M, ids, pos, quat, mode, skip);
+    const size_t es = esize(h), B = (size_t)h->B;
+    size_t k0 = 0;
+    for (int f = 0; f < nframes; ++f) {
+        const int rc = launch_frame(h, kc[f], (const char*)accel + k0 * B * 3 * es, (const char*)gyro + k0 * B * 3 * es,
+                                    (const char*)dt + k0 * (dt_per_filter ? B : 1) * es, dt_per_filter, M,
+                                    ids ? ids + (size_t)f * B * M : nullptr, pos ? (const char*)pos + (size_t)f * B * M * 3 * es : nullptr,
+                                    quat ? (const char*)quat + (size_t)f * B * M * 4 * es : nullptr, mode,
+                                    skip ? skip + (size_t)f * B : nullptr);
+        if (rc != FBUS_OK) return rc;
+        k0 += kc[f];
+    }
+    return FBUS_OK;
 }
 
 int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,

@@ -152,8 +152,33 @@ void launch_pixels_k(hipStream_t s, T* recs, int B, int M, const int* ids, const
                                                            const FBUS_TU_T*, const FBUS_TU_T*, bool, FBUS_TU_T,       \
                                                            FBUS_TU_T, const unsigned char*, unsigned char*,           \
                                                            const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&);
+#elif FBUS_TU_FAMILY == 5
+template <typename T, int N, int D>
+void launch_frames_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro,
+                     const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
+                     const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
+{
+    const int grid = (B + BLOCK - 1) / BLOCK;
+    const bool joint = mode == MODE_STACKED;
+    FrameCounts kc;
+    for (int f = 0; f < FBUS_MAX_WINDOW_FRAMES; ++f) kc.k[f] = f < F ? kcount[f] : 0;
+#define FBUS_LAUNCH_FRAMES(COV, JOINT)                                                                                \
+    hipLaunchKernelGGL((frames_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, F, kc, accel, gyro, dt, \
+                       dt_stride, M, ids, pos, quat, mode, skip, applied, dc)
+    // (Joseph form, nearest marker) is not built with the record resident, as for frame_kernel: the caller runs that
+    // combination frame by frame
+    if (joseph) { FBUS_LAUNCH_FRAMES(COV_JOSEPH, true); }
+    else        { if (joint) FBUS_LAUNCH_FRAMES(COV_SIMPLE, true); else FBUS_LAUNCH_FRAMES(COV_SIMPLE, false); }
+#undef FBUS_LAUNCH_FRAMES
+}
+#define FBUS_INST(D)                                                                                                  \
+    template void launch_frames_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const unsigned char*,   \
+                                                           const FBUS_TU_T*, const FBUS_TU_T*, const FBUS_TU_T*, int,  \
+                                                           int, const int*, const FBUS_TU_T*, const FBUS_TU_T*, int,   \
+                                                           bool, const unsigned char*, unsigned char*,                 \
+                                                           const DevConst<FBUS_TU_T>&);
 #else
-#error "FBUS_TU_FAMILY must be 1..4"
+#error "FBUS_TU_FAMILY must be 1..5"
 #endif
 
 FBUS_INST(DIALECT_MATLAB)

@@ -16,6 +16,7 @@ VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D = 0, 1, 2
 POSE_INIT, POSE_RESET = 0, 1
 L0_QUAT_MUL, L0_QUAT_TO_ROTMAT_M, L0_QUAT_TO_ROTMAT_E, L0_QUAT_NORMALIZE, L0_EXPM_SO3_NEG, L0_DTHETA_TO_QUAT, L0_SINCOS_HALF = range(7)
 MAX_MARKERS, MAX_VISIBLE = 32, 16
+MAX_WINDOW_FRAMES = 64           # fbus_ekf_frames_fused_dev
 STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
 
 
@@ -105,6 +106,7 @@ def load_library():
         "fbus_ekf_get_applied": ([H, u8p], C.c_int),
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_frames_fused_dev": ([H, C.c_int, ip, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_init_gravity_bias": ([H, C.c_int, vp, vp], C.c_int),
         "fbus_ekf_init_gravity_bias_dev": ([H, C.c_int, vp, vp], C.c_int),
         "fbus_ekf_pose_init": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),

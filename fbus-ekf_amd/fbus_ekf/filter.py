@@ -268,6 +268,34 @@ class BatchedFilter:
                                           self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
         self._check(rc, "frame_dev")
 
+    def frames(self, kcount, accel, gyro, dt, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
+        """A window of camera frames in ONE launch (device arrays): len(kcount) times { kcount[f] predicts, one correct }
+        with the records resident in registers in between -- the frame loop of FBUS_EKF.m:151-210 over a recorded stretch.
+        accel, gyro: (sum kcount, B, 3); dt: (sum kcount,) or (sum kcount, B); ids: (F, B, M); pos: (F, B, M, 3);
+        quat: (F, B, M, 4); skip: (F, B) or None.  applied() afterwards reports the last frame."""
+        B = self.B
+        kcount = np.ascontiguousarray(kcount, np.int32)
+        F, Kt = int(kcount.size), int(kcount.sum())
+        if F > capi.MAX_WINDOW_FRAMES:
+            raise ValueError(f"at most {capi.MAX_WINDOW_FRAMES} frames per window")
+        M = ids.numel() // (B * F) if (ids is not None and F > 0) else 0
+        per = 0
+        if Kt > 0:
+            per = 1 if (dt.numel() == Kt * B and B > 1) else 0
+            if not per and dt.numel() < Kt:
+                raise ValueError("dt must have sum(kcount) or sum(kcount)*B elements")
+            self._dev_checked(accel, Kt * B * 3, "accel"); self._dev_checked(gyro, Kt * B * 3, "gyro")
+            self._dev_checked(dt, dt.numel(), "dt")
+        if M > 0:
+            self._dev_checked(ids, F * B * M, "ids"); self._dev_checked(pos, F * B * M * 3, "pos")
+            self._dev_checked(quat, F * B * M * 4, "quat")
+        if skip is not None:
+            self._dev_checked(skip, F * B, "skip")
+        rc = self._lib.fbus_ekf_frames_fused_dev(self._h, F, kcount.ctypes.data_as(C.POINTER(C.c_int32)), self._p(accel),
+                                                 self._p(gyro), self._p(dt), per, M, self._p(ids), self._p(pos), self._p(quat),
+                                                 mode, self._p(skip))
+        self._check(rc, "frames_fused_dev")
+
     # ---- init / reset / front door (host arrays) --------------------------------------------
     def init_gravity_bias(self, accel, gyro):
         """InitGravityAndGyrobias.m:36-40: accel, gyro (T, B, 3) -> g, bg of every filter."""

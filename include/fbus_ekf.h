@@ -192,6 +192,19 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
 int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                              int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
 
+/* A WINDOW of camera frames in ONE launch (offline replay of a recorded stretch: the frame loop of
+ * matlab/FBUS_EKF.m:151-210 / FilterThreadFunction, filter.cpp:229-235): nframes times { kcount[f] predicts, one
+ * correct } with the records resident in registers from the first load to the last store.  Same arithmetic and
+ * results as nframes calls of fbus_ekf_frame_fused_dev.
+ *   kcount  HOST array, nframes entries (<= FBUS_MAX_WINDOW_FRAMES), each 0..255: IMU samples in front of frame f
+ *   accel, gyro  [sum kcount][B][3], dt [sum kcount] or [sum kcount][B] (dt_per_filter)       device
+ *   ids [nframes][B][M], pos [nframes][B][M][3], quat [nframes][B][M][4], skip [nframes][B] or NULL   device
+ * fbus_ekf_get_applied afterwards reports the LAST frame of the window. */
+#define FBUS_MAX_WINDOW_FRAMES 64
+int fbus_ekf_frames_fused_dev(fbus_ekf_t h, int nframes, const int32_t* kcount, const void* accel, const void* gyro,
+                              const void* dt, int dt_per_filter, int M, const int32_t* ids, const void* pos,
+                              const void* quat, int mode, const uint8_t* skip);
+
 /* ---- initialisation / reset (the callers' side of the path) ------------------- */
 /* Replaces: InitGravityAndGyrobias (matlab/InitGravityAndGyrobias.m:36-40) /
  * FILTER::InitializeGravityAndBias (filter.cpp:256-285).  accel, gyro: T x B x 3.
