@@ -84,6 +84,18 @@ public:
                    const Real* pos, const Real* quat, Mode mode = Mode::Nearest)
     { check(fbus_ekf_frame_dev(h_, K, accel, gyro, dt, 0, M, ids, pos, quat, int(mode), nullptr), "frame_dev"); }
 
+    // the same frame in one launch, and a window of frames in one launch (records resident in registers; offline replay)
+    void frame_fused_dev(int K, const Real* accel, const Real* gyro, const Real* dt, int M, const int32_t* ids,
+                         const Real* pos, const Real* quat, Mode mode = Mode::Nearest)
+    { check(fbus_ekf_frame_fused_dev(h_, K, accel, gyro, dt, 0, M, ids, pos, quat, int(mode), nullptr), "frame_fused_dev"); }
+    void frames_fused_dev(const std::vector<int32_t>& kcount, const Real* accel, const Real* gyro, const Real* dt, int M,
+                          const int32_t* ids, const Real* pos, const Real* quat, Mode mode = Mode::Nearest,
+                          const uint8_t* skip = nullptr)
+    {
+        check(fbus_ekf_frames_fused_dev(h_, int(kcount.size()), kcount.data(), accel, gyro, dt, 0, M, ids, pos, quat, int(mode), skip),
+              "frames_fused_dev");
+    }
+
     // correct() from corner pixels (north-star extension): left / right (B, M, 8) normalised image points, right may be null
     void correct_pixels(int M, const int32_t* ids, const Real* left, const Real* right = nullptr, const uint8_t* skip = nullptr)
     { check(fbus_ekf_correct_pixels(h_, M, ids, left, right, skip), "correct_pixels"); }
