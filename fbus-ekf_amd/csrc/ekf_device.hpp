@@ -27,7 +27,7 @@
 namespace fbus {
 
 enum { DIALECT_MATLAB = 0, DIALECT_CPP = 1 };
-enum { MODE_NEAREST = 0, MODE_STACKED = 1 };
+enum { MODE_NEAREST = 0, MODE_STACKED = 1, MODE_MEAS_VEC = 0x100 /* kernel-internal flag, see MarkerGroup::fetch */ };
 enum { COV_SIMPLE = 0, COV_JOSEPH = 1 };
 
 constexpr int MK_STRIDE = 8;    // per marker-map slot: pos3 quat4 pad1

@@ -216,9 +216,41 @@ template <typename T, int G>
 struct MarkerGroup {
     int id[G], slot[G], n;          // n = slots of this group that exist (the loaded values are not touched in fetch)
     T yp[G][3], yq[G][4], mk[G][MK_STRIDE];
-    __device__ __forceinline__ void fetch(const int* my_ids, const T* my_pos, const T* my_quat, int i0, int last)
+    // vec (wave-uniform; G == 4, M % 4 == 0 and 16-byte aligned arrays, checked by the launcher): the group's 4 ids, 12 position
+    // and 16 quaternion values as 8 16-byte loads per lane instead of 32 4-byte ones (fp64: 15 instead of 32)
+    __device__ __forceinline__ void fetch(const int* my_ids, const T* my_pos, const T* my_quat, int i0, int last, bool vec = false)
     {
         n = last - i0;
+        if (G == 4 && vec) {
+            constexpr int EP = 16 / (int)sizeof(T);
+            const u32x4 vi = *reinterpret_cast<const u32x4*>(my_ids + i0);
+            const u32x4* pp = reinterpret_cast<const u32x4*>(my_pos + 3 * i0);
+            const u32x4* pq = reinterpret_cast<const u32x4*>(my_quat + 4 * i0);
+            T bp[12], bq[16];
+#pragma unroll
+            for (int c = 0; c < 12 / EP; ++c) {
+                const u32x4 v = pp[c];
+                const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                for (int k = 0; k < EP; ++k) bp[c * EP + k] = e[k];
+            }
+#pragma unroll
+            for (int c = 0; c < 16 / EP; ++c) {
+                const u32x4 v = pq[c];
+                const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                for (int k = 0; k < EP; ++k) bq[c * EP + k] = e[k];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                id[g] = (int)vi[g];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) yp[g][k] = bp[3 * g + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) yq[g][k] = bq[4 * g + k];
+            }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int i = (i0 + g < last) ? i0 + g : last - 1;
@@ -476,6 +508,8 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     using L = Lay<N>;
     using RC = Rec<T, N>;
     constexpr int G = FBUS_MARKER_GROUP;
+    const bool vec = (mode & MODE_MEAS_VEC) != 0;     // set by the launcher: 16-byte loads of the measurement inputs are legal
+    mode &= ~MODE_MEAS_VEC;
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     const bool live = b < B && !(skip && skip[b < B ? b : 0]);
     const int bc = live ? b : 0;
@@ -520,7 +554,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         treg.load(dc);
         order_fence();
         if (!JOINT && DIALECT == DIALECT_CPP) prev_raw = recs[elem_index<T, N>(bc, L::OFF_PREV)];
-        if (M > 0) mg.fetch(my_ids, my_pos, my_quat, 0, M);
+        if (M > 0) mg.fetch(my_ids, my_pos, my_quat, 0, M, vec);
         order_fence();
         // the whole nominal state up front (p, q, R for the rows; v, ba, bg, g only for the injection -- 12 registers
         // that save a dependent reload between the last update and the stores)
@@ -568,7 +602,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         // nothing -- so that the nominal loads it needs stay where they were issued; further groups in a loop
         fold_group();
         for (int i0 = G; i0 < last; i0 += G) {
-            mg.fetch(my_ids, my_pos, my_quat, i0, last);
+            mg.fetch(my_ids, my_pos, my_quat, i0, last, vec);
             fold_group();
         }
         if constexpr (LEAN) {
@@ -618,7 +652,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         };
         scan_group();
         for (int i0 = G; i0 < last; i0 += G) {
-            mg.fetch(my_ids, my_pos, my_quat, i0, last);
+            mg.fetch(my_ids, my_pos, my_quat, i0, last, vec);
             scan_group();
         }
         if (min_id >= 0 && DIALECT == DIALECT_CPP && pv_id >= 0 && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) {

@@ -67,6 +67,10 @@ void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
     const bool joint = mode == MODE_STACKED;
+    // measurement inputs as 16-byte loads where that is legal (groups of four markers, aligned arrays)
+    if (M % 4 == 0 && ((reinterpret_cast<uintptr_t>(ids) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(quat)) & 15) == 0 &&
+        !getenv("FBUS_NO_MEAS_VEC"))
+        mode |= MODE_MEAS_VEC;
 #define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                              \
     hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, pos, quat, \
                        mode, skip, applied, dc)
