@@ -830,9 +830,22 @@ def test_frame_entry_points_validate_before_they_launch():
             assert fn(h, K, p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), None, p(d_quat), 1, None) == 1       # NULL pos
             assert fn(h, K, p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 7, None) == 4   # unknown mode
             assert fn(h, -1, p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1
+        # the frame-window entry point: the same checks, plus its frame counts
+        fw = lib.fbus_ekf_frames_fused_dev
+        kc = lambda *v: (C.c_int32 * len(v))(*v)
+        assert fw(h, 1, kc(K), None, p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1             # NULL accel
+        assert fw(h, 1, None, p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1          # NULL kcount
+        assert fw(h, 65, kc(*([0] * 65)), p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1   # too many frames
+        assert fw(h, 1, kc(256), p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1        # count > 255
+        assert fw(h, 1, kc(-1), p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 1, None) == 1
+        assert fw(h, 1, kc(K), p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), None, 1, None) == 1              # NULL quat
+        assert fw(h, 1, kc(K), p(d_acc), p(d_gyr), p(d_dt), 0, M, p(d_ids), p(d_pos), p(d_quat), 3, None) == 4         # unknown mode
+        assert fw(h, 0, None, None, None, None, 0, 0, None, None, None, 1, None) == 0                                   # empty window: nothing to do
         flt.sync()
         after = flt.get_state()
         assert all(np.array_equal(x, y) for x, y in zip(before, after))         # nothing was launched
+        with pytest.raises(ValueError):
+            flt.frames([K], d_acc, d_gyr[:2], d_dt, d_ids, d_pos, d_quat, 1)      # gyro of the wrong size
         with pytest.raises(ValueError):
             flt.frame(d_acc, d_gyr[:2], d_dt, d_ids, d_pos, d_quat, 1)            # gyro of the wrong size
         with pytest.raises(ValueError):
