@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json config 5: batch 65 536, M = 16 markers per frame (stacked, 112 rows of 7 per marker),
 fp32 vs fp64 on the GPU: per-step and 1 s (30 frames) error of fp32 against fp64, and the fp64/fp32 timing.
-(The per-corner 128-row form has no reference counterpart and is not built; the stacked pose rows are.)"""
+(The per-corner 128 / 256-row pixel form of the same config is tests/test_pixels_gpu.py::test_config5_128_reprojection_rows_at_full_batch;
+the wall times printed here include a host synchronisation per launch -- kernel times are in profiles/r02_run_configs.txt.)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
