@@ -32,7 +32,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 // nt on the once-read record stream of predict 18.05 -> 17.30 us; nt on lines that are re-read +9 %; nt STORES win in
 // the streamed predict kernel (the lines leave L2 while the launch still reads: 14.9 -> 14.0 us) and lose in correct
 // (its default-policy stores are what puts the records back into the Infinity Cache for the predicts that follow).
-constexpr int AUX_DEFAULT = 0, AUX_NT = 2;
+constexpr int AUX_DEFAULT = 0, AUX_NT = 2, AUX_SC1 = 16;
 // Per-step inputs (IMU samples, marker measurements) are read once: nt as well.  Measured: with default-policy
 // loads of 1.5 MB of fresh IMU data per launch the nt-streamed records lose their Infinity Cache residency and a
 // predict launch takes 13.8 us instead of 11.8 us (tools/exp_predict_timeline.hip).
@@ -40,7 +40,12 @@ template <typename T>
 __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_load(p); }
 // experiment knobs (tools/ab_bench.sh builds variants with -D...)
 #ifndef FBUS_X_CORRECT_ST
-#define FBUS_X_CORRECT_ST AUX_DEFAULT
+// record stores of the per-call correct: sc1 = write-through.  The lines reach the Infinity Cache at once instead of sitting
+// dirty in the XCD's L2 until something evicts them, and the predict that follows streams them with the same non-temporal
+// loads as every other predict: correct 20.9 -> 19.0 us (HIP events), headline 4.94e9 -> 5.03e9 at 65 536 filters, +0.8 % /
+// +0.6 % at 131 072 / 262 144 (round 1's answer to the same problem, default-policy loads in the first predict behind a
+// correct, is no longer used behind correct; sc1 + nt stores lose: gpurun_out/r02_sc1.log)
+#define FBUS_X_CORRECT_ST AUX_SC1
 #endif
 #ifndef FBUS_X_SPLIT
 #define FBUS_X_SPLIT RC::CH_VAR_END

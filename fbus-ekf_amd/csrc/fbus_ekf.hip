@@ -249,7 +249,7 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
                      const uint8_t* skip)
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
-    h->records_warm = true;
+    h->records_warm = false;        // written through (sc1): the next predict streams them like any other
     launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
                               h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
     timing_end(h, ev);
