@@ -56,11 +56,17 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_STREAM_ST
 #define FBUS_X_STREAM_ST 1      // stacked correct / fused frame: the last rank-1 pass stores each chunk when its rows are final
 #endif
+#ifndef FBUS_X_FRAME_ST
+#define FBUS_X_FRAME_ST AUX_DEFAULT    // record stores of the fused frame / frame window kernels
+#endif
 #ifndef FBUS_X_PREDICT_ST
 #define FBUS_X_PREDICT_ST AUX_NT       // store policy of the streamed per-call predict
 #endif
 #ifndef FBUS_X_CORRECT_LD
-#define FBUS_X_CORRECT_LD AUX_NT       // load policy of the covariance in the correct kernels
+// load policy of the covariance in the correct kernels.  Default policy since correct writes through (sc1): three runs each on
+// one box 5.025e9-5.035e9 (nt) -> 5.043e9-5.064e9 (the predicts behind it 12.72 -> 12.55 us, correct itself +1 us by HIP events);
+// also tried there: sc1 record stores in predict 4.50e9, sc1 / nt stores in the fused frame kernel 1.34e10 / 1.29e10 (unchanged / worse)
+#define FBUS_X_CORRECT_LD AUX_DEFAULT
 #endif
 #ifndef FBUS_X_CORRECT_STAGGER_BIT
 #define FBUS_X_CORRECT_STAGGER_BIT 3
@@ -797,7 +803,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     bool streamed = false;
     if constexpr (joint) {
         if (used > 0) {
-            if constexpr (STREAM_ST) { joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, AUX_DEFAULT>{ rs, my_lane(), P }); streamed = true; }
+            if constexpr (STREAM_ST) { joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_FRAME_ST>{ rs, my_lane(), P }); streamed = true; }
             else joint_update<T, N, COV>(P, dx, acc);
         }
     }
@@ -806,10 +812,10 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
         if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     }
     if (M > 0) applied[b] = used > 0 ? 1 : 0;
-    store_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
-    constexpr int C_REST = RowStore<T, N, AUX_DEFAULT>::streamed_end();
-    if (!streamed) store_chunks<T, N, RC::CH_NOM, C_REST>(rs, my_lane(), P);
-    store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
+    store_chunks<T, N, 0, RC::CH_NOM, FBUS_X_FRAME_ST>(rs, my_lane(), nom);
+    constexpr int C_REST = RowStore<T, N, FBUS_X_FRAME_ST>::streamed_end();
+    if (!streamed) store_chunks<T, N, RC::CH_NOM, C_REST, FBUS_X_FRAME_ST>(rs, my_lane(), P);
+    store_chunks<T, N, C_REST, RC::NCH, FBUS_X_FRAME_ST>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
 }
 
 // A WINDOW of camera frames in one launch (offline replay: the frame loop of FBUS_EKF.m:151-210 / FilterThreadFunction,
@@ -912,8 +918,8 @@ frames_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __res
         __builtin_amdgcn_sched_barrier(0);
     }
     if (M > 0 && F > 0) applied[b] = last_used > 0 ? 1 : 0;
-    store_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, my_lane(), P);
+    store_chunks<T, N, 0, RC::CH_NOM, FBUS_X_FRAME_ST>(rs, my_lane(), nom);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_FRAME_ST>(rs, my_lane(), P);
 }
 
 // The fused frame for launches of >= 2048 waves: at most 256 registers, two waves per SIMD (stacked mode, simple form).
