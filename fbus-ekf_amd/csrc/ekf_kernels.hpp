@@ -59,6 +59,9 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_FRAME_ST
 #define FBUS_X_FRAME_ST AUX_DEFAULT    // record stores of the fused frame / frame window kernels
 #endif
+#ifndef FBUS_X_PREDICT_LD
+#define FBUS_X_PREDICT_LD AUX_NT       // record-load policy of the streamed per-call predict (records that fit the Infinity Cache)
+#endif
 #ifndef FBUS_X_PREDICT_ST
 #define FBUS_X_PREDICT_ST AUX_NT       // store policy of the streamed per-call predict
 #endif

@@ -38,7 +38,7 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
                        dt_stride, dc)
         if (policy == 2) FBUS_LAUNCH_PREDICT(AUX_DEFAULT, AUX_DEFAULT);      // records larger than the Infinity Cache
         else if (policy == 1) FBUS_LAUNCH_PREDICT(AUX_DEFAULT, AUX_NT);      // first predict behind a default-policy writer
-        else FBUS_LAUNCH_PREDICT(AUX_NT, FBUS_X_PREDICT_ST);
+        else FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD, FBUS_X_PREDICT_ST);
 #undef FBUS_LAUNCH_PREDICT
     } else if constexpr (sizeof(T) == 8) {
         // fp64 is the verification path: K resident steps need more than the 512 registers a lane has in fp64 (the
