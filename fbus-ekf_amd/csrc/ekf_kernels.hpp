@@ -62,6 +62,12 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_PREDICT_LD
 #define FBUS_X_PREDICT_LD AUX_NT       // record-load policy of the streamed per-call predict (records that fit the Infinity Cache)
 #endif
+#ifndef FBUS_X_PREDICT_LD_BIG
+#define FBUS_X_PREDICT_LD_BIG AUX_DEFAULT      // ... and of records that do not fit it (> 160 MB)
+#endif
+#ifndef FBUS_X_PREDICT_ST_BIG
+#define FBUS_X_PREDICT_ST_BIG AUX_DEFAULT
+#endif
 #ifndef FBUS_X_PREDICT_ST
 #define FBUS_X_PREDICT_ST AUX_NT       // store policy of the streamed per-call predict
 #endif
