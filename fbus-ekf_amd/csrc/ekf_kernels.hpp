@@ -549,7 +549,14 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     // the stacked path asks for the predict-invariant covariance tail behind the fold: fewer registers are tied up
     // while the rows are built, and the first scalar update only needs it for its last rows
     constexpr int C_SPLIT = JOINT ? FBUS_X_SPLIT : RC::NCH;
-    constexpr bool STREAM_ST = JOINT && FBUS_X_STREAM_ST;
+#ifndef FBUS_X_NEAREST_INFO
+#define FBUS_X_NEAREST_INFO 1     // the reference mode (one marker, 7 rows) through the information form too: 6 passes, streamed stores
+#endif
+    // fp32 reference mode: the 7 rows of the chosen marker are folded like the rows of the stacked mode and applied as six
+    // rank-1 passes whose last one streams the stores (instead of 7 row-by-row updates and a store phase behind them); the
+    // same posterior -- the reference itself solves the 7 x 7 system at once (inv / LDLT), neither form is its operation order
+    constexpr bool NEAREST_INFO = !JOINT && FBUS_X_NEAREST_INFO && COV == COV_SIMPLE;
+    constexpr bool STREAM_ST = (JOINT || NEAREST_INFO) && FBUS_X_STREAM_ST;
     // fp64 (LEAN): 171 covariance doubles are 342 of the 512 registers.  The six passes run in the row-split form
     // (joint_apply_early / joint_apply_late, ekf_device.hpp): factorise first, then bring in storage rows 0..8 only, run
     // the passes on them (the last one streams them out), then bring in rows 9..17 and give them their six rank-1
@@ -705,7 +712,15 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
             MarkerCommon<T, N> mc;
             mc.build(nom, dc);
-            marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mk, min_y, min_y + 3);
+            if constexpr (NEAREST_INFO) {
+                InfoAcc<T> acc;
+                acc.clear();
+                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mk, min_y, min_y + 3, T(1) / dc.r_pos, T(1) / dc.r_quat);
+                if constexpr (STREAM_ST) joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_CORRECT_ST>{ rs, my_lane(), P });
+                else joint_update<T, N, COV>(P, dx, acc);
+            } else {
+                marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mk, min_y, min_y + 3);
+            }
             used = 1;
         }
     }
