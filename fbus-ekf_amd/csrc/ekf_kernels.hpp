@@ -806,7 +806,8 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0;
     InfoAcc<T> acc;
-    constexpr bool joint = JOINT;
+    // the reference mode in the simple form goes through the information fold as well (see correct_kernel: NEAREST_INFO)
+    constexpr bool joint = JOINT || COV == COV_SIMPLE;
     const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
     if (joint) acc.clear();
     MarkerCommon<T, N> mc;
@@ -823,7 +824,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
             ++used;
         }
     }
-    constexpr bool STREAM_ST = JOINT && FBUS_X_STREAM_ST;
+    constexpr bool STREAM_ST = joint && FBUS_X_STREAM_ST;
     bool streamed = false;
     if constexpr (joint) {
         if (used > 0) {
@@ -916,7 +917,8 @@ frames_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __res
         int used = 0;
         InfoAcc<T> acc;
         const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
-        if (JOINT) acc.clear();
+        constexpr bool INFO = JOINT || COV == COV_SIMPLE;      // reference mode, simple form: through the information fold too
+        if (INFO) acc.clear();
         MarkerCommon<T, N> mc;
         mc.build(nom, dc);
         for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
@@ -926,12 +928,12 @@ frames_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __res
 #pragma unroll
             for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
                 if (mg.slot[g] < 0) continue;
-                if constexpr (JOINT) marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                if constexpr (INFO) marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
                 else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
                 ++used;
             }
         }
-        if constexpr (JOINT) {
+        if constexpr (INFO) {
             if (used > 0) joint_update<T, N, COV>(P, dx, acc);
         }
         if (used > 0) {
