@@ -1583,51 +1583,169 @@ __global__ void l0_eval_kernel(int op, int n, const T* __restrict__ a, const T* 
     }
 }
 
-// AoS (API arrays) <-> records.  Not on the hot path.
+// AoS (API arrays) <-> records.  Not on the hot path, but the API arrays are filter-major (1296 bytes of P per filter) and the
+// records lane-major, so a lane-per-filter copy touches a different cache line with every 4-byte access (the round-1 kernels:
+// 0.35 of peak with 9x write amplification on the unpack side).  One wave per 64-filter tile: the tile's records pass
+// through LDS ([filter][element], odd pitch), the records move as 1 KiB chunk loads / stores and the API arrays as
+// lane-consecutive accesses over the tile's contiguous stretch of each array.
 template <typename T, int N>
-__global__ void pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ nominal,
-                            const T* __restrict__ rot, const T* __restrict__ P, const int* __restrict__ prev)
-{
+struct TileIO {
     using L = Lay<N>;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    auto put = [&](int e, T v) { recs[elem_index<T, N>(b, e)] = v; };
-    // API order p v q ba bg g -> record order
-    const int map[19] = { L::OFF_P3, L::OFF_P3 + 1, L::OFF_P3 + 2, L::OFF_V, L::OFF_V + 1, L::OFF_V + 2,
-                          L::OFF_Q, L::OFF_Q + 1, L::OFF_Q + 2, L::OFF_Q + 3, L::OFF_BA, L::OFF_BA + 1, L::OFF_BA + 2,
-                          L::OFF_BG, L::OFF_BG + 1, L::OFF_BG + 2, L::OFF_G, L::OFF_G + 1, L::OFF_G + 2 };
-    if (nominal) for (int i = 0; i < 19; ++i) put(map[i], nominal[(size_t)b * 19 + i]);
-    if (rot) for (int i = 0; i < 9; ++i) put(L::OFF_R + i, rot[(size_t)b * 9 + i]);
-    if (prev) put(L::OFF_PREV, (T)prev[b]);
-    if (P)
-        for (int i = 0; i < N; ++i)
-            for (int j = i; j < N; ++j) {   // the reference symmetrises every step; store the mean of the two halves
-                const T u = P[((size_t)b * N + i) * N + j], l = P[((size_t)b * N + j) * N + i];
-                put(L::OFF_COV + pidx<N>(i, j), (u + l) / 2);
+    using RC = Rec<T, N>;
+    static constexpr int NR = RC::NRECP;
+    static constexpr int PITCH = NR | 1;                   // odd: lanes writing their own record hit different banks
+    // record element of API nominal element i (API order p v q ba bg g)
+    __device__ static int nom_elem(int i)
+    {
+        return i < 3 ? L::OFF_P3 + i : i < 6 ? L::OFF_V + (i - 3) : i < 10 ? L::OFF_Q + (i - 6)
+             : i < 13 ? L::OFF_BA + (i - 10) : i < 16 ? L::OFF_BG + (i - 13) : L::OFF_G + (i - 16);
+    }
+    __device__ static int cov_elem(int r)                  // r = i * N + j of the full matrix
+    {
+        const int i = r / N, j = r - i * N;
+        return L::OFF_COV + (i <= j ? pidx<N>(i, j) : pidx<N>(j, i));
+    }
+};
+
+template <typename T, int N>
+__global__ void __launch_bounds__(BLOCK)
+pack_kernel(T* __restrict__ recs, int B, const T* __restrict__ nominal, const T* __restrict__ rot,
+            const T* __restrict__ P, const int* __restrict__ prev)
+{
+    using IO = TileIO<T, N>;
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    __shared__ T lds[BLOCK * IO::PITCH];
+    __shared__ short tab[N * N];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const int nvalid = min(BLOCK, B - tile * BLOCK);
+    const size_t f0 = (size_t)tile * BLOCK;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    T rec[IO::NR];
+    // Only the parts of the record that the caller supplies are read, patched and written back (whatever is not supplied
+    // stays as it is): the nominal chunks for nominal / rot, the covariance chunks for P, the last chunk for prev alone.
+    const bool do_nom = nominal || rot, do_cov = P != nullptr, do_prev = prev != nullptr;
+    constexpr int CN = RC::CH_NOM, EPC = RC::EPC, CL = RC::NCH - 1;
+    if (do_nom) {
+        load_chunks<T, N, 0, CN>(rs, lane, rec);
+#pragma unroll
+        for (int e = 0; e < CN * EPC; ++e) lds[lane * IO::PITCH + e] = rec[e];
+    }
+    if (do_cov) {
+        load_chunks<T, N, CN, RC::NCH>(rs, lane, rec + CN * EPC);
+#pragma unroll
+        for (int e = CN * EPC; e < IO::NR; ++e) lds[lane * IO::PITCH + e] = rec[e];
+        for (int r = lane; r < N * N; r += BLOCK) {            // tab[packed index] = i * N + j of the upper-triangle element stored there
+            const int ii = r / N, jj = r - ii * N;
+            if (ii <= jj) tab[IO::cov_elem(r) - L::OFF_COV] = (short)r;
+        }
+    } else if (do_prev) {
+        load_chunks<T, N, CL, RC::NCH>(rs, lane, rec + CL * EPC);
+#pragma unroll
+        for (int e = CL * EPC; e < IO::NR; ++e) lds[lane * IO::PITCH + e] = rec[e];
+    }
+    __syncthreads();
+    if (nominal)
+        for (int o = lane; o < nvalid * 19; o += BLOCK) {
+            const int f = o / 19, i = o - f * 19;
+            lds[f * IO::PITCH + IO::nom_elem(i)] = nominal[f0 * 19 + o];
+        }
+    if (rot)
+        for (int o = lane; o < nvalid * 9; o += BLOCK) {
+            const int f = o / 9, i = o - f * 9;
+            lds[f * IO::PITCH + L::OFF_R + i] = rot[f0 * 9 + o];
+        }
+    if (prev && lane < nvalid) lds[lane * IO::PITCH + L::OFF_PREV] = (T)prev[f0 + lane];
+    if (P) {
+        // the reference symmetrises every step: store the mean of the two halves.  One packed element per lane and iteration:
+        // both halves are read by the same lane (the upper one nearly lane-consecutive, the lower one strided -- all inside the
+        // tile's 83 KB stretch of P, which stays in cache), UB pairs of loads are requested before the first is used (three waves
+        // fit a CU beside their 51 KiB of LDS: a load per loop iteration would cost its whole latency 648 times).
+        constexpr int UB = 9, NN = N * N, NP = L::NP;
+        const int total = nvalid * NP;
+        const T* src = P + f0 * NN;
+        for (int o0 = lane; o0 < total; o0 += BLOCK * UB) {
+            T u[UB], l[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int o = o0 + k * BLOCK < total ? o0 + k * BLOCK : 0;
+                const int f = o / NP, q = o - f * NP, r = tab[q], i = r / N, jj = r - i * N;
+                u[k] = src[f * NN + r];
+                l[k] = src[f * NN + jj * N + i];
             }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int o = o0 + k * BLOCK;
+                const int f = o / NP, q = o - f * NP;
+                if (o < total) lds[f * IO::PITCH + L::OFF_COV + q] = (u[k] + l[k]) / 2;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane >= nvalid) return;
+    if (do_nom) {
+#pragma unroll
+        for (int e = 0; e < CN * EPC; ++e) rec[e] = lds[lane * IO::PITCH + e];
+        store_chunks<T, N, 0, CN>(rs, lane, rec);
+    }
+    if (do_cov) {
+#pragma unroll
+        for (int e = CN * EPC; e < IO::NR; ++e) rec[e] = lds[lane * IO::PITCH + e];
+        store_chunks<T, N, CN, RC::NCH>(rs, lane, rec + CN * EPC);
+    } else if (do_prev) {
+#pragma unroll
+        for (int e = CL * EPC; e < IO::NR; ++e) rec[e] = lds[lane * IO::PITCH + e];
+        store_chunks<T, N, CL, RC::NCH>(rs, lane, rec + CL * EPC);
+    }
 }
 
 template <typename T, int N>
-__global__ void unpack_kernel(const T* __restrict__ recs, int B, T* __restrict__ nominal,
-                              T* __restrict__ rot, T* __restrict__ P, int* __restrict__ prev)
+__global__ void __launch_bounds__(BLOCK)
+unpack_kernel(const T* __restrict__ recs, int B, T* __restrict__ nominal, T* __restrict__ rot, T* __restrict__ P,
+              int* __restrict__ prev)
 {
+    using IO = TileIO<T, N>;
     using L = Lay<N>;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    auto get = [&](int e) { return recs[elem_index<T, N>(b, e)]; };
-    const int map[19] = { L::OFF_P3, L::OFF_P3 + 1, L::OFF_P3 + 2, L::OFF_V, L::OFF_V + 1, L::OFF_V + 2,
-                          L::OFF_Q, L::OFF_Q + 1, L::OFF_Q + 2, L::OFF_Q + 3, L::OFF_BA, L::OFF_BA + 1, L::OFF_BA + 2,
-                          L::OFF_BG, L::OFF_BG + 1, L::OFF_BG + 2, L::OFF_G, L::OFF_G + 1, L::OFF_G + 2 };
-    if (nominal) for (int i = 0; i < 19; ++i) nominal[(size_t)b * 19 + i] = get(map[i]);
-    if (rot) for (int i = 0; i < 9; ++i) rot[(size_t)b * 9 + i] = get(L::OFF_R + i);
-    if (prev) prev[b] = (int)get(L::OFF_PREV);
+    using RC = Rec<T, N>;
+    __shared__ T lds[BLOCK * IO::PITCH];
+    __shared__ short tab[N * N];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const int nvalid = min(BLOCK, B - tile * BLOCK);
+    const size_t f0 = (size_t)tile * BLOCK;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    T rec[IO::NR];
+    // only the parts that are asked for are read
+    constexpr int CN = RC::CH_NOM, EPC = RC::EPC, CL = RC::NCH - 1;
+    if (nominal || rot) {
+        load_chunks<T, N, 0, CN>(rs, lane, rec);
+#pragma unroll
+        for (int e = 0; e < CN * EPC; ++e) lds[lane * IO::PITCH + e] = rec[e];
+    }
+    if (P) {
+        load_chunks<T, N, CN, RC::NCH>(rs, lane, rec + CN * EPC);
+#pragma unroll
+        for (int e = CN * EPC; e < IO::NR; ++e) lds[lane * IO::PITCH + e] = rec[e];
+        for (int r = lane; r < N * N; r += BLOCK) tab[r] = (short)IO::cov_elem(r);
+    } else if (prev) {
+        load_chunks<T, N, CL, RC::NCH>(rs, lane, rec + CL * EPC);
+    }
+    __syncthreads();
+    if (nominal)
+        for (int o = lane; o < nvalid * 19; o += BLOCK) {
+            const int f = o / 19, i = o - f * 19;
+            nominal[f0 * 19 + o] = lds[f * IO::PITCH + IO::nom_elem(i)];
+        }
+    if (rot)
+        for (int o = lane; o < nvalid * 9; o += BLOCK) {
+            const int f = o / 9, i = o - f * 9;
+            rot[f0 * 9 + o] = lds[f * IO::PITCH + L::OFF_R + i];
+        }
+    if (prev && lane < nvalid) prev[f0 + lane] = (int)rec[L::OFF_PREV];
     if (P)
-        for (int i = 0; i < N; ++i)
-            for (int j = i; j < N; ++j) {
-                const T v = get(L::OFF_COV + pidx<N>(i, j));
-                P[((size_t)b * N + i) * N + j] = v;
-                P[((size_t)b * N + j) * N + i] = v;
-            }
+        for (int o = lane; o < nvalid * N * N; o += BLOCK) {
+            const int f = o / (N * N), r = o - f * (N * N);
+            P[f0 * N * N + o] = lds[f * IO::PITCH + tab[r]];
+        }
 }
 
 template <typename T, int N>

@@ -341,8 +341,8 @@ int launch_frames(fbus_ekf_t h, int F, const unsigned char* kc, const void* a, c
 template <typename T, int N>
 int pack_t(fbus_ekf_t h, const void* nom, const void* rot, const void* P, const int32_t* prev)
 {
-    const int grid = (h->B + 255) / 256;
-    hipLaunchKernelGGL((pack_kernel<T, N>), dim3(grid), dim3(256), 0, h->stream, (T*)h->recs, h->B,
+    const int grid = (h->B + BLOCK - 1) / BLOCK;             // one wave per 64-filter tile
+    hipLaunchKernelGGL((pack_kernel<T, N>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,
                        (const T*)nom, (const T*)rot, (const T*)P, (const int*)prev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -351,8 +351,8 @@ int pack_t(fbus_ekf_t h, const void* nom, const void* rot, const void* P, const 
 template <typename T, int N>
 int unpack_t(fbus_ekf_t h, void* nom, void* rot, void* P, int32_t* prev)
 {
-    const int grid = (h->B + 255) / 256;
-    hipLaunchKernelGGL((unpack_kernel<T, N>), dim3(grid), dim3(256), 0, h->stream, (const T*)h->recs, h->B,
+    const int grid = (h->B + BLOCK - 1) / BLOCK;             // one wave per 64-filter tile
+    hipLaunchKernelGGL((unpack_kernel<T, N>), dim3(grid), dim3(BLOCK), 0, h->stream, (const T*)h->recs, h->B,
                        (T*)nom, (T*)rot, (T*)P, (int*)prev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
