@@ -1749,17 +1749,25 @@ unpack_kernel(const T* __restrict__ recs, int B, T* __restrict__ nominal, T* __r
 }
 
 template <typename T, int N>
-__global__ void reset_cov_kernel(T* __restrict__ recs, int B, T d0, T d1, T d2, T d3, T d4, T d5)
+__global__ void __launch_bounds__(BLOCK)
+reset_cov_kernel(T* __restrict__ recs, int B, T d0, T d1, T d2, T d3, T d4, T d5)
 {
+    // P = diag(P0) for every filter: the covariance chunks are built in registers and stored whole (1 KiB per store
+    // instruction); the last chunk also holds the previous-marker id, so it is read, patched and written back
     using L = Lay<N>;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    using RC = Rec<T, N>;
+    constexpr int CN = RC::CH_NOM, EPC = RC::EPC, CL = RC::NCH - 1;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    T cov[RC::NCOVP];
+    load_chunks<T, N, CL, RC::NCH>(rs, my_lane(), cov + (CL - CN) * EPC);
     const T d[6] = { d0, d1, d2, d3, d4, d5 };
-    for (int i = 0; i < N; ++i)
-        for (int j = i; j < N; ++j) {
-            const int e = L::OFF_COV + pidx<N>(i, j);
-            recs[elem_index<T, N>(b, e)] = (i == j) ? d[i / 3] : T(0);
-        }
+#pragma unroll
+    for (int e = 0; e < L::NP; ++e) cov[e] = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) cov[pidx<N>(i, i)] = d[i / 3];
+    if (b >= B) return;
+    store_chunks<T, N, CN, RC::NCH>(rs, my_lane(), cov);
 }
 
 }  // namespace

@@ -361,9 +361,9 @@ int unpack_t(fbus_ekf_t h, void* nom, void* rot, void* P, int32_t* prev)
 template <typename T, int N>
 int reset_cov_t(fbus_ekf_t h)
 {
-    const int grid = (h->B + 255) / 256;
+    const int grid = (h->B + BLOCK - 1) / BLOCK;
     const double* d = h->prm.p0_diag;
-    hipLaunchKernelGGL((reset_cov_kernel<T, N>), dim3(grid), dim3(256), 0, h->stream, (T*)h->recs, h->B,
+    hipLaunchKernelGGL((reset_cov_kernel<T, N>), dim3(grid), dim3(BLOCK), 0, h->stream, (T*)h->recs, h->B,
                        (T)d[0], (T)d[1], (T)d[2], (T)d[3], (T)d[4], (T)d[5]);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;

@@ -16,7 +16,7 @@ for B in [int(a) for a in sys.argv[1:]] or [65536, 262144, 65536 - 3]:
     with BatchedFilter(B, prm) as flt:
         o = [torch.empty_like(nom), torch.empty_like(rot), torch.empty_like(P), torch.empty_like(prev)]
         for name, fn in (("set_state_dev", lambda: flt.set_state(nom, rot, P, prev)), ("get_state_dev", lambda: flt._lib.fbus_ekf_get_state_dev(flt._h, *[flt._p(x) for x in o])),
-                         ("set_state_dev (nominal only)", lambda: flt.set_state(nom, None, None, None))):
+                         ("set_state_dev (nominal only)", lambda: flt.set_state(nom, None, None, None)), ("reset_cov", flt.reset_cov)):
             for _ in range(3): fn()
             flt.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20): fn()
