@@ -72,10 +72,10 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #define FBUS_X_PREDICT_ST AUX_NT       // store policy of the streamed per-call predict
 #endif
 #ifndef FBUS_X_CORRECT_LD
-// load policy of the covariance in the correct kernels.  Default policy since correct writes through (sc1): three runs each on
-// one box 5.025e9-5.035e9 (nt) -> 5.043e9-5.064e9 (the predicts behind it 12.72 -> 12.55 us, correct itself +1 us by HIP events);
-// also tried there: sc1 record stores in predict 4.50e9, sc1 / nt stores in the fused frame kernel 1.34e10 / 1.29e10 (unchanged / worse)
-#define FBUS_X_CORRECT_LD AUX_DEFAULT
+// load policy of the covariance in the correct kernels.  With the write-through stores the default policy here makes the predicts
+// behind a correct 0.17 us faster and correct itself 1.0 us slower (16.6 -> 17.6 us by rocprofv3): + 0.5 % on the headline in a
+// same-box A/B (5.025e9-5.035e9 -> 5.043e9-5.064e9), less than boxes differ from each other; nt keeps correct at 0.84 of peak
+#define FBUS_X_CORRECT_LD AUX_NT
 #endif
 #ifndef FBUS_X_CORRECT_STAGGER_BIT
 #define FBUS_X_CORRECT_STAGGER_BIT 3
