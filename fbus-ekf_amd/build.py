@@ -22,7 +22,7 @@ OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so") 
 OBJDIR = os.environ.get("FBUS_OBJDIR") or os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("FBUS_OUT") else
                                                        "obj_" + os.path.splitext(os.path.basename(OUT))[0])
 FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4, "frames": 5}
-# Per-family scheduler choice (measured in one run, B = 65 536, tools/ab_bench.sh, gpurun_out/r02_ab2.log): the
+# Per-family scheduler choice (measured in one run, B = 65 536, tools/ab_bench.sh, profiles/logs/r02_ab2.log): the
 # max-ILP strategy of the AMDGPU machine scheduler shortens the per-call kernels, where one wave per SIMD has nothing
 # but its own independent instructions to cover dependent-issue stalls (predict 13.4 -> 13.05 us, stacked correct
 # 23.0 -> 21.6 us, headline +3.5 %), and lengthens the fused frame kernel (-2.8 %: more live registers, more

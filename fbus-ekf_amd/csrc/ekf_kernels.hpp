@@ -44,7 +44,7 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 // dirty in the XCD's L2 until something evicts them, and the predict that follows streams them with the same non-temporal
 // loads as every other predict: correct 20.9 -> 19.0 us (HIP events), headline 4.94e9 -> 5.03e9 at 65 536 filters, +0.8 % /
 // +0.6 % at 131 072 / 262 144 (round 1's answer to the same problem, default-policy loads in the first predict behind a
-// correct, is no longer used behind correct; sc1 + nt stores lose: gpurun_out/r02_sc1.log)
+// correct, is no longer used behind correct; sc1 + nt stores lose: profiles/logs/r02_sc1.log)
 #define FBUS_X_CORRECT_ST AUX_SC1
 #endif
 #ifndef FBUS_X_SPLIT
@@ -446,7 +446,7 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
 // The launcher picks it from 2048 waves on: predict_n K = 7 at 131 072 filters 64.5 -> 53.4 us, at 262 144 filters
 // 122.1 -> 97.6 us (91 % of the VALU bound of its 1600 instructions per step); with one wave per SIMD (65 536 filters) the
 // parking is pure overhead, 31.4 -> 32.4 us.  Parking rows p alone leaves 16-32 bytes of scratch, all 7 nominal chunks
-// cost 20 KiB of LDS for nothing (gpurun_out/r02_park.log).
+// cost 20 KiB of LDS for nothing (profiles/logs/r02_park.log).
 constexpr int PARK_NOM_CHUNKS = 4;
 template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST, bool PARK = false>
 __global__ void __launch_bounds__(BLOCK, PARK ? 2 : 1)
@@ -566,7 +566,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
     // fp32 (SPLIT chosen by the launcher for launches of >= 2048 waves): the same form needs 194 registers instead of
     // 355, so two waves share a SIMD and overlap each other's load / pass / store phases: 44.4 -> 41.1 us at 131 072
     // filters, 73.0 -> 71.9 us at 262 144; with one wave per SIMD (65 536 filters) it is slower, 21.9 -> 25.4 us
-    // (the covariance is requested behind the fold instead of under it) -- gpurun_out/r02_ab8.log.
+    // (the covariance is requested behind the fold instead of under it) -- profiles/logs/r02_ab8.log.
     constexpr bool LEAN = SPLIT;
     constexpr int RS = 9;
     using Stash = LateStash<T, N, RS>;

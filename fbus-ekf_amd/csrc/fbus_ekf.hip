@@ -231,7 +231,7 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
     // reads them with the default policy too; the others stream them non-temporally (see predict_kernel)
     // ... and a batch whose records do not fit the Infinity Cache runs with the default policy on loads AND stores:
     // measured at 262 144 filters (210 MB of records) 65.4 us nt / nt -> 59.8 us default loads -> 55.7 us default loads
-    // and stores; at 131 072 (105 MB) and below the nt forms win (gpurun_out/r02_ld_policy.log, r02_ab4.log)
+    // and stores; at 131 072 (105 MB) and below the nt forms win (profiles/logs/r02_ab4.log)
     const bool big = h->rec_bytes > ((size_t)160 << 20);
     int policy = (big ? 2 : (h->records_warm ? 1 : 0));
     if (h->predict_ld == 1) policy = 0;
