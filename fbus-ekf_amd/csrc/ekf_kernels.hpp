@@ -62,6 +62,9 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_PREDICT_LD
 #define FBUS_X_PREDICT_LD AUX_NT       // record-load policy of the streamed per-call predict (records that fit the Infinity Cache)
 #endif
+#ifndef FBUS_X_PREDICT_LD_WARM
+#define FBUS_X_PREDICT_LD_WARM AUX_DEFAULT     // ... of the first predict behind a kernel that left the records in L2 (fused frame, corners, pixels)
+#endif
 #ifndef FBUS_X_PREDICT_LD_BIG
 #define FBUS_X_PREDICT_LD_BIG AUX_DEFAULT      // ... and of records that do not fit it (> 160 MB)
 #endif

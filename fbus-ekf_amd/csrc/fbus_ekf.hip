@@ -101,6 +101,7 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
 // ---------------------------------------------------------------------------------
 struct fbus_ekf {
     bool records_warm = false;        // the last kernel stored the records with the default cache policy (they sit in L2)
+    bool warm_after_correct = false;  // experiment knob FBUS_WARM_AFTER_CORRECT=1: the first predict behind a correct takes the "warm" load policy
     int predict_ld = 0;               // record-load policy of the per-call predict: 0 auto (see launch_predict_t), 1 always nt, 2 always default
     int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
     fbus_params prm{};
@@ -249,7 +250,7 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
                      const uint8_t* skip)
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
-    h->records_warm = false;        // written through (sc1): the next predict streams them like any other
+    h->records_warm = h->warm_after_correct;   // false: written through (sc1), the next predict streams them like any other
     launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
                               h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
     timing_end(h, ev);
@@ -623,6 +624,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (!h) return FBUS_ERR_NOMEM;
     h->B = batch;
     h->Bs = (batch + 63) / 64 * 64;
+    if (const char* e = std::getenv("FBUS_WARM_AFTER_CORRECT")) h->warm_after_correct = std::atoi(e) != 0;
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
     h->device = device;

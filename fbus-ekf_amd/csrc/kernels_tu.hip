@@ -37,7 +37,7 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
     hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD, ST>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, \
                        dt_stride, dc)
         if (policy == 2) FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD_BIG, FBUS_X_PREDICT_ST_BIG);      // records larger than the Infinity Cache
-        else if (policy == 1) FBUS_LAUNCH_PREDICT(AUX_DEFAULT, AUX_NT);      // first predict behind a default-policy writer
+        else if (policy == 1) FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD_WARM, AUX_NT);      // first predict behind a default-policy writer
         else FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD, FBUS_X_PREDICT_ST);
 #undef FBUS_LAUNCH_PREDICT
     } else if constexpr (sizeof(T) == 8) {
