@@ -95,6 +95,105 @@ def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
     return np.array(out), np.array(npred)
 
 
+def plan_windows(imu, image, max_frames=None, matlab_reset=True, max_window=64):
+    """The frame loop of FBUS_EKF.m:151-210 as a PLAN: which IMU samples (with their dt) go in front of which frame, where the
+    script would reset instead (a vision gap > 0.1 s, FBUS_EKF.m:168-171), cut into windows of consecutive non-reset frames
+    of at most `max_window` frames.  Everything here depends on the time stamps only, so a whole recording can be planned
+    before the first launch.  Returns a list of ("reset", meas) and ("window", kcount, imu_rows, dts, [meas per frame])."""
+    imu = np.asarray(imu, float)
+    image = np.asarray(image, float)
+    idx = int(np.argmax(imu[:, 0] > image[0, 0]))
+    pre_img, n_img, nframes = 0.0, 0, 0
+    plan, cur_win = [], None
+
+    def flush():
+        nonlocal cur_win
+        if cur_win is not None and cur_win[1]:
+            plan.append(("window", np.array(cur_win[1], np.int32), np.array(cur_win[2], int), np.array(cur_win[3], float), cur_win[4]))
+        cur_win = None
+
+    while n_img < len(image) - 1 and (max_frames is None or nframes < max_frames):
+        j = n_img + 1
+        while j < len(image) and image[j, 0] == image[n_img, 0]:
+            j += 1
+        cur = image[n_img, 0]
+        meas = image[n_img:j, 1:9]
+        n_img = j
+        nframes += 1
+        if cur - pre_img > 0.1 and pre_img != 0 and matlab_reset:
+            flush()
+            plan.append(("reset", meas))
+            pre_img = cur
+            continue
+        rows, dts = [], []
+        pre_imu = imu[idx - 1, 0]
+        k = idx
+        while k < len(imu):
+            if imu[k, 0] > cur:
+                break
+            if imu[k, 0] < pre_img:
+                pre_imu = imu[k, 0]
+                k += 1
+                continue
+            dts.append(imu[k, 0] - pre_imu)
+            pre_imu = imu[k, 0]
+            rows.append(k)
+            k += 1
+        idx = k
+        pre_img = cur
+        if cur_win is None:
+            cur_win = ["window", [], [], [], []]
+        if len(cur_win[1]) == max_window or len(rows) > 255:
+            flush()
+            cur_win = ["window", [], [], [], []]
+        cur_win[1].append(len(rows)); cur_win[2] += rows; cur_win[3] += dts; cur_win[4].append(meas)
+    flush()
+    return plan
+
+
+def replay_windowed(flt, imu, image, params, max_frames=None, max_window=64):
+    """The recording through the Matlab loop on `flt` (a BatchedFilter of B filters, every one of them fed the same recording:
+    config 1 at batch scale) with each stretch of consecutive frames as ONE launch of the frame-window kernel
+    (fbus_ekf_frames_fused_dev) instead of one launch per EKF step.  Returns the number of EKF steps per filter; the state is
+    read with flt.get_state().  Same arithmetic as replay(); the results agree to fp32 rounding (resident vs streamed predict)."""
+    import torch
+    imu = np.asarray(imu, float)
+    image = np.asarray(image, float)
+    B, N = flt.B, flt.N
+    dev = torch.device("cuda", flt.device) if hasattr(flt, "device") else torch.device("cuda:0")
+    tt = torch.float32 if flt.np_dtype == np.float32 else torch.float64
+    P0 = np.diag(np.repeat(np.array(list(params.p0_diag)), 3)[:N])[None]
+    flt.set_state(np.zeros((B, 19)), np.zeros((B, 9)), np.repeat(P0, B, 0), np.zeros(B, np.int32))
+    rep = lambda a: np.ascontiguousarray(np.broadcast_to(a, (B,) + a.shape[1:]))
+    flt.init_gravity_bias(np.ascontiguousarray(np.broadcast_to(imu[:500, None, 1:4], (500, B, 3))),
+                          np.ascontiguousarray(np.broadcast_to(imu[:500, None, 4:7], (500, B, 3))))
+    meas0 = image[0:1, 1:9]
+    flt.pose_init(rep(meas0[:, 0].astype(np.int32)[None]), rep(meas0[None, :, 1:4]), rep(meas0[None, :, 4:8]), 0)
+    steps = 0
+    for item in plan_windows(imu, image, max_frames, True, max_window):
+        if item[0] == "reset":
+            meas = item[1]
+            flt.pose_init(rep(meas[:, 0].astype(np.int32)[None]), rep(meas[None, :, 1:4]), rep(meas[None, :, 4:8]), 1)
+            continue
+        _, kcount, rows, dts, frames = item
+        F, M = len(frames), max(len(m) for m in frames)
+        ids = np.full((F, 1, M), -1, np.int32); pos = np.zeros((F, 1, M, 3)); quat = np.zeros((F, 1, M, 4)); quat[..., 0] = 1
+        for f, m in enumerate(frames):
+            ids[f, 0, :len(m)] = m[:, 0].astype(np.int32); pos[f, 0, :len(m)] = m[:, 1:4]; quat[f, 0, :len(m)] = m[:, 4:8]
+        up = lambda a, t=tt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(t)
+        d_acc = up(imu[rows, 1:4])[:, None, :].expand(len(rows), B, 3).contiguous()
+        d_gyr = up(imu[rows, 4:7])[:, None, :].expand(len(rows), B, 3).contiguous()
+        d_ids = torch.from_numpy(ids).to(dev).expand(F, B, M).contiguous()
+        d_pos = up(pos).expand(F, B, M, 3).contiguous()
+        d_quat = up(quat).expand(F, B, M, 4).contiguous()
+        d_dt = up(dts)
+        flt.wait_stream(torch.cuda.current_stream())          # the uploads above ran on torch's stream
+        flt.frames(kcount, d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, 0)
+        steps += int(kcount.sum()) + F
+    flt.sync()
+    return steps
+
+
 def replay_cpp_loop(engine, imu, image, params, max_frames=None, n_init=500):
     """The recording through the loop of FILTER::FilterThreadFunction (C++/src/filter.cpp:190-250) instead of the
     Matlab script's: per camera frame

@@ -307,6 +307,48 @@ def test_full_recording_replay_matlab_loop(rec):
         assert np.abs(got[0, 14:17] - fb[0, 1:4]).max() < 1e-3
 
 
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_recording_replay_through_frame_windows(dialect):
+    """config 1 at batch scale: the land recording (with two stretches of camera frames removed, so that the Matlab loop's reset
+    branch runs) replayed for 256 filters at once, every stretch of consecutive frames as ONE launch of the frame-window kernel
+    (replay.replay_windowed -> fbus_ekf_frames_fused_dev), against the frame-by-frame replay of the same recording: all 256
+    filters identical, the end state equal to the per-call replay's to fp32 rounding, fp64 to 1e-9; throughput printed."""
+    import time
+    d = np.load(os.path.join(GOLD, "recordings.npz"))
+    imu, image = d["land_imu"], d["land_image"]
+    t = image[:, 0]
+    keep = ~(((t > t[0] + 8.0) & (t < t[0] + 8.4)) | ((t > t[0] + 20.0) & (t < t[0] + 20.25)))
+    image = image[keep]
+    prm = capi.default_params(dialect)
+    plan = replay.plan_windows(imu, image)
+    nres = sum(1 for p in plan if p[0] == "reset")
+    nwin = sum(1 for p in plan if p[0] == "window")
+    assert nres == 2 and nwin >= 3 and max(len(p[1]) for p in plan if p[0] == "window") == 64
+    B = 256
+    for dtype, tol in ((64, 1e-9), (32, None)):
+        with BatchedFilter(1, prm, dtype=dtype) as f1:
+            ref, nref = replay.replay(f1, imu, image, prm)
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            t0 = time.perf_counter()
+            steps = replay.replay_windowed(flt, imu, image, prm)
+            wall = time.perf_counter() - t0
+            nom, rot, P, _ = flt.get_state()
+        assert steps == int(nref.sum()) + len(ref) - nres                      # a reset frame is no EKF step
+        assert all(np.array_equal(a[0], a[-1]) and np.array_equal(a[0], a[B // 2]) for a in (nom, rot, P))
+        end = ref[-1]
+        en, eP = end[1:20], end[29:].reshape(18, 18)
+        lit = state_rel_err_literal(nom[:1].astype(np.float64), en[None])
+        sig = state_rel_err(nom[:1].astype(np.float64), en[None], eP[None])
+        cb = cov_rel_err_blockwise(P[:1].astype(np.float64), eP[None])
+        print(f"[replay] land recording through frame windows, dialect {dialect}, fp{dtype}: {len(ref)} frames / {steps} EKF steps x {B} "
+              f"filters in {nwin} window launches + {nres} resets, {wall * 1e3:.0f} ms wall incl. uploads = {steps * B / wall:.2e} steps/s; "
+              f"end state vs the frame-by-frame replay: literal {lit:.2e} sigma-aware {sig[0]:.2e} cov block-wise {cb:.2e}")
+        if tol is not None:
+            assert lit < tol and sig[0] < tol and cb < 1e-8
+        else:
+            assert lit < 1e-4 and sig[0] < 3e-3 and cb < 3e-3                   # the same loose band as the whole-run fp32 drift above
+
+
 def test_cpp_frame_loop_with_resets_and_gapped_recording():
     """FILTER::FilterThreadFunction's loop (filter.cpp:229-235): reset-then-CONTINUE after a vision gap of more than 0.1 s
     (filter.cpp:462-474), on the land recording with three stretches of camera frames removed; and the Matlab loop's
