@@ -395,3 +395,55 @@ int main() {
                                 [[1, 0, 0, 0], [0.5, 0.5, 0.5, 0.25 * frame]], 1)
         got.append("F %d %d %.9f" % (used, fb.buffered, fb.t_state))
     assert got == want
+
+
+def test_window_plan_is_the_matlab_frame_loop():
+    """replay.plan_windows (the host-side plan behind replay_windowed / fbus_ekf_frames_fused_dev) against replay() itself on
+    the recorded land sequence with two stretches of camera frames removed: the same frames, the same IMU samples with the
+    same dt in front of each, resets where the script resets (FBUS_EKF.m:168-171), windows of at most 64 frames."""
+    from replay_ref import OracleEngine
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "recordings.npz"))
+    imu, image = d["land_imu"], d["land_image"]
+    t = image[:, 0]
+    image = image[~(((t > t[0] + 8.0) & (t < t[0] + 8.4)) | ((t > t[0] + 20.0) & (t < t[0] + 20.25)))]
+    calls = []
+
+    class Spy(OracleEngine):                    # records what replay() asks of the engine
+        def predict(self, a, g, dt):
+            calls.append(("p", float(np.ravel(dt)[0]), np.array(a).ravel().copy()))
+            return super().predict(a, g, dt)
+
+        def correct(self, ids, pos, quat, mode=0, skip=None):
+            calls.append(("c", np.array(ids).ravel().copy()))
+            return super().correct(ids, pos, quat, mode)
+
+        def pose_init(self, ids, pos, quat, reset):
+            if reset:
+                calls.append(("r", np.array(ids).ravel().copy()))
+            return super().pose_init(ids, pos, quat, reset)
+
+    prm = capi.default_params(0)
+    nfr = 700
+    ref, npred = replay.replay(Spy(1, 0, 18), imu, image, prm, max_frames=nfr)
+    plan = replay.plan_windows(imu, image, max_frames=nfr)
+    flat = []
+    for item in plan:
+        if item[0] == "reset":
+            flat.append(("r", item[1][:, 0].astype(np.int32)))
+            continue
+        _, kcount, rows, dts, frames = item
+        assert 1 <= len(kcount) <= 64 and len(frames) == len(kcount) and kcount.sum() == len(rows) == len(dts)
+        k0 = 0
+        for f, K in enumerate(kcount):
+            for k in range(K):
+                flat.append(("p", float(dts[k0 + k]), imu[rows[k0 + k], 1:4]))
+            flat.append(("c", frames[f][:, 0].astype(np.int32)))
+            k0 += K
+    assert len(flat) == len(calls) and sum(1 for c in calls if c[0] == "r") == 2
+    for a, b in zip(flat, calls):
+        assert a[0] == b[0]
+        if a[0] == "p":
+            assert a[1] == b[1] and np.array_equal(a[2], b[2])
+        else:
+            assert np.array_equal(a[1], b[1])
+    assert sum(len(p[1]) for p in plan if p[0] == "window") + 2 == nfr == len(ref)
