@@ -29,20 +29,21 @@ def timed(flt, kind, fn, reps):
     return ms / n * 1e3
 
 
-def run(B, dtype, M, what, K=1, mode=1, reps=200):
+def run(B, dtype, M, what, K=1, mode=1, reps=200, n=18):
     tdt = torch.float32 if dtype == 32 else torch.float64
     es = 4 if dtype == 32 else 8
-    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18)
+    nrec = 28 + n * (n + 1) // 2                    # record elements priced by SURVEY 8(d): nominal + R + packed covariance
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), n)
     acc, gyr = synth.imu_samples(0, B, 0, max(K, 1), nom)
     d_acc, d_gyr, d_dt = tensors(acc, tdt), tensors(gyr, tdt), tensors(np.full(max(K, 1), 0.005), tdt)
-    with BatchedFilter(B, prm, dtype=dtype) as flt:
+    with BatchedFilter(B, prm, dtype=dtype, nstate=n) as flt:
         flt.set_state(nom, rot, P, prev)
         if what == "predict":
             us = timed(flt, capi.KERNEL_PREDICT, lambda: flt.predict(d_acc[0], d_gyr[0], d_dt[:1]), reps)
-            steps, bytes_ = B, (2 * 199 * es + 7 * es) * B
+            steps, bytes_ = B, (2 * nrec * es + 7 * es) * B
         elif what == "predict_n":
             us = timed(flt, capi.KERNEL_PREDICT_N, lambda: flt.predict_n(d_acc, d_gyr, d_dt), reps)
-            steps, bytes_ = B * K, (2 * 199 * es + 7 * es) * B * K
+            steps, bytes_ = B * K, (2 * nrec * es + 7 * es) * B * K
         elif what == "correct_corners":
             # north-star B2: stereo corner pixels -> refractive triangulation -> 12 rows per marker, on the device
             ids, _, _ = synth.marker_frame(0, B, 0, min(M, 12), nom, prm)
@@ -54,7 +55,7 @@ def run(B, dtype, M, what, K=1, mode=1, reps=200):
             d = (torch.from_numpy(ids).to(dev), tensors(left, tdt), tensors(right, tdt))
             us = timed(flt, capi.KERNEL_CORRECT_CORNERS,
                        lambda: flt.correct_corners(d[0], d[1], d[2], capi.VIS_REFRACTIVE, mode), reps)
-            steps, bytes_ = B, (2 * 199 * es + 17 * es * M) * B
+            steps, bytes_ = B, (2 * nrec * es + 17 * es * M) * B
         else:
             ids, pos, quat = synth.marker_frame(0, B, 0, min(M, 12), nom, prm)
             if M > 12:
@@ -64,7 +65,7 @@ def run(B, dtype, M, what, K=1, mode=1, reps=200):
                 quat = np.concatenate([quat, np.tile([1.0, 0, 0, 0], (B, pad, 1))], axis=1)
             d = (torch.from_numpy(ids).to(dev), tensors(pos, tdt), tensors(quat, tdt))
             us = timed(flt, capi.KERNEL_CORRECT, lambda: flt.correct(d[0], d[1], d[2], mode), reps)
-            steps, bytes_ = B, (2 * 199 * es + 8 * es * M) * B
+            steps, bytes_ = B, (2 * nrec * es + 8 * es * M) * B
     return us, steps / us * 1e6, bytes_ / us * 1e-3
 
 
@@ -80,8 +81,13 @@ for name, args in (
     ("5", dict(B=65536, dtype=64, M=16, what="correct", mode=1, reps=20)),
     ("5", dict(B=65536, dtype=64, M=0, what="predict", reps=50)),
     ("-", dict(B=65536, dtype=32, M=1, what="correct", mode=0)),
+    # the north star's literal 15-state filter (N = 18 without the gravity block): 608-byte records instead of 800
+    ("n15", dict(B=65536, dtype=32, M=0, what="predict", n=15)),
+    ("n15", dict(B=65536, dtype=32, M=4, what="correct", mode=1, n=15)),
+    ("n18", dict(B=65536, dtype=32, M=0, what="predict")),
+    ("n18", dict(B=65536, dtype=32, M=4, what="correct", mode=1)),
 ):
     us, sps, gbs = run(**args)
-    desc = f"B={args['B']} fp{args['dtype']} {args['what']}" + (f" K={args['K']}" if "K" in args else "") + \
+    desc = f"B={args['B']} fp{args['dtype']} {'N=15 ' if args.get('n') == 15 else ''}{args['what']}" + (f" K={args['K']}" if "K" in args else "") + \
            (f" M={args['M']} {'stacked' if args.get('mode', 1) else 'nearest'}" if args["what"].startswith("correct") else "")
     print(f"{name:>4}    {desc:<48} {us:9.2f}   {sps:13.4g}   {gbs:10.0f}")
