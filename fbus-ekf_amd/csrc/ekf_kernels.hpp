@@ -66,7 +66,7 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #define FBUS_X_PREDICT_LD_WARM AUX_DEFAULT     // ... of the first predict behind a kernel that left the records in L2 (fused frame, corners, pixels)
 #endif
 #ifndef FBUS_X_PREDICT_LD_BIG
-#define FBUS_X_PREDICT_LD_BIG AUX_DEFAULT      // ... and of records that do not fit it (> 160 MB)
+#define FBUS_X_PREDICT_LD_BIG AUX_DEFAULT      // ... and of larger batches (records > 56 MB, see fbus_ekf.hip::launch_predict_t)
 #endif
 #ifndef FBUS_X_PREDICT_ST_BIG
 #define FBUS_X_PREDICT_ST_BIG AUX_DEFAULT
@@ -435,7 +435,7 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
 // stay as they are in HBM (N = 18: 33 of the 43 covariance chunks are stored).
 //
 // ST = cache policy of the record stores, LD = cache policy of the record loads.  A batch whose records do not fit the
-// 256 MB Infinity Cache (> 160 MB of records: B >= ~200 000 in fp32) runs with the default policy on both: measured at
+// 256 MB Infinity Cache -- in practice every batch beyond one round of 1024 waves (records > 56 MB) -- runs with the default policy on both: measured at
 // 262 144 filters 65.4 us (nt / nt) -> 59.8 (default loads) -> 55.7 us (default loads and stores) = 6.75 TB/s moved; at
 // 131 072 and below the non-temporal forms win (records stay resident in the Infinity Cache between launches).
 // LD = cache policy of the record loads.  Non-temporal in a run of predicts (each line is read once per launch); the

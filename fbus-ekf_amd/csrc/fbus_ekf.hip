@@ -101,6 +101,7 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
 // ---------------------------------------------------------------------------------
 struct fbus_ekf {
     bool records_warm = false;        // the last kernel stored the records with the default cache policy (they sit in L2)
+    int big_records_mb = 56;          // records larger than this run the predict with default-policy loads and stores (FBUS_BIG_RECORDS_MB)
     bool warm_after_correct = false;  // experiment knob FBUS_WARM_AFTER_CORRECT=1: the first predict behind a correct takes the "warm" load policy
     int predict_ld = 0;               // record-load policy of the per-call predict: 0 auto (see launch_predict_t), 1 always nt, 2 always default
     int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
@@ -230,10 +231,12 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
     const int ev = timing_begin(h, K == 1 ? FBUS_KERNEL_PREDICT : FBUS_KERNEL_PREDICT_N);
     // the first predict after a kernel that stored the records with the default cache policy (correct, fused frame)
     // reads them with the default policy too; the others stream them non-temporally (see predict_kernel)
-    // ... and a batch whose records do not fit the Infinity Cache runs with the default policy on loads AND stores:
-    // measured at 262 144 filters (210 MB of records) 65.4 us nt / nt -> 59.8 us default loads -> 55.7 us default loads
-    // and stores; at 131 072 (105 MB) and below the nt forms win (profiles/logs/r02_ab4.log)
-    const bool big = h->rec_bytes > ((size_t)160 << 20);
+    // ... and larger batches run with the default policy on loads AND stores.  Measured on the final round-2 kernels
+    // (profiles/logs/r02_policy_by_size.log, headline nt/nt -> default/default): 65 536 filters (52 MB of records, 1024 waves = one
+    // round) 4.91e9 -> 4.39e9; 73 728: +1 %; 81 920: +2.5 %; 98 304: +3 %; 131 072: +7 %; 163 840: +11 %; 196 608: +13 %;
+    // 262 144 (210 MB): 65.4 -> 55.7 us per launch.  The non-temporal stream only pays while the whole batch is one round of
+    // waves whose records stay in the Infinity Cache between launches; the threshold sits just above that batch.
+    const bool big = h->rec_bytes > ((size_t)h->big_records_mb << 20);
     int policy = (big ? 2 : (h->records_warm ? 1 : 0));
     if (h->predict_ld == 1) policy = 0;
     if (h->predict_ld == 2) policy = big ? 2 : 1;
@@ -624,6 +627,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (!h) return FBUS_ERR_NOMEM;
     h->B = batch;
     h->Bs = (batch + 63) / 64 * 64;
+    if (const char* e = std::getenv("FBUS_BIG_RECORDS_MB")) h->big_records_mb = std::atoi(e);
     if (const char* e = std::getenv("FBUS_WARM_AFTER_CORRECT")) h->warm_after_correct = std::atoi(e) != 0;
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
