@@ -237,7 +237,7 @@ class Workload:
         self.d_dt = f32(np.full(max(PATTERN), 0.005))
         # The handle stays on its own (non-blocking) stream; the inputs above were uploaded on torch's stream, so
         # the device is synchronised before the first launch and on both sides of every timed region.
-        self.flt = BatchedFilter(self.B, prm, device=local_rank, dtype=32, nstate=18)
+        self.flt = BatchedFilter(self.B, prm, device=local_rank, dtype=32, nstate=18, order_streams=False)   # inputs are uploaded and synchronised before the timed region
         self.state0 = (nom, rot, P, prev)
         self.reset_state()
         _, self.bpf, total = self.flt.records()

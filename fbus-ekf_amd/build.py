@@ -16,12 +16,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HEADERS = [os.path.join(CSRC, h) for h in ("ekf_kernels.hpp", "ekf_device.hpp", "vision_device.hpp", "ekf_launch.hpp")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("ekf_kernels.hpp", "ekf_device.hpp", "vision_device.hpp", "ekf_launch.hpp", "ekf_team.hpp")] + \
           [os.path.join(HERE, "..", "include", "fbus_ekf.h")]
 OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so")   # FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds
 OBJDIR = os.environ.get("FBUS_OBJDIR") or os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("FBUS_OUT") else
                                                        "obj_" + os.path.splitext(os.path.basename(OUT))[0])
-FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4, "frames": 5}
+FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4, "frames": 5, "team": 6}
 # Per-family scheduler choice (measured in one run, B = 65 536, tools/ab_bench.sh, profiles/logs/r02_ab2.log): the
 # max-ILP strategy of the AMDGPU machine scheduler shortens the per-call kernels, where one wave per SIMD has nothing
 # but its own independent instructions to cover dependent-issue stalls (predict 13.4 -> 13.05 us, stacked correct
@@ -29,7 +29,8 @@ FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4, "frames": 5}
 # v_accvgpr traffic), which therefore keeps the default strategy.
 FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "correct": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-                "frame": [], "corners": [], "frames": []}
+                "frame": [], "corners": [], "frames": [],
+                "team": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 TYPES = {"f32": "float", "f64": "double"}
 
 
@@ -46,7 +47,7 @@ def units():
     for tn, t in TYPES.items():
         for n in (18, 15):
             for fam, code in FAMILIES.items():
-                if fam in ("frame", "frames") and tn == "f64":
+                if fam in ("frame", "frames", "team") and tn == "f64":
                     continue                    # no fused fp64 kernels: fbus_ekf.hip runs predict_n + correct instead
                 out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
                             [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"] +

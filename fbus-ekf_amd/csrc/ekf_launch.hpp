@@ -42,4 +42,13 @@ template <typename T, int N, int D>
 void launch_pixels_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, bool joseph, T size,
                      T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc);
 
+// ---- team kernels (ekf_team.hpp): several waves per 64-filter tile, fp32 only -------------------------------------------
+// roles: waves per tile (predict 2..4, predict_n always 4, correct 2..4); policy as in launch_predict_k
+template <typename T, int N, int D>
+void launch_predict_team_k(hipStream_t s, T* recs, int B, int K, int roles, int policy, const T* accel, const T* gyro,
+                           const T* dt, int dt_stride, const DevConst<T>& dc);
+template <typename T, int N, int D>
+void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode, int roles,
+                           const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
+
 }  // namespace fbus

@@ -8,6 +8,7 @@
 // ((b / 64) * NCH + c) * 1024 + (b % 64) * 16: a wave moves its tile with NCH fully
 // coalesced 1 KiB buffer_load_dwordx4 / buffer_store_dwordx4 over one contiguous
 // NCH KiB region, and a rank's records are one contiguous block for the RCCL gather.
+#define FBUS_EKF_NO_ABI_CHECK      // this file DEFINES fbus_ekf_create: no macro here
 #include "../../include/fbus_ekf.h"
 #include "ekf_kernels.hpp"
 #include "ekf_launch.hpp"
@@ -105,6 +106,9 @@ struct fbus_ekf {
     bool warm_after_correct = false;  // experiment knob FBUS_WARM_AFTER_CORRECT=1: the first predict behind a correct takes the "warm" load policy
     int predict_ld = 0;               // record-load policy of the per-call predict: 0 auto (see launch_predict_t), 1 always nt, 2 always default
     int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
+    // team kernels (several waves per 64-filter tile, ekf_team.hpp): 0 = chosen per launch from the wave count, 1 = never,
+    // 2..4 = always with that many roles (fbus_ekf_set_team, FBUS_TEAM_PREDICT / FBUS_TEAM_CORRECT at create)
+    int team_predict = 0, team_correct = 0;
     fbus_params prm{};
     HostConst hc;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -225,6 +229,29 @@ void timing_end(fbus_ekf_t h, int i)
     if (i >= 0) (void)hipEventRecord(h->ev_pool[i].b, h->stream);
 }
 
+// How many waves should share one 64-filter tile?  One wave per tile (the lane-per-filter kernels) fills the chip from
+// 1024 tiles on; below that the SIMDs that would idle can take a share of every filter's work instead (ekf_team.hpp).
+// Measured (rocprofv3 kernel trace, profiles/r03_team_kernels.txt), one-wave -> team:
+//   predict    4096 filters 4.96 -> 4.12 us (3 roles), 16 384: 5.88 -> 4.84, 32 768: 7.12 -> 8.3 (the roles' overlapping loads cost
+//              more than the shorter instruction streams save once the launch moves 47 MB)            => up to 256 tiles
+//   predict_n  K = 8: 4096 filters 18.9 -> 10.4 us, 16 384: 20.8 -> 16.7, 32 768: 23.1 -> 22.2                 => up to 512 tiles
+//   correct    4096 filters 7.7 -> 8.1 us, 16 384: 8.6 -> 9.5, 32 768: 10.2 -> 18: the one-wave kernel folds its markers under
+//              the load latency and the team pays two exchanges and a redundant 6 x 6 solve per role       => never by default
+int team_roles_predict(const fbus_ekf* h, int K)
+{
+    if (h->dtype != 32 || h->team_predict == 1) return 1;
+    if (h->team_predict >= 2) return K > 1 ? 4 : (h->team_predict > 4 ? 4 : h->team_predict);
+    const int tiles = (h->B + 63) / 64;
+    if (K > 1) return tiles <= 512 ? 4 : 1;
+    return tiles <= 256 ? 3 : 1;
+}
+int team_roles_correct(const fbus_ekf* h, int mode)
+{
+    if (h->dtype != 32 || h->team_correct <= 1 || h->prm.cov_form == FBUS_COV_JOSEPH) return 1;
+    if (mode != MODE_NEAREST && mode != MODE_STACKED) return 1;
+    return h->team_correct > 4 ? 4 : h->team_correct;
+}
+
 template <typename T, int N, int D>
 int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
 {
@@ -241,6 +268,13 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
     if (h->predict_ld == 1) policy = 0;
     if (h->predict_ld == 2) policy = big ? 2 : 1;
     h->records_warm = false;
+    const int roles = team_roles_predict(h, K);
+    if constexpr (sizeof(T) == 4) {
+        if (roles > 1)
+            launch_predict_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, roles, policy, (const T*)accel, (const T*)gyro,
+                                           (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h));
+    }
+    if (roles <= 1 || sizeof(T) != 4)
     launch_predict_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, policy, (const T*)accel, (const T*)gyro, (const T*)dt,
                               dt_per_filter ? 1 : 0, make_dc<T>(h));
     timing_end(h, ev);
@@ -254,6 +288,13 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
     h->records_warm = h->warm_after_correct;   // false: written through (sc1), the next predict streams them like any other
+    const int roles = team_roles_correct(h, mode);
+    if constexpr (sizeof(T) == 4) {
+        if (roles > 1)
+            launch_correct_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+                                           roles, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+    }
+    if (roles <= 1 || sizeof(T) != 4)
     launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
                               h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
     timing_end(h, ev);
@@ -553,6 +594,7 @@ const char* fbus_status_string(int s)
         case FBUS_ERR_HIP: return "HIP runtime error";
         case FBUS_ERR_UNSUPPORTED: return "unsupported dtype/nstate/mode";
         case FBUS_ERR_NOMEM: return "out of memory";
+        case FBUS_ERR_ABI: return "caller and library were built against different versions of fbus_ekf.h";
         default: return "unknown status";
     }
 }
@@ -610,6 +652,18 @@ int fbus_params_default(fbus_params* prm, int dialect)
     return FBUS_OK;
 }
 
+int fbus_ekf_abi_version(void) { return FBUS_ABI_VERSION; }
+size_t fbus_params_size(void) { return sizeof(fbus_params); }
+
+int fbus_ekf_create_checked(fbus_ekf_t* out, const fbus_params* prm, size_t params_size, int abi_version, int batch, int device,
+                            int dtype, int nstate)
+{
+    if (out) *out = nullptr;
+    // checked BEFORE prm is read: a shorter struct must not be copied past its end
+    if (abi_version != FBUS_ABI_VERSION || params_size != sizeof(fbus_params)) return FBUS_ERR_ABI;
+    return fbus_ekf_create(out, prm, batch, device, dtype, nstate);
+}
+
 int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int device, int dtype, int nstate)
 {
     if (!out) return FBUS_ERR_INVALID;
@@ -629,6 +683,8 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     h->Bs = (batch + 63) / 64 * 64;
     if (const char* e = std::getenv("FBUS_BIG_RECORDS_MB")) h->big_records_mb = std::atoi(e);
     if (const char* e = std::getenv("FBUS_WARM_AFTER_CORRECT")) h->warm_after_correct = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
+    if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
     h->device = device;
@@ -681,6 +737,14 @@ int fbus_ekf_destroy(fbus_ekf_t h)
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+    return FBUS_OK;
+}
+
+int fbus_ekf_set_team(fbus_ekf_t h, int predict_roles, int correct_roles)
+{
+    if (!h || predict_roles < 0 || predict_roles > 4 || correct_roles < 0 || correct_roles > 4) return FBUS_ERR_INVALID;
+    h->team_predict = predict_roles;
+    h->team_correct = correct_roles;
     return FBUS_OK;
 }
 

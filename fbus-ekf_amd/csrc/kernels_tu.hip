@@ -1,12 +1,15 @@
 // kernels_tu.hip -- one kernel family for one (scalar type, state size), both dialects.
-// Compiled 16 times by build.py:  -DFBUS_TU_T=float|double  -DFBUS_TU_N=18|15  -DFBUS_TU_FAMILY=1..4
+// Compiled 16 times by build.py:  -DFBUS_TU_T=float|double  -DFBUS_TU_N=18|15  -DFBUS_TU_FAMILY=1..6
 //   1 predict (per-call streamed kernel, both record-load policies, and predict_n)
 //   2 correct (nearest / stacked x simple / Joseph)
 //   3 fused frame (K predicts + correct in one launch)
 //   4 correct from stereo corners
+//   5 frame window (F frames per launch)
+//   6 team kernels (several waves per tile: predict, predict_n, correct; fp32 only)
 // gfx950 only.
 #include <cstdlib>
 #include "ekf_kernels.hpp"
+#include "ekf_team.hpp"
 #include "ekf_launch.hpp"
 
 #ifndef FBUS_TU_T
@@ -181,8 +184,57 @@ void launch_frames_k(hipStream_t s, T* recs, int B, int F, const unsigned char* 
                                                            int, const int*, const FBUS_TU_T*, const FBUS_TU_T*, int,   \
                                                            bool, const unsigned char*, unsigned char*,                 \
                                                            const DevConst<FBUS_TU_T>&);
+#elif FBUS_TU_FAMILY == 6
+// team kernels (ekf_team.hpp): fp32 only
+template <typename T, int N, int D>
+void launch_predict_team_k(hipStream_t s, T* recs, int B, int K, int roles, int policy, const T* accel, const T* gyro,
+                           const T* dt, int dt_stride, const DevConst<T>& dc)
+{
+    const int tiles = (B + 63) / 64;
+    if (K > 1) {
+        hipLaunchKernelGGL((predict_n_team_kernel<T, N, D>), dim3(tiles), dim3(256), 0, s, recs, B, K, accel, gyro, dt, dt_stride, dc);
+        return;
+    }
+    // cache policy of the record accesses as in launch_predict_k: 0 nt / nt, 1 default loads, 2 default loads and stores
+#define FBUS_LAUNCH_PT(NR, LD, ST)                                                                                         \
+    hipLaunchKernelGGL((predict_team_kernel<T, N, D, NR, LD, ST>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, accel, gyro, dt, \
+                       dt_stride, dc)
+#define FBUS_LAUNCH_PT_POL(NR)                                                                                             \
+    do {                                                                                                                   \
+        if (policy == 2) FBUS_LAUNCH_PT(NR, AUX_DEFAULT, AUX_DEFAULT);                                                     \
+        else if (policy == 1) FBUS_LAUNCH_PT(NR, AUX_DEFAULT, AUX_NT);                                                     \
+        else FBUS_LAUNCH_PT(NR, AUX_NT, AUX_NT);                                                                           \
+    } while (0)
+    if (roles <= 2) FBUS_LAUNCH_PT_POL(2);
+    else if (roles == 3) FBUS_LAUNCH_PT_POL(3);
+    else FBUS_LAUNCH_PT_POL(4);
+#undef FBUS_LAUNCH_PT_POL
+#undef FBUS_LAUNCH_PT
+}
+template <typename T, int N, int D>
+void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode, int roles,
+                           const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
+{
+    const int tiles = (B + 63) / 64;
+    const bool joint = mode == MODE_STACKED;
+#define FBUS_LAUNCH_CT(JOINT, NR)                                                                                          \
+    hipLaunchKernelGGL((correct_team_kernel<T, N, D, JOINT, NR>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, pos, quat, \
+                       skip, applied, dc)
+    if (roles <= 2) { if (joint) FBUS_LAUNCH_CT(true, 2); else FBUS_LAUNCH_CT(false, 2); }
+    else if (roles == 3) { if (joint) FBUS_LAUNCH_CT(true, 3); else FBUS_LAUNCH_CT(false, 3); }
+    else { if (joint) FBUS_LAUNCH_CT(true, 4); else FBUS_LAUNCH_CT(false, 4); }
+#undef FBUS_LAUNCH_CT
+}
+#define FBUS_INST(D)                                                                                                   \
+    template void launch_predict_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, int, int, const FBUS_TU_T*, \
+                                                                 const FBUS_TU_T*, const FBUS_TU_T*, int,              \
+                                                                 const DevConst<FBUS_TU_T>&);                          \
+    template void launch_correct_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,        \
+                                                                 const FBUS_TU_T*, const FBUS_TU_T*, int, int,         \
+                                                                 const unsigned char*, unsigned char*,                 \
+                                                                 const DevConst<FBUS_TU_T>&);
 #else
-#error "FBUS_TU_FAMILY must be 1..5"
+#error "FBUS_TU_FAMILY must be 1..6"
 #endif
 
 FBUS_INST(DIALECT_MATLAB)

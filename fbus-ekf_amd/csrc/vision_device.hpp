@@ -137,13 +137,23 @@ __device__ __forceinline__ void refraction_project(const VisConst<T>& vc, const 
     const T zw = z - vc.d_air - vc.d_glass;
     T t = rho / (vc.d_air + a0 * vc.d_glass + a1 * zw);
     constexpr int NEWTON_MAX = (sizeof(T) == 4) ? 7 : 10;
-    constexpr T NEWTON_TOL = (sizeof(T) == 4) ? T(3e-4) : T(1e-8);
+    // fp32: a lane stops after a step of <= 1e-4 t (quadratic convergence: what is left is ~1e-8 t, below fp32 rounding).  With the
+    // wave-wide exit of round 2 the bound was 3e-4, but most lanes ran one step further for the sake of their slowest
+    // neighbour; per-lane convergence at 3e-4 lost that accidental step and with it accuracy (block-wise covariance figure
+    // of the 235-row stereo case 2.0e-3 -> 2.7e-3).
+    constexpr T NEWTON_TOL = (sizeof(T) == 4) ? T(1e-4) : T(1e-8);
+    // Convergence is decided PER LANE: a lane that has converged keeps its t while the wave runs on for its slower
+    // lanes (the vote only ends the loop).  A filter's iteration count, and with it the last bits of its result, must not
+    // depend on which other filters share its wave -- the batch composition and the shard layout.
+    bool conv = false;
 #pragma unroll 1
     for (int it = 0; it < NEWTON_MAX; ++it) {
         const PortRay<T> f = port_ray(vc, a0, a1, zw, t);
         const T dt = (rho - f.L) * fb_rcp(f.Lt);
-        t = fmax(t + dt, T(0));
-        if (!__any(fb_abs(dt) > NEWTON_TOL * t)) break;
+        const T tn = fmax(t + dt, T(0));
+        t = conv ? t : tn;
+        conv = conv || !(fb_abs(dt) > NEWTON_TOL * tn);
+        if (!__any(!conv)) break;
     }
     const PortRay<T> f = port_ray(vc, a0, a1, zw, t);
     const T Lt = f.Lt, Lz = f.Lz;

@@ -18,6 +18,8 @@ L0_QUAT_MUL, L0_QUAT_TO_ROTMAT_M, L0_QUAT_TO_ROTMAT_E, L0_QUAT_NORMALIZE, L0_EXP
 MAX_MARKERS, MAX_VISIBLE = 32, 16
 MAX_WINDOW_FRAMES = 64           # fbus_ekf_frames_fused_dev
 STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
+ABI_VERSION = 3                    # FBUS_ABI_VERSION of the header this mirror was written against
+ERR_ABI = 6
 
 
 class FbusError(RuntimeError):
@@ -78,9 +80,13 @@ def load_library():
     H = C.c_void_p
     sig = {
         "fbus_params_default": ([C.POINTER(FbusParams), C.c_int], C.c_int),
+        "fbus_ekf_abi_version": ([], C.c_int),
+        "fbus_params_size": ([], C.c_size_t),
+        "fbus_ekf_create_checked": ([C.POINTER(H), C.POINTER(FbusParams), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
         "fbus_ekf_create": ([C.POINTER(H), C.POINTER(FbusParams), C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
         "fbus_ekf_destroy": ([H], C.c_int),
         "fbus_ekf_set_stream": ([H, vp], C.c_int),
+        "fbus_ekf_set_team": ([H, C.c_int, C.c_int], C.c_int),
         "fbus_ekf_wait_stream": ([H, vp], C.c_int),
         "fbus_ekf_signal_stream": ([H, vp], C.c_int),
         "fbus_ekf_sync": ([H], C.c_int),
@@ -130,6 +136,11 @@ def load_library():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
+    # a binding that cannot use the header's create macro checks the ABI once after loading (include/fbus_ekf.h)
+    if lib.fbus_ekf_abi_version() != ABI_VERSION or lib.fbus_params_size() != C.sizeof(FbusParams):
+        raise FbusError(ERR_ABI, "load_library",
+                        f"{path}: library ABI {lib.fbus_ekf_abi_version()} / fbus_params {lib.fbus_params_size()} B, "
+                        f"this mirror expects ABI {ABI_VERSION} / {C.sizeof(FbusParams)} B -- rebuild the library")
     _lib = lib
     return lib
 

@@ -24,13 +24,14 @@ def _is_dev(x):
 
 class BatchedFilter:
     def __init__(self, batch, params=None, dialect=capi.DIALECT_MATLAB, device=0, dtype=32, nstate=18,
-                 stream=None):
+                 stream=None, order_streams=True):
         self._lib = capi.load_library()
         self._h = C.c_void_p()
         self.params = params if params is not None else capi.default_params(dialect)
         self.B, self.device, self.dtype, self.N = int(batch), int(device), int(dtype), int(nstate)
         self.np_dtype = np.float32 if dtype == 32 else np.float64
-        rc = self._lib.fbus_ekf_create(C.byref(self._h), C.byref(self.params), self.B, self.device, self.dtype, self.N)
+        rc = self._lib.fbus_ekf_create_checked(C.byref(self._h), C.byref(self.params), C.sizeof(capi.FbusParams), capi.ABI_VERSION,
+                                               self.B, self.device, self.dtype, self.N)
         if rc != 0:
             self._h = C.c_void_p()
             raise capi.FbusError(rc, "fbus_ekf_create", self._lib.fbus_status_string(rc).decode())
@@ -39,6 +40,13 @@ class BatchedFilter:
         # complete before the call and results are complete after sync() (or order the streams with
         # wait_stream()/signal_stream(), or share the caller's stream with set_stream()).
         self._own_stream = True
+        # order_streams (default): while the handle runs on its own stream, every device-array call first makes that
+        # stream wait for the caller's current torch stream (inputs produced there, e.g. an upload or a .to(dtype), are
+        # complete before a kernel reads them) and afterwards makes the caller's stream wait for the call (results are
+        # visible to work queued there).  A caller that synchronises by itself (bench.py's timed region) switches it
+        # off: the two event markers per call cost launch-stream time.
+        self.order_streams = bool(order_streams)
+        self._capturing = False
         if stream is not None:
             self.set_stream(stream)
 
@@ -76,6 +84,10 @@ class BatchedFilter:
         self._check(self._lib.fbus_ekf_set_stream(self._h, C.c_void_p(handle)), "set_stream")
         self._own_stream = stream is None
 
+    def set_team(self, predict_roles=0, correct_roles=0):
+        """waves per 64-filter tile of predict / correct: 0 = chosen per launch (default), 1 = one wave per tile, 2..4 fixed"""
+        self._check(self._lib.fbus_ekf_set_team(self._h, int(predict_roles), int(correct_roles)), "set_team")
+
     def wait_stream(self, stream):
         """work submitted to this filter from now on starts after everything already queued on `stream`"""
         self._check(self._lib.fbus_ekf_wait_stream(self._h, C.c_void_p(int(getattr(stream, "cuda_stream", stream)))), "wait_stream")
@@ -87,6 +99,25 @@ class BatchedFilter:
     def sync(self):
         self._check(self._lib.fbus_ekf_sync(self._h), "sync")
         self._keep.clear()
+
+    def _order_in(self, *arrays):
+        """own stream + order_streams: wait for the caller's current stream; returns it for _order_out (else None)"""
+        if not (self._own_stream and self.order_streams) or self._capturing:
+            return None
+        dev = next((a for a in arrays if a is not None and _is_dev(a) and hasattr(a, "device")), None)
+        if dev is None:
+            return None
+        try:
+            import torch
+            cur = torch.cuda.current_stream(dev.device)
+        except Exception:           # a non-torch device array: the caller orders the streams
+            return None
+        self.wait_stream(cur)
+        return cur
+
+    def _order_out(self, cur):
+        if cur is not None:
+            self.signal_stream(cur)
 
     def _host(self, a, shape, dtype=None):
         a = np.ascontiguousarray(a, dtype or self.np_dtype)
@@ -114,8 +145,10 @@ class BatchedFilter:
     def set_state(self, nominal=None, rot=None, P=None, prev_id=None):
         B, N = self.B, self.N
         if any(_is_dev(x) for x in (nominal, rot, P, prev_id) if x is not None):
+            cur = self._order_in(nominal, rot, P, prev_id)
             rc = self._lib.fbus_ekf_set_state_dev(self._h, self._p(nominal), self._p(rot), self._p(P), self._p(prev_id))
-            return self._check(rc, "set_state_dev")
+            self._check(rc, "set_state_dev")
+            return self._order_out(cur)
         nominal = None if nominal is None else self._host(nominal, (B, 19))
         rot = None if rot is None else self._host(rot, (B, 9))
         P = None if P is None else self._host(P, (B, N, N))
@@ -161,8 +194,10 @@ class BatchedFilter:
                 raise ValueError("dt must have K or K*B elements")
             self._dev_checked(accel, K * B * 3, "accel"); self._dev_checked(gyro, K * B * 3, "gyro")
             self._dev_checked(dt, dt.numel(), "dt")
+            cur = self._order_in(accel, gyro, dt)
             rc = self._lib.fbus_ekf_predict_n_dev(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per)
-            return self._check(rc, "predict_n_dev")
+            self._check(rc, "predict_n_dev")
+            return self._order_out(cur)
         accel = np.ascontiguousarray(accel, self.np_dtype)
         K = K if K is not None else accel.size // (3 * B)
         accel = self._host(accel, (K, B, 3))
@@ -183,8 +218,10 @@ class BatchedFilter:
             self._dev_checked(quat, B * M * 4, "quat")
             if skip is not None:
                 self._dev_checked(skip, B, "skip")
+            cur = self._order_in(ids, pos, quat, skip)
             rc = self._lib.fbus_ekf_correct_dev(self._h, M, self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
-            return self._check(rc, "correct_dev")
+            self._check(rc, "correct_dev")
+            return self._order_out(cur)
         ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
         M = ids.shape[1]
         pos = self._host(pos, (B, M, 3))
@@ -206,9 +243,11 @@ class BatchedFilter:
                 self._dev_checked(right, B * M * 8, "right")
             if skip is not None:
                 self._dev_checked(skip, B, "skip")
+            cur = self._order_in(ids, left, right, skip)
             rc = self._lib.fbus_ekf_correct_corners_dev(self._h, M, self._p(ids), self._p(left), self._p(right),
                                                         geometry, mode, self._p(skip))
-            return self._check(rc, "correct_corners_dev")
+            self._check(rc, "correct_corners_dev")
+            return self._order_out(cur)
         ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
         M = ids.shape[1]
         left = self._host(left, (B, M, w))
@@ -230,8 +269,10 @@ class BatchedFilter:
                 self._dev_checked(right, B * M * 8, "right")
             if skip is not None:
                 self._dev_checked(skip, B, "skip")
+            cur = self._order_in(ids, left, right, skip)
             rc = self._lib.fbus_ekf_correct_pixels_dev(self._h, M, self._p(ids), self._p(left), self._p(right), self._p(skip))
-            return self._check(rc, "correct_pixels_dev")
+            self._check(rc, "correct_pixels_dev")
+            return self._order_out(cur)
         ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
         M = ids.shape[1]
         left = self._host(left, (B, M, 8))
@@ -264,9 +305,11 @@ class BatchedFilter:
         if skip is not None:
             self._dev_checked(skip, B, "skip")
         fn = self._lib.fbus_ekf_frame_fused_dev if fused else self._lib.fbus_ekf_frame_dev
+        cur = self._order_in(accel, gyro, dt, ids, pos, quat, skip)
         rc = fn(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per, M,
                                           self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip))
         self._check(rc, "frame_dev")
+        self._order_out(cur)
 
     def frames(self, kcount, accel, gyro, dt, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
         """A window of camera frames in ONE launch (device arrays): len(kcount) times { kcount[f] predicts, one correct }
@@ -291,10 +334,12 @@ class BatchedFilter:
             self._dev_checked(quat, F * B * M * 4, "quat")
         if skip is not None:
             self._dev_checked(skip, F * B, "skip")
+        cur = self._order_in(accel, gyro, dt, ids, pos, quat, skip)
         rc = self._lib.fbus_ekf_frames_fused_dev(self._h, F, kcount.ctypes.data_as(C.POINTER(C.c_int32)), self._p(accel),
                                                  self._p(gyro), self._p(dt), per, M, self._p(ids), self._p(pos), self._p(quat),
                                                  mode, self._p(skip))
         self._check(rc, "frames_fused_dev")
+        self._order_out(cur)
 
     # ---- init / reset / front door (host arrays) --------------------------------------------
     def init_gravity_bias(self, accel, gyro):
@@ -347,14 +392,11 @@ class BatchedFilter:
             quat = torch.empty((n, 4), dtype=left.dtype, device=left.device)
             c3 = torch.empty((n, 4, 3), dtype=left.dtype, device=left.device) if want_corners else None
             self._keep += [left, right, pos, quat, c3]
-            cur = torch.cuda.current_stream(left.device) if self._own_stream else None
-            if cur is not None:                     # inputs come from / outputs go to torch's stream: order both ways
-                self.wait_stream(cur)
+            cur = self._order_in(left, right)       # inputs come from / outputs go to torch's stream: order both ways
             rc = self._lib.fbus_ekf_marker_pose_dev(self._h, n, geometry, self._p(left), self._p(right),
                                                     self._p(pos), self._p(quat), self._p(c3))
             self._check(rc, "marker_pose_dev")
-            if cur is not None:
-                self.signal_stream(cur)
+            self._order_out(cur)
             return (pos, quat, c3) if want_corners else (pos, quat)
         left = np.ascontiguousarray(left, self.np_dtype).reshape(-1, w)
         n = left.shape[0]
@@ -382,9 +424,11 @@ class BatchedFilter:
     def graph_capture(self, fn):
         """Runs fn() (device-array calls on this filter only) under stream capture; returns a graph id."""
         self._check(self._lib.fbus_ekf_graph_begin(self._h), "graph_begin")
+        self._capturing = True          # no cross-stream markers inside a capture: the caller orders the graph launch
         try:
             fn()
         finally:
+            self._capturing = False
             gid = C.c_int(-1)
             rc = self._lib.fbus_ekf_graph_end(self._h, C.byref(gid))
         self._check(rc, "graph_end")

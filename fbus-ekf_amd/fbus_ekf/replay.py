@@ -14,6 +14,9 @@ helpers below restate the same formulas for the tests.
 import numpy as np
 
 from . import synth
+from .capi import MAX_VISIBLE
+
+MAX_KCOUNT = 255      # IMU samples a window entry can name (fbus_ekf_frames_fused_dev: kcount is 0..255)
 
 
 def init_gravity_gyrobias(imu_rows):
@@ -99,7 +102,9 @@ def plan_windows(imu, image, max_frames=None, matlab_reset=True, max_window=64):
     """The frame loop of FBUS_EKF.m:151-210 as a PLAN: which IMU samples (with their dt) go in front of which frame, where the
     script would reset instead (a vision gap > 0.1 s, FBUS_EKF.m:168-171), cut into windows of consecutive non-reset frames
     of at most `max_window` frames.  Everything here depends on the time stamps only, so a whole recording can be planned
-    before the first launch.  Returns a list of ("reset", meas) and ("window", kcount, imu_rows, dts, [meas per frame])."""
+    before the first launch.  Returns a list of ("reset", meas), ("window", kcount, imu_rows, dts, [meas per frame]) and --
+    only when a frame has more than 255 IMU samples in front of it -- ("predict", imu_rows, dts) for the leading samples
+    that do not fit a window entry.  Raises ValueError for a frame with more than MAX_VISIBLE markers."""
     imu = np.asarray(imu, float)
     image = np.asarray(image, float)
     idx = int(np.argmax(imu[:, 0] > image[0, 0]))
@@ -141,9 +146,18 @@ def plan_windows(imu, image, max_frames=None, matlab_reset=True, max_window=64):
             k += 1
         idx = k
         pre_img = cur
+        if len(meas) > MAX_VISIBLE:
+            raise ValueError(f"frame at t = {cur}: {len(meas)} markers, at most {MAX_VISIBLE} per frame")
+        if len(rows) > MAX_KCOUNT:
+            # more IMU samples in front of this frame than a window entry can name (kcount is 0..255; a 1 kHz IMU after a
+            # long vision gap with matlab_reset = False): the leading samples run as plain predicts in front of the window
+            flush()
+            cut = len(rows) - MAX_KCOUNT
+            plan.append(("predict", np.array(rows[:cut], int), np.array(dts[:cut], float)))
+            rows, dts = rows[cut:], dts[cut:]
         if cur_win is None:
             cur_win = ["window", [], [], [], []]
-        if len(cur_win[1]) == max_window or len(rows) > 255:
+        if len(cur_win[1]) == max_window:
             flush()
             cur_win = ["window", [], [], [], []]
         cur_win[1].append(len(rows)); cur_win[2] += rows; cur_win[3] += dts; cur_win[4].append(meas)
@@ -175,12 +189,23 @@ def replay_windowed(flt, imu, image, params, max_frames=None, max_window=64):
             meas = item[1]
             flt.pose_init(rep(meas[:, 0].astype(np.int32)[None]), rep(meas[None, :, 1:4]), rep(meas[None, :, 4:8]), 1)
             continue
+        up = lambda a, t=tt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(t)
+        if item[0] == "predict":
+            _, rows, dts = item
+            for c0 in range(0, len(rows), 64):              # bounded uploads: (64, B, 3) per call
+                r = rows[c0:c0 + 64]
+                d_acc = up(imu[r, 1:4])[:, None, :].expand(len(r), B, 3).contiguous()
+                d_gyr = up(imu[r, 4:7])[:, None, :].expand(len(r), B, 3).contiguous()
+                d_dt = up(dts[c0:c0 + 64])
+                flt.wait_stream(torch.cuda.current_stream())
+                flt.predict_n(d_acc, d_gyr, d_dt, K=len(r))
+            steps += len(rows)
+            continue
         _, kcount, rows, dts, frames = item
         F, M = len(frames), max(len(m) for m in frames)
         ids = np.full((F, 1, M), -1, np.int32); pos = np.zeros((F, 1, M, 3)); quat = np.zeros((F, 1, M, 4)); quat[..., 0] = 1
         for f, m in enumerate(frames):
             ids[f, 0, :len(m)] = m[:, 0].astype(np.int32); pos[f, 0, :len(m)] = m[:, 1:4]; quat[f, 0, :len(m)] = m[:, 4:8]
-        up = lambda a, t=tt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(t)
         d_acc = up(imu[rows, 1:4])[:, None, :].expand(len(rows), B, 3).contiguous()
         d_gyr = up(imu[rows, 4:7])[:, None, :].expand(len(rows), B, 3).contiguous()
         d_ids = torch.from_numpy(ids).to(dev).expand(F, B, M).contiguous()

@@ -48,7 +48,8 @@ typedef enum fbus_status {
     FBUS_ERR_NO_DEVICE = 2,     /* no usable HIP device                  */
     FBUS_ERR_HIP = 3,           /* a HIP runtime call failed             */
     FBUS_ERR_UNSUPPORTED = 4,   /* dtype / nstate / mode not built       */
-    FBUS_ERR_NOMEM = 5
+    FBUS_ERR_NOMEM = 5,
+    FBUS_ERR_ABI = 6            /* caller built against another header version (see FBUS_ABI_VERSION) */
 } fbus_status;
 
 /* Which of the reference's two implementations is reproduced. */
@@ -94,10 +95,30 @@ typedef struct fbus_params {
  * (FBUS_EKF.m / paramconfig.yml / camerainfo1.yml / GetMarkerMap.m). */
 int fbus_params_default(fbus_params* prm, int dialect);
 
+/* ---- ABI version ---------------------------------------------------------- */
+/* fbus_params is passed by pointer and has grown (round 2 added r_pix); fbus_ekf_set_stream(h, NULL) changed
+ * meaning in round 2 (NULL is HIP's legacy default stream now, FBUS_STREAM_OWN the handle's own stream).  A caller built
+ * against an older header must not run silently against a newer library: fbus_ekf_create below is a macro that hands
+ * the caller's compile-time sizeof(fbus_params) and FBUS_ABI_VERSION to fbus_ekf_create_checked, which refuses a
+ * mismatch with FBUS_ERR_ABI.  (Bindings that cannot use the macro -- ctypes, loadlibrary -- call
+ * fbus_ekf_abi_version() / fbus_params_size() once after loading and compare; the Python mirror does.)
+ *   3  round 3: FBUS_ERR_ABI, create_checked, team kernels (fbus_ekf_set_team), fbus_ekf_gather
+ *   2  round 2: r_pix in fbus_params, set_stream(NULL) = legacy default stream
+ *   1  round 1 */
+#define FBUS_ABI_VERSION 3
+int fbus_ekf_abi_version(void);
+size_t fbus_params_size(void);
+
 /* ---- lifetime ------------------------------------------------------------- */
 /* Replaces: FILTER::FILTER (filter.hpp:63-137) for a batch of filters.
  * dtype 32|64, nstate 15|18.  device = HIP ordinal. */
+int fbus_ekf_create_checked(fbus_ekf_t* out, const fbus_params* prm, size_t params_size, int abi_version,
+                            int batch, int device, int dtype, int nstate);
 int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int device, int dtype, int nstate);
+#ifndef FBUS_EKF_NO_ABI_CHECK
+#define fbus_ekf_create(out, prm, batch, device, dtype, nstate) \
+    fbus_ekf_create_checked((out), (prm), sizeof(fbus_params), FBUS_ABI_VERSION, (batch), (device), (dtype), (nstate))
+#endif
 int fbus_ekf_destroy(fbus_ekf_t h);
 /* Run all work of this handle on an existing hipStream_t (e.g. the caller's
  * framework stream).  hip_stream is the hipStream_t itself: NULL (0) is HIP's
@@ -109,6 +130,14 @@ int fbus_ekf_destroy(fbus_ekf_t h);
  * below). */
 #define FBUS_STREAM_OWN ((void*)(intptr_t)-1)
 int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream);
+/* Waves per 64-filter tile of predict / correct (fp32; no reference counterpart -- the reference runs one filter on one
+ * thread, filter.cpp:190-250).  0 (default): chosen per launch from what was measured faster (predict: 3 waves per tile up to
+ * 16 384 filters, predict_n: 4 up to 32 768, correct: always one -- DESIGN.md section 4.5); 1: always one wave per tile;
+ * 2..4: always that many ("team" kernels).  Results agree to fp32 rounding whatever the choice (predict: the same arithmetic, 1 ulp on a few
+ * covariance elements where the compiler fuses a different product; correct: the team kernel applies the stacked update in
+ * one step, the one-wave kernel as six sequential rank-1 passes), so a caller that compares runs BIT FOR BIT across batch
+ * sizes or shard layouts pins the value. */
+int fbus_ekf_set_team(fbus_ekf_t h, int predict_roles, int correct_roles);
 /* Cross-stream ordering without a host sync (hipEventRecord + hipStreamWaitEvent):
  * wait_stream   -- work submitted to the handle's stream after this call starts
  *                  only when everything already submitted to other_stream is done

@@ -66,8 +66,14 @@ static void symmetrise(double* P, int n)
  * Matlab's inv, MeasureUpdate.m:84). Returns 0 on success.                */
 static int mat_inv(double* A, int n)
 {
-    double W[FBO_MMAX * 2 * FBO_MMAX];     /* stack scratch: thread-friendly, no allocator in the timed path */
-    if (n > FBO_MMAX) return -1;
+    /* scratch sized by the ACTUAL n: the reference path (7 rows) needs 7 x 14 doubles on the stack, not the 1 MiB
+     * FBO_MMAX would reserve in every worker thread; above FBO_STACK_ROWS rows (stacked corner / pixel models) the
+     * scratch comes from the heap. */
+    if (n > FBO_MMAX || n <= 0) return -1;
+    const int on_stack = (n <= FBO_STACK_ROWS);
+    double Wstack[on_stack ? n * 2 * n : 1];
+    double* W = on_stack ? Wstack : (double*)malloc(sizeof(double) * (size_t)n * 2 * n);
+    if (!W) return -3;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             W[i * 2 * n + j] = A[i * n + j];
@@ -77,7 +83,7 @@ static int mat_inv(double* A, int n)
         int piv = c;
         for (int r = c + 1; r < n; ++r)
             if (fabs(W[r * 2 * n + c]) > fabs(W[piv * 2 * n + c])) piv = r;
-        if (W[piv * 2 * n + c] == 0.0) return -2;
+        if (W[piv * 2 * n + c] == 0.0) { if (!on_stack) free(W); return -2; }
         if (piv != c)
             for (int j = 0; j < 2 * n; ++j) {
                 double t = W[c * 2 * n + j];
@@ -95,6 +101,7 @@ static int mat_inv(double* A, int n)
     }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) A[i * n + j] = W[i * 2 * n + n + j];
+    if (!on_stack) free(W);
     return 0;
 }
 
@@ -102,7 +109,10 @@ static int mat_inv(double* A, int n)
  * for Eigen's S.ldlt().solve(H*P), filter.cpp:711.  X overwrites B.        */
 static void ldlt_solve(const double* S, double* B, int m, int n)
 {
-    double L[FBO_MMAX * FBO_MMAX], D[FBO_MMAX];
+    const int on_stack = (m <= FBO_STACK_ROWS);
+    double Lstack[on_stack ? m * m : 1], D[FBO_MMAX];
+    double* L = on_stack ? Lstack : (double*)malloc(sizeof(double) * (size_t)m * m);
+    if (!L) return;
     memset(L, 0, sizeof(double) * (size_t)m * m);
     for (int j = 0; j < m; ++j) {
         double d = S[j * m + j];
@@ -128,6 +138,7 @@ static void ldlt_solve(const double* S, double* B, int m, int n)
             B[i * n + c] = v;
         }
     }
+    if (!on_stack) free(L);
 }
 
 /* ------------------------------------------------------------------ */
@@ -386,7 +397,7 @@ void fbo_predict(fbo_state* s, const fbo_params* prm,
     double Fx[FBO_NMAX * FBO_NMAX];
     build_Fx(s, prm, a, w, dt, Fx);
 
-    double FP[FBO_NMAX * FBO_NMAX], Pn[FBO_NMAX * FBO_NMAX];
+    double FP[FBO_NMAX * FBO_NMAX], Pn[FBO_NMAX * FBO_NMAX] = { 0 };
     mat_mul(Fx, s->P, FP, n, n, n);
     mat_mul_bt(FP, Fx, Pn, n, n, n);
     for (int i = 3; i < 15; ++i) Pn[i * n + i] += prm->q_diag[(i - 3) / 3];   /* Fi*Q*Fi' */
@@ -558,18 +569,23 @@ static void dense_update(fbo_state* s, const fbo_params* prm, int m, const doubl
 {
     const int n = prm->nstate;
     const int cpp = (prm->dialect == FBO_DIALECT_CPP);
-    double HP[FBO_MMAX * FBO_NMAX], S[FBO_MMAX * FBO_MMAX], K[FBO_NMAX * FBO_MMAX];
+    /* scratch by the actual row count m (see mat_inv): stack up to FBO_STACK_ROWS rows, heap above */
+    const int on_stack = (m <= FBO_STACK_ROWS);
+    const size_t need = (size_t)m * n * 4 + (size_t)m * m;                 /* HP, K, PHt, X, S */
+    double scratch_stack[on_stack ? need : 1];
+    double* scratch = on_stack ? scratch_stack : (double*)malloc(sizeof(double) * need);
+    if (!scratch) return;
+    double* HP = scratch; double* K = HP + (size_t)m * n; double* PHt = K + (size_t)m * n; double* X = PHt + (size_t)m * n;
+    double* S = X + (size_t)m * n;
     /* S = H P H' + Rm    MeasureUpdate.m:84 ; filter.cpp:709-710 */
     mat_mul(H, s->P, HP, m, n, n);
     mat_mul_bt(HP, H, S, m, n, m);
     for (int j = 0; j < m; ++j) S[j * m + j] += Rd[j];
     if (!cpp) {                             /* K = P H' inv(S) */
-        double PHt[FBO_NMAX * FBO_MMAX];
         mat_mul_bt(s->P, H, PHt, n, n, m);
         mat_inv(S, m);
         mat_mul(PHt, S, K, n, m, m);
     } else {                                /* K' = S.ldlt().solve(H P) */
-        double X[FBO_MMAX * FBO_NMAX];
         memcpy(X, HP, sizeof(double) * m * n);
         ldlt_solve(S, X, m, n);
         for (int i = 0; i < n; ++i)
@@ -606,6 +622,7 @@ static void dense_update(fbo_state* s, const fbo_params* prm, int m, const doubl
     }
     symmetrise(Pn, n);
     memcpy(s->P, Pn, sizeof(double) * n * n);
+    if (!on_stack) free(scratch);
     /* rotateMat / rotmatI2G deliberately NOT refreshed (both dialects) */
 }
 

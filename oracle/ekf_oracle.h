@@ -41,6 +41,7 @@ extern "C" {
 #define FBO_NMAX 18
 #define FBO_MAX_MARKERS 32      /* map entries */
 #define FBO_MAX_VISIBLE 16      /* markers per frame */
+#define FBO_STACK_ROWS 32                 /* dense updates of up to this many rows keep their scratch on the stack (<= 29 KiB) */
 #define FBO_MMAX (16 * FBO_MAX_VISIBLE)  /* stacked measurement rows (7 per marker pose, 12 per marker corners, 16 per marker stereo pixels) */
 
 enum { FBO_DIALECT_MATLAB = 0, FBO_DIALECT_CPP = 1 };

@@ -447,3 +447,31 @@ def test_window_plan_is_the_matlab_frame_loop():
         else:
             assert np.array_equal(a[1], b[1])
     assert sum(len(p[1]) for p in plan if p[0] == "window") + 2 == nfr == len(ref)
+
+
+def test_window_plan_long_gap_and_too_many_markers():
+    """A frame with more than 255 IMU samples in front of it (1 kHz IMU across a vision gap, C++-style loop without the Matlab
+    reset) must not produce a window entry fbus_ekf_frames_fused_dev rejects (kcount is 0..255): the leading samples come
+    back as a ("predict", rows, dts) item, every sample exactly once and in order; a frame with more than MAX_VISIBLE markers
+    is a clear ValueError, not an opaque C error in the middle of a replay."""
+    t_imu = np.arange(0, 1.0, 1e-3)
+    imu = np.concatenate([t_imu[:, None], np.zeros((len(t_imu), 6))], axis=1)
+    image = np.array([[0.05, 0, 0, 0, 1, 1, 0, 0, 0], [0.10, 0, 0, 0, 1, 1, 0, 0, 0],
+                      [0.50, 0, 0, 0, 1, 1, 0, 0, 0], [0.55, 0, 0, 0, 1, 1, 0, 0, 0], [0.60, 0, 0, 0, 1, 1, 0, 0, 0]])
+    plan = replay.plan_windows(imu, image, matlab_reset=False)
+    seen = []
+    for item in plan:
+        if item[0] == "predict":
+            assert len(item[1]) == len(item[2]) > 0
+            seen += list(item[1])
+        elif item[0] == "window":
+            assert item[1].max() <= replay.MAX_KCOUNT
+            seen += list(item[2])
+    assert any(i[0] == "predict" for i in plan)
+    assert seen == sorted(seen) and len(set(seen)) == len(seen)
+    # the matlab loop resets across that gap instead: no oversize entry, no predict item
+    plan_m = replay.plan_windows(imu, image, matlab_reset=True)
+    assert not any(i[0] == "predict" for i in plan_m) and any(i[0] == "reset" for i in plan_m)
+    crowded = np.array([[0.05, k, 0, 0, 1, 1, 0, 0, 0] for k in range(capi.MAX_VISIBLE + 1)] + [[0.1, 0, 0, 0, 1, 1, 0, 0, 0]])
+    with pytest.raises(ValueError, match="markers"):
+        replay.plan_windows(imu, crowded)

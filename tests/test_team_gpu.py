@@ -1,0 +1,185 @@
+"""GPU suite for the team kernels (fbus-ekf_amd/csrc/ekf_team.hpp): several waves per 64-filter tile.
+
+predict / predict_n run the SAME device functions on the same operands as the one-wave kernels; the results are equal up to
+the compiler's FMA contraction, which picks a different product of an `a*b + c*d` to fuse in a few expressions of the
+differently specialised kernels (measured: 1 ulp on 5 of the 171 covariance elements of 17 of 311 filters, nominal state
+bit-equal) -- asserted to 2 ulp-level bounds.  correct applies the stacked update in one step (P - W W') instead of six sequential rank-1 passes: it goes
+through the parity gate against the fp64 oracle (tests/util.py) like every other kernel, and is compared with the
+one-wave kernel's posterior.  Reference operations: matlab/ImuUpdate.m:63-81, matlab/MeasureUpdate.m:71-102,
+C++/src/filter.cpp:588-616,622-741."""
+import numpy as np
+import pytest
+
+from fbus_ekf import BatchedFilter, capi, synth
+from replay_ref import OracleEngine
+from util import assert_parity, parity_errors
+
+pytestmark = pytest.mark.gpu
+DT = np.array([np.float64(np.float32(0.005))])
+
+
+def _r32(a):
+    return np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+
+
+def _batch(B, dialect, n, seed_off=0):
+    prm = capi.default_params(dialect)
+    nom, rot, P, prev = synth.initial_state(seed_off, seed_off + B, list(prm.p0_diag), n, mixed_cov=True)
+    return prm, _r32(nom), _r32(rot), _r32(P), prev
+
+
+def _same(a, b, what, ulps=2.0, nominal_exact=True):
+    """nominal state, rotation bit-equal (or to `ulps` fp32 ulps), marker id equal; covariance equal to `ulps` fp32 ulps of
+    sqrt(P_ii P_jj)"""
+    for x, y, name in zip((a[0], a[1]), (b[0], b[1]), ("nominal", "rot")):
+        x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+        ok = np.array_equal(x, y) if nominal_exact else np.allclose(x, y, rtol=ulps * 1.2e-7, atol=ulps * 1.2e-7 * 0.05)
+        assert ok, f"{what}: {name} differs (max |d| {np.abs(x - y).max():.3g})"
+    assert np.array_equal(a[3], b[3]), f"{what}: prev id"
+    Pa, Pb = np.asarray(a[2], np.float64), np.asarray(b[2], np.float64)
+    d = np.sqrt(np.abs(np.einsum("bii->bi", Pb)))
+    rel = np.abs(Pa - Pb) / (d[:, :, None] * d[:, None, :])
+    assert rel.max() <= ulps * 1.2e-7, f"{what}: covariance differs by {rel.max() / 1.2e-7:.2f} ulp of sqrt(P_ii P_jj)"
+    return float((Pa != Pb).mean())
+
+
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_team_predict_equals_one_wave_predict(dialect, n):
+    """one ImuUpdate per launch: 2, 3 and 4 roles against the one-wave kernel, ragged batch, per-filter and scalar dt,
+    several steps in a row (every stored byte of the record is compared through get_state)"""
+    B = 5 * 64 - 9
+    prm, nom, rot, P, prev = _batch(B, dialect, n)
+    acc, gyr = synth.imu_samples(0, B, 0, 3, nom)
+    acc, gyr = _r32(acc), _r32(gyr)
+    dtb = _r32(np.random.default_rng(3).uniform(0.001, 0.01, B))
+    ref = None
+    for roles in (1, 2, 3, 4):
+        with BatchedFilter(B, prm, nstate=n) as flt:
+            flt.set_team(roles, 1)
+            flt.set_state(nom, rot, P, prev)
+            flt.predict(acc[0], gyr[0], dtb)
+            flt.predict(acc[1], gyr[1], DT)
+            flt.predict(acc[2], gyr[2], DT)
+            got = flt.get_state()
+        if ref is None:
+            ref = got
+            eng = OracleEngine(B, dialect, n)
+            eng.set_state(nom, rot, P, prev)
+            eng.predict(acc[0], gyr[0], dtb); eng.predict(acc[1], gyr[1], DT); eng.predict(acc[2], gyr[2], DT)
+            assert_parity(ref, eng.get_state(), 32, f"one-wave predict x3 dialect {dialect} N {n}", plain_tol=5e-3)
+        else:
+            _same(got, ref, f"predict, {roles} roles, dialect {dialect}, N {n}")
+
+
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_team_predict_n_equals_one_wave_predict_n(dialect, n):
+    """K samples per launch with the rows handed on through LDS between the steps: K = 1, 2, 3, 8 against the one-wave predict_n
+    and against K per-call predicts"""
+    B = 3 * 64 + 5
+    prm, nom, rot, P, prev = _batch(B, dialect, n, seed_off=11)
+    for K in (2, 3, 8):
+        acc, gyr = synth.imu_samples(11, 11 + B, 0, K, nom)
+        acc, gyr = _r32(acc), _r32(gyr)
+        dts = _r32(np.random.default_rng(K).uniform(0.002, 0.008, K))
+        out = {}
+        for roles in (1, 4):
+            with BatchedFilter(B, prm, nstate=n) as flt:
+                flt.set_team(roles, 1)
+                flt.set_state(nom, rot, P, prev)
+                flt.predict_n(acc, gyr, dts)
+                out[roles] = flt.get_state()
+        _same(out[4], out[1], f"predict_n K = {K}, dialect {dialect}, N {n}", ulps=2.0 * K, nominal_exact=False)
+        with BatchedFilter(B, prm, nstate=n) as flt:
+            flt.set_team(1, 1)
+            flt.set_state(nom, rot, P, prev)
+            for k in range(K):
+                flt.predict(acc[k], gyr[k], dts[k:k + 1])
+            per_call = flt.get_state()
+        e = parity_errors(out[4], per_call)
+        assert e["literal"] < 2e-6 and e["cov_block"] < 2e-6, (K, e)   # resident vs streamed: same functions, fp32 rounding of reloads only
+
+
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_team_correct_parity(dialect, mode, n):
+    """MeasureUpdate through 2, 3 and 4 roles: the parity gate against the oracle, the one-wave kernel's posterior, the applied
+    flags, prev_id; filters without a usable marker, with ids outside the map, skipped filters; M = 1, 4, 7, 16"""
+    B = 4 * 64 - 3
+    prm, nom, rot, P, prev = _batch(B, dialect, n, seed_off=5)
+    rng = np.random.default_rng(5)
+    for M in (1, 4, 7, 16):
+        ids, pos, quat = synth.marker_frame(5, 5 + B, 0, min(M, 12), nom, prm)
+        if M > 12:
+            pad = M - 12
+            ids = np.concatenate([ids, np.full((B, pad), -1, np.int32)], axis=1)
+            pos = np.concatenate([pos, np.zeros((B, pad, 3))], axis=1)
+            quat = np.concatenate([quat, np.tile([1.0, 0, 0, 0], (B, pad, 1))], axis=1)
+        pos = _r32(pos + rng.normal(0, 0.02, pos.shape))
+        quat = _r32(quat)
+        ids[0] = -1
+        ids[1] = 9
+        if M > 1:
+            ids[2, 1] = -1
+            ids[3, 0] = 9
+        prev_in = rng.choice([0, 1, 2, 16], B).astype(np.int32)
+        skip = np.zeros(B, np.uint8)
+        skip[7] = 1
+        eng = OracleEngine(B, dialect, n)
+        eng.set_state(nom, rot, P, prev_in)
+        eng.correct(ids, pos, quat, mode)
+        ref = [np.array(x) for x in eng.get_state()]
+        for x, x0 in zip(ref, (nom, rot, P, prev_in)):          # the oracle has no skip mask: a skipped filter keeps its state
+            x[7] = x0[7]
+        one = None
+        for roles in (1, 2, 3, 4):
+            with BatchedFilter(B, prm, nstate=n) as flt:
+                flt.set_team(1, roles)
+                flt.set_state(nom, rot, P, prev_in)
+                flt.correct(ids, pos, quat, mode, skip)
+                got = flt.get_state()
+                app = flt.applied()
+            assert_parity(got, ref, 32, f"correct {roles} roles mode {mode} dialect {dialect} N {n} M {M}")
+            if one is None:
+                one, app1 = got, app
+            else:
+                assert np.array_equal(app, app1)
+                e = parity_errors(got, one)
+                assert e["literal"] < 2e-6 and e["sigma"] < 5e-6 and e["cov_block"] < 5e-6 and e["prev_equal"], (roles, M, e)
+        assert app1[0] == 0 and app1[1] == 0 and app1[7] == 0 and app1[10] == 1
+
+
+def test_team_is_the_default_for_small_batches():
+    """the launcher's choice: with the default setting a 4096-filter predict must give the team kernel's result (bit-equal to
+    an explicit set_team; correct stays on the one-wave kernel) -- and the whole per-call frame (K predicts + correct) stays
+    inside the parity gate"""
+    B, M, n, dialect = 4096, 4, 18, 0
+    prm, nom, rot, P, prev = _batch(B, dialect, n, seed_off=3)
+    acc, gyr = synth.imu_samples(3, 3 + B, 0, 7, nom)
+    acc, gyr = _r32(acc), _r32(gyr)
+    ids, pos, quat = synth.marker_frame(3, 3 + B, 0, M, nom, prm)
+    pos, quat = _r32(pos), _r32(quat)
+    out = {}
+    for setting in ("default", "explicit"):
+        with BatchedFilter(B, prm) as flt:
+            if setting == "explicit":
+                flt.set_team(3, 1)
+            flt.set_state(nom, rot, P, prev)
+            for k in range(7):
+                flt.predict(acc[k], gyr[k], DT)
+            flt.correct(ids, pos, quat, capi.MODE_STACKED)
+            out[setting] = flt.get_state()
+    for x, y in zip(out["default"], out["explicit"]):
+        assert np.array_equal(x, y), "default policy at 4096 filters is not the team kernels"
+    eng = OracleEngine(B, dialect, n)
+    eng.set_state(nom, rot, P, prev)
+    sub = slice(0, B, 37)
+    eng = OracleEngine(len(range(B)[sub]), dialect, n)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    for k in range(7):
+        eng.predict(acc[k][sub], gyr[k][sub], DT)
+    eng.correct(ids[sub], pos[sub], quat[sub], capi.MODE_STACKED)
+    got = tuple(x[sub] for x in out["default"])
+    assert_parity(got, eng.get_state(), 32, "frame of 7 + 1 steps, team kernels, 4096 filters", plain_tol=5e-3)

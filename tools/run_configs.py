@@ -36,7 +36,7 @@ def run(B, dtype, M, what, K=1, mode=1, reps=200, n=18):
     nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), n)
     acc, gyr = synth.imu_samples(0, B, 0, max(K, 1), nom)
     d_acc, d_gyr, d_dt = tensors(acc, tdt), tensors(gyr, tdt), tensors(np.full(max(K, 1), 0.005), tdt)
-    with BatchedFilter(B, prm, dtype=dtype, nstate=n) as flt:
+    with BatchedFilter(B, prm, dtype=dtype, nstate=n, order_streams=False) as flt:
         flt.set_state(nom, rot, P, prev)
         if what == "predict":
             us = timed(flt, capi.KERNEL_PREDICT, lambda: flt.predict(d_acc[0], d_gyr[0], d_dt[:1]), reps)
