@@ -26,8 +26,10 @@ Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (predict)
 launch (1436 B per filter: 828 read, 608 written -- the predict-invariant covariance tail and ba/bg/g are not
 written back) / its average duration measured with HIP events on the launch stream inside the timed region;
 `achieved_api` prices SURVEY.md 8(d)'s full record round trip (1620 B) instead.  `roofline_hbm_resident` is the
-same measurement at 262 144 filters per GPU (210 MB of records: past the 256 MB Infinity Cache once the inputs are
-counted).  `cpu_baseline` is the fp64 dense oracle port (oracle/), timed on a bounded sample.
+same measurement at 1 048 576 filters per GPU (839 MB of records: three times the 256 MiB Infinity Cache);
+`roofline_b262144` the round-2 leg (210 MB: partly cache-resident).  `fp64` is the same workload through the fp64 kernels,
+`compute_bound` the 128-row reprojection update (correct_pixels).  `cpu_baseline` is the fp64 dense oracle port (oracle/),
+timed on a bounded sample.
 """
 import argparse
 import json
@@ -56,7 +58,11 @@ CORRECT_BYTES_API = lambda M: 2 * 796 + 32 * M
 PREDICT_BYTES_MOVED = 50 * 16 + 28 + 38 * 16
 CORRECT_BYTES_MOVED = lambda M: 50 * 16 + 32 * M + 48 * 16 + 1
 POOL = 4                            # distinct 0.1 s input patterns (IMU samples + marker frames) resident in HBM, cycled
-HBM_LEG_BATCH = 262144              # the HBM-roofline claim needs B >= 262 144 per GPU
+# The HBM-roofline claim needs records that do NOT fit the 256 MiB (268 MB) Infinity Cache: 1 048 576 filters = 839 MB of records.
+# (Round 2 used 262 144 filters = 210 MB, which still fits: that leg is kept as `roofline_b262144`, labelled for what it is.)
+HBM_LEG_BATCH = 1048576
+MID_LEG_BATCH = 262144
+HBM_COPY_CEILING_GBS = 6290.0       # MI355X_MICROARCH.md: what a float4 copy kernel reaches on this part (0.79 of the 8 TB/s spec)
 
 
 def parse():
@@ -68,12 +74,17 @@ def parse():
     ap.add_argument("--total-batch", type=int, default=0,
                     help="strong scaling: this many filters in total, cut into contiguous 64-aligned shards over the "
                          "ranks (BASELINE.json config 4: 262144 over 1/2/4/8 GPUs)")
+    ap.add_argument("--tile", type=int, default=1,
+                    help="generate the inputs for batch/tile filters and repeat them on the device (the 1 048 576-filter "
+                         "leg as the main workload: --batch 1048576 --tile 16)")
+    ap.add_argument("--only-pixels", action="store_true", help="run only the compute-bound correct_pixels leg (profiling)")
     ap.add_argument("--markers", type=int, default=4)
     ap.add_argument("--mode", choices=["stacked", "nearest"], default="stacked")
     ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 262 144-filter HBM-resident roofline leg")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1 048 576-filter (HBM-resident) and 262 144-filter roofline legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the fp64 leg and the correct_pixels (compute-bound) leg")
     ap.add_argument("--graphs", action="store_true",
                     help="replay each 0.1 s pattern (23 launches) from a captured HIP graph (launch-bound small batches); "
                          "the per-kernel HIP-event timing then comes from a short eager pass after the timed region")
@@ -121,7 +132,7 @@ def pmc_traffic(batch, args, world, kernel="predict"):
     it was taken on THIS configuration (batch, dialect, markers, mode, eager launches, one GPU); otherwise None."""
     if world != 1 or args.graphs:
         return None, None
-    path = os.path.join(ROOT, "profiles", f"r02_digest_b{batch}.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_digest_b{batch}.json") for r in (3, 2)) if os.path.exists(q)), "")
     try:
         d = json.load(open(path))
         cfg = d.get("_config", {})
@@ -215,29 +226,39 @@ def cpu_baseline(args, seconds):
 
 
 class Workload:
-    """device-resident inputs of `pool` distinct 0.1 s patterns for the filters [lo, hi) + the filter handle"""
+    """device-resident inputs of `pool` distinct 0.1 s patterns for the filters [lo, hi) + the filter handle.
+    tile > 1: the inputs and the initial nominal state are generated for (hi - lo) / tile filters and repeated `tile` times on
+    the device (the 1 048 576-filter leg: every filter still has its own record and its own copy of the inputs in HBM -- the
+    traffic is that of distinct filters -- but the host generates 65 536 of them, not a million)."""
 
-    def __init__(self, torch, dev, local_rank, lo, hi, args, pool, with_cov=True):
+    def __init__(self, torch, dev, local_rank, lo, hi, args, pool, with_cov=True, dtype=32, tile=1):
         from fbus_ekf import BatchedFilter, capi, synth
         self.torch, self.capi = torch, capi
         dialect = capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP
         self.mode = capi.MODE_STACKED if args.mode == "stacked" else capi.MODE_NEAREST
-        self.B, self.M = hi - lo, args.markers
+        self.B, self.M, self.dtype = hi - lo, args.markers, dtype
+        assert self.B % tile == 0
+        gen_hi = lo + self.B // tile
         prm = capi.default_params(dialect)
-        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-        nom, rot, P, prev = synth.initial_state(lo, hi, list(prm.p0_diag), 18, with_cov=with_cov)
+        npdt, tdt = (np.float32, torch.float32) if dtype == 32 else (np.float64, torch.float64)
+        rep = (lambda t, d: t if tile == 1 else torch.cat([t] * tile, dim=d))
+        f32 = lambda a, d=0: rep(torch.from_numpy(np.ascontiguousarray(a, npdt)).to(dev), d)
+        nom, rot, P, prev = synth.initial_state(lo, gen_hi, list(prm.p0_diag), 18, with_cov=with_cov)
         self.pool = []
         for s in range(pool):
-            acc, gyr = synth.imu_samples(lo, hi, s * sum(PATTERN), sum(PATTERN), nom)
+            acc, gyr = synth.imu_samples(lo, gen_hi, s * sum(PATTERN), sum(PATTERN), nom)
             frames = []
             for f in range(len(PATTERN)):
-                ids, pos, quat = synth.marker_frame(lo, hi, s * len(PATTERN) + f, self.M, nom, prm)
-                frames.append((torch.from_numpy(ids).to(dev), f32(pos), f32(quat)))
-            self.pool.append((f32(acc), f32(gyr), frames))
-        self.d_dt = f32(np.full(max(PATTERN), 0.005))
+                ids, pos, quat = synth.marker_frame(lo, gen_hi, s * len(PATTERN) + f, self.M, nom, prm)
+                frames.append((rep(torch.from_numpy(ids).to(dev), 0), f32(pos), f32(quat)))
+            self.pool.append((f32(acc, 1), f32(gyr, 1), frames))            # IMU samples are (K, B, 3): filters along dim 1
+        self.d_dt = torch.from_numpy(np.full(max(PATTERN), 0.005, npdt)).to(dev)
         # The handle stays on its own (non-blocking) stream; the inputs above were uploaded on torch's stream, so
         # the device is synchronised before the first launch and on both sides of every timed region.
-        self.flt = BatchedFilter(self.B, prm, device=local_rank, dtype=32, nstate=18, order_streams=False)   # inputs are uploaded and synchronised before the timed region
+        self.flt = BatchedFilter(self.B, prm, device=local_rank, dtype=dtype, nstate=18, order_streams=False)   # inputs are uploaded and synchronised before the timed region
+        if tile > 1:
+            assert P is None
+            nom, rot, prev = np.tile(nom, (tile, 1)), np.tile(rot, (tile, 1)), np.tile(prev, tile)
         self.state0 = (nom, rot, P, prev)
         self.reset_state()
         _, self.bpf, total = self.flt.records()
@@ -277,7 +298,7 @@ class Workload:
                                  torch.stack([f[0] for e in ent for f in e[2]]), torch.stack([f[1] for e in ent for f in e[2]]),
                                  torch.stack([f[2] for e in ent for f in e[2]]))
         self.kcount = np.array(list(PATTERN) * PATTERNS_PER_STEP, np.int32)
-        self.d_dt_window = torch.full((int(self.kcount.sum()),), 0.005, dtype=torch.float32, device=self.rec.device)
+        self.d_dt_window = torch.full((int(self.kcount.sum()),), 0.005, dtype=self.d_dt.dtype, device=self.rec.device)
 
     def step_window(self, i):
         """the same bench step as ONE launch (records resident in registers for the whole second of sensor time)"""
@@ -327,27 +348,102 @@ def _timed(torch, fn, steps, warmup, barrier, before_timing):
 
 def roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src):
     B, M = w.B, w.M
+    es = 1 if w.dtype == 32 else 2                                # fp64 records and inputs are twice the bytes
+    tname = "float" if w.dtype == 32 else "double"
     pred_us = pred_ms / pred_n * 1e3 if pred_n else float("nan")
     corr_us = corr_ms / corr_n * 1e3 if corr_n else float("nan")
-    moved = PREDICT_BYTES_MOVED * B
+    moved = PREDICT_BYTES_MOVED * B * es
     achieved = moved / (pred_us * 1e-6) / 1e9
-    api = PREDICT_BYTES_API * B / (pred_us * 1e-6) / 1e9
-    roof = {"bound": "hbm", "kernel": "predict_kernel<float,18>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    api = PREDICT_BYTES_API * B * es / (pred_us * 1e-6) / 1e9
+    roof = {"bound": "hbm", "kernel": f"predict_kernel<{tname},18>", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": pred_us, "launches": pred_n, "bytes_moved_per_launch": moved,
-            "achieved_api": api, "frac_api": api / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": PREDICT_BYTES_API * B,
+            "achieved_api": api, "frac_api": api / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": PREDICT_BYTES_API * B * es,
+            "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "traffic_GBs": (traffic / (pred_us * 1e-6) / 1e9) if traffic else None,
             "note": "achieved = bytes the kernel moves (1436 B per filter: 828 read, 608 written; the PMC `traffic` of the "
                     "committed profile is the cross-check) / HIP-event launch time; achieved_api prices SURVEY 8(d)'s full "
                     "record round trip (1620 B) and can pass the peak. At 65 536 filters the 52 MB of records stay in the "
                     "256 MB Infinity Cache between launches: that rate is cache + HBM, see roofline_hbm_resident"}
-    corr = {"kernel": "correct_kernel<float,18,stacked>" if w.mode == w.capi.MODE_STACKED else "correct_kernel<float,18,nearest>",
+    cmoved = (CORRECT_BYTES_MOVED(M) - 1) * es + 1
+    corr = {"kernel": f"correct_kernel<{tname},18,{'stacked' if w.mode == w.capi.MODE_STACKED else 'nearest'}>",
             "avg_launch_us": corr_us, "launches": corr_n,
-            "achieved_GBs": CORRECT_BYTES_MOVED(M) * B / (corr_us * 1e-6) / 1e9,
-            "frac": CORRECT_BYTES_MOVED(M) * B / (corr_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "bytes_moved_per_launch": CORRECT_BYTES_MOVED(M) * B,
-            "achieved_api_GBs": CORRECT_BYTES_API(M) * B / (corr_us * 1e-6) / 1e9}
+            "achieved_GBs": cmoved * B / (corr_us * 1e-6) / 1e9,
+            "frac": cmoved * B / (corr_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "bytes_moved_per_launch": cmoved * B,
+            "achieved_api_GBs": CORRECT_BYTES_API(M) * B * es / (corr_us * 1e-6) / 1e9}
     return roof, corr
+
+
+
+def fp64_leg(torch, dev, local_rank, args, capi):
+    """the same per-call workload through the fp64 kernels (the reference's own arithmetic: common.hpp:205-247) at the batch of
+    the headline: value, ms per step and the roofline of the dominant kernel from the bytes the fp64 kernels move"""
+    torch.cuda.empty_cache()
+    w = Workload(torch, dev, local_rank, 0, args.batch, args, 2, with_cov=(args.batch <= 131072), dtype=64)
+    steps, warm = max(2, min(args.steps, 4)), 1
+    w.flt.timing_enable(True, stride=2)
+    el = timed(torch, w.step, steps, warm, before_timing=lambda: (w.flt.timing_reset(), w.flt._keep.clear()))
+    p_ms, p_n = w.flt.timing_read(capi.KERNEL_PREDICT)
+    pn_ms, pn_n = w.flt.timing_read(capi.KERNEL_PREDICT_N)
+    c_ms, c_n = w.flt.timing_read(capi.KERNEL_CORRECT)
+    w.flt.timing_enable(False)
+    roof, corr = roofline_block(w, p_ms, p_n, c_ms, c_n, None, None)
+    roof.pop("note")
+    blk = {"value": w.B * STEPS_PER_BENCH_STEP * steps / el, "unit": "EKF steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+           "dtype": "f64", "batch": w.B, "records_MB": w.B * 1600 / 1e6, "roofline": roof, "correct_kernel": corr,
+           "note": "per-call API, fp64 kernels (the verification path: same device functions instantiated for double, 1600-byte records)"}
+    w.flt.close()
+    return blk
+
+
+def pixels_leg(torch, dev, local_rank, args, capi, B=65536, SLOTS=16):
+    """BASELINE config 5's literal shape -- 16 marker slots x 4 corners x 2 rows = 128 stacked reprojection rows per filter through
+    the flat port (fbus_ekf_correct_pixels_dev, left camera) -- is the one COMPUTE-bound row of SURVEY.md 8(d): ~550 VALU
+    instructions per projected corner against 2.7 kB of traffic per filter.  Reported: launch time (HIP events), rows/s, and the
+    VALU issue fraction = wave-level VALU instructions of one launch (SQ_INSTS_VALU of the committed rocprofv3 pass,
+    profiles/r03_pixels_sq.json) / (launch time x 1024 SIMDs x clock / 4 cycles per wave64 instruction).
+    Inputs: a wall of 16 markers 1.2-1.8 m in front of the camera; the measured image points are pin-hole projections of the true
+    corners + noise (the kernel's work -- the refractive projection of the PREDICTED corners and its Jacobian -- does not depend
+    on the measured values)."""
+    from fbus_ekf import BatchedFilter, synth
+    torch.cuda.empty_cache()
+    prm = capi.default_params(capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP)
+    size = 0.15
+    prm.marker_size = size
+    nom, rot, ids, left = synth.pixel_wall_scene(B, SLOTS, prm, size, seed=9)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_ids, d_left = torch.from_numpy(ids).to(dev), f32(left)
+    nvis = float((ids >= 0).sum(axis=1).mean())
+    with BatchedFilter(B, prm, device=local_rank, order_streams=False) as flt:
+        reps = 12
+        torch.cuda.synchronize()
+        prev0 = np.zeros(B, np.int32)
+        for k in range(reps + 2):
+            if k == 2:
+                flt.sync(); flt.timing_enable(True); flt.timing_reset()
+            flt.set_state(nom, rot, None, prev0)          # every launch from the same prior (state and covariance)
+            flt.reset_cov()
+            flt.correct_pixels(d_ids, d_left, None)
+        ms, n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
+        flt.timing_enable(False)
+        applied = float(flt.applied().mean())
+    us = ms / n * 1e3
+    rows = nvis * 8
+    blk = {"kernel": "correct_pixels_kernel<float,18> (left camera)", "bound": "valu", "batch": B, "marker_slots": SLOTS,
+           "markers_in_view_mean": nvis, "rows_per_filter_mean": rows, "avg_launch_us": us, "launches": n,
+           "reprojection_rows_per_s": rows * B / (us * 1e-6), "filters_updated_frac": applied,
+           "valu_insts_per_launch": None, "valu_issue_frac": None, "clock_MHz": None, "source": None}
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r03_pixels_sq.json")))
+        insts, mhz = float(prof["SQ_INSTS_VALU_per_launch"]), float(prof.get("clock_MHz", 2400.0))
+        if int(prof.get("batch", 0)) == B and int(prof.get("marker_slots", 0)) == SLOTS:
+            blk.update({"valu_insts_per_launch": insts, "clock_MHz": mhz, "source": "profiles/r03_pixels_sq.json",
+                        "valu_issue_frac": insts / (us * 1e-6 * 1024 * mhz * 1e6 / 4.0),
+                        "sq_active_inst_valu_over_wave_cycles": prof.get("SQ_ACTIVE_INST_VALU_over_SQ_WAVE_CYCLES")})
+    except Exception:
+        pass
+    return blk
 
 
 def main():
@@ -399,7 +495,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    w = Workload(torch, dev, local_rank, lo, hi, args, POOL, with_cov=(hi - lo) <= 131072)
+    if args.only_pixels:
+        print(json.dumps({"compute_bound": pixels_leg(torch, dev, local_rank, args, capi)}), flush=True)
+        return
+    w = Workload(torch, dev, local_rank, lo, hi, args, POOL if args.tile == 1 else 2, with_cov=(hi - lo) <= 131072 and args.tile == 1,
+                 tile=args.tile)
     flt = w.flt
     frames_timed = args.steps * len(PATTERN) * PATTERNS_PER_STEP
     # HIP-event brackets on every stride-th camera frame (a pair costs ~8 us of stream time: <= 1.5 % of the timed region)
@@ -462,11 +562,14 @@ def main():
         traffic, traffic_src = pmc_traffic(w.B, args, world)
         roof, corr = roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src)
         out = {
-            "metric": "EKF steps/s (ImuUpdate+MeasureUpdate), batch=65536, 4 markers",
+            "metric": f"EKF steps/s (ImuUpdate+MeasureUpdate), batch={total_filters if strong else w.B}, {w.M} markers",
             "value": value, "unit": "EKF steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "f32 is the arithmetic BASELINE.json's north_star quotes the metric on; the reference itself computes in "
+                          "double (common.hpp:205-247, filter.cpp:533-741) -- the same workload through the fp64 kernels is the "
+                          "`fp64` block of this line",
             "config": {"workload": (f"{args.total_batch} filters in total, sharded over {world} GPU(s) "
                                     f"({w.B} on rank 0)" if strong else f"batch {w.B} filters/GPU") +
                                    f", 200 Hz IMU + 30 Hz stereo (7/7/6 predicts per correct, 1 s of sensor time per bench step), "
@@ -494,33 +597,45 @@ def main():
     flt.close()
     del w
 
-    # ---- HBM-resident roofline leg: the same bench at 262 144 filters on this GPU (rank 0, N = 1 only) ----
+    # ---- roofline legs at other batch sizes on this GPU (rank 0, N = 1 only) ----
+    def batch_leg(batch, pool, tile, steps2, note, pmc_batch=None):
+        torch.cuda.empty_cache()
+        w2 = Workload(torch, dev, local_rank, 0, batch, args, pool, with_cov=False, tile=tile)
+        warm2 = 1
+        w2.flt.timing_enable(True, stride=2)
+        el2 = timed(torch, w2.step, steps2, warm2, before_timing=lambda: (w2.flt.timing_reset(), w2.flt._keep.clear()))
+        p_ms, p_n = w2.flt.timing_read(capi.KERNEL_PREDICT)
+        c_ms, c_n = w2.flt.timing_read(capi.KERNEL_CORRECT)
+        w2.flt.timing_enable(False)
+        w2.reset_state()
+        elf = timed(torch, lambda i: w2.step(i, fused=True), steps2, warm2, before_timing=lambda: w2.flt._keep.clear())
+        tr2, src2 = pmc_traffic(batch, args, 1)
+        roof2, corr2 = roofline_block(w2, p_ms, p_n, c_ms, c_n, tr2, src2)
+        roof2.pop("note")
+        roof2.update({"batch": batch, "records_MB": batch * 800 / 1e6, "input_patterns": pool, "steps": steps2,
+                      "value": batch * STEPS_PER_BENCH_STEP * steps2 / el2, "unit_value": "EKF steps/s",
+                      "correct_kernel": corr2,
+                      "fused_frame_value": batch * STEPS_PER_BENCH_STEP * steps2 / elf, "note": note})
+        w2.flt.close()
+        del w2
+        return roof2
+
     if rank == 0:
-        out["roofline_hbm_resident"] = None
-        if world == 1 and not args.no_hbm_leg and not strong and args.batch < HBM_LEG_BATCH:
-            torch.cuda.empty_cache()
-            w2 = Workload(torch, dev, local_rank, 0, HBM_LEG_BATCH, args, 1, with_cov=False)
-            steps2, warm2 = max(2, min(args.steps, 6)), 1
-            w2.flt.timing_enable(True, stride=2)
-            el2 = timed(torch, w2.step, steps2, warm2, before_timing=lambda: (w2.flt.timing_reset(), w2.flt._keep.clear()))
-            p_ms, p_n = w2.flt.timing_read(capi.KERNEL_PREDICT)
-            c_ms, c_n = w2.flt.timing_read(capi.KERNEL_CORRECT)
-            w2.flt.timing_enable(False)
-            w2.reset_state()
-            elf = timed(torch, lambda i: w2.step(i, fused=True), steps2, warm2, before_timing=lambda: w2.flt._keep.clear())
-            tr2, src2 = pmc_traffic(HBM_LEG_BATCH, args, 1)
-            roof2, corr2 = roofline_block(w2, p_ms, p_n, c_ms, c_n, tr2, src2)
-            roof2.pop("note")
-            roof2.update({"batch": HBM_LEG_BATCH, "records_MB": HBM_LEG_BATCH * 800 / 1e6, "steps": steps2,
-                          "value": HBM_LEG_BATCH * STEPS_PER_BENCH_STEP * steps2 / el2, "unit_value": "EKF steps/s",
-                          "correct_kernel": corr2,
-                          "fused_frame_value": HBM_LEG_BATCH * STEPS_PER_BENCH_STEP * steps2 / elf,
-                          "note": "same bench pattern at 262 144 filters on one GPU: 210 MB of records + the per-step inputs "
-                                  "exceed what stays resident in the 256 MB Infinity Cache between launches, so this is the "
-                                  "HBM streaming rate (the guide's float4-copy ceiling is 6.29 TB/s = 0.79 of the 8 TB/s spec)"})
-            out["roofline_hbm_resident"] = roof2
-            w2.flt.close()
-            del w2
+        out["roofline_hbm_resident"] = out["roofline_b262144"] = out["fp64"] = out["compute_bound"] = None
+        if world == 1 and not args.no_hbm_leg and not strong and args.batch < MID_LEG_BATCH:
+            out["roofline_hbm_resident"] = batch_leg(
+                HBM_LEG_BATCH, 2, 16, max(2, min(args.steps, 3)),
+                "same bench pattern at 1 048 576 filters on one GPU: 839 MB of records (three times the 256 MiB Infinity Cache) + "
+                "two input patterns of 168 MB each -- nothing survives in the cache from one launch to the next, so this is the "
+                "HBM streaming rate.  `frac` is against the 8 TB/s spec, `frac_of_copy_ceiling` against the 6.29 TB/s a float4 "
+                "copy reaches on this part (MI355X_MICROARCH.md)")
+            out["roofline_b262144"] = batch_leg(
+                MID_LEG_BATCH, 1, 1, max(2, min(args.steps, 4)),
+                "262 144 filters: 210 MB of records -- PARTLY CACHE-RESIDENT (they fit the 268 MB Infinity Cache; round 2 reported "
+                "this leg as the HBM figure): kept for continuity, the HBM claim is roofline_hbm_resident")
+        if world == 1 and not args.no_extra_legs and not strong:
+            out["fp64"] = fp64_leg(torch, dev, local_rank, args, capi)
+            out["compute_bound"] = pixels_leg(torch, dev, local_rank, args, capi)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

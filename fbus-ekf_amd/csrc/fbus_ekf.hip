@@ -105,6 +105,7 @@ struct fbus_ekf {
     int big_records_mb = 56;          // records larger than this run the predict with default-policy loads and stores (FBUS_BIG_RECORDS_MB)
     bool warm_after_correct = false;  // experiment knob FBUS_WARM_AFTER_CORRECT=1: the first predict behind a correct takes the "warm" load policy
     int predict_ld = 0;               // record-load policy of the per-call predict: 0 auto (see launch_predict_t), 1 always nt, 2 always default
+    int predict_policy_force = -1;    // FBUS_PREDICT_POLICY=0|1|2 (sweeps): nt / nt, default loads + nt stores, default / default
     int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
     // team kernels (several waves per 64-filter tile, ekf_team.hpp): 0 = chosen per launch from the wave count, 1 = never,
     // 2..4 = always with that many roles (fbus_ekf_set_team, FBUS_TEAM_PREDICT / FBUS_TEAM_CORRECT at create)
@@ -263,10 +264,19 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
     // round) 4.91e9 -> 4.39e9; 73 728: +1 %; 81 920: +2.5 %; 98 304: +3 %; 131 072: +7 %; 163 840: +11 %; 196 608: +13 %;
     // 262 144 (210 MB): 65.4 -> 55.7 us per launch.  The non-temporal stream only pays while the whole batch is one round of
     // waves whose records stay in the Infinity Cache between launches; the threshold sits just above that batch.
+    // Round 3 sweep (profiles/logs/r03_policy_sweep.txt: fp32 N = 18 / N = 15 and fp64, 32 768 .. 1 048 576 filters, all three
+    // policies forced through the environment knobs): the crossover between nt / nt and default / default sits at 52-60 MB of
+    // records for 800-byte, 608-byte AND 1600-byte records alike (768 waves of fp64 records are on the default side, 1024 waves
+    // of N = 15 records on the nt side): a cache-capacity effect, keyed on bytes, not on the wave count.  Beyond the 256 MiB
+    // Infinity Cache the records stream from HBM and non-temporal STORES win again (524 288 filters = 419 MB: 133 -> 116 us
+    // with default loads; 1 048 576 = 839 MB: 290 -> 275 us with nt loads as well -- nothing is left to hit).
+    const size_t mall = (size_t)256 << 20;
     const bool big = h->rec_bytes > ((size_t)h->big_records_mb << 20);
     int policy = (big ? 2 : (h->records_warm ? 1 : 0));
+    if (big && h->rec_bytes > mall) policy = (h->rec_bytes > 2 * mall) ? 0 : 1;
     if (h->predict_ld == 1) policy = 0;
     if (h->predict_ld == 2) policy = big ? 2 : 1;
+    if (h->predict_policy_force >= 0) policy = h->predict_policy_force;
     h->records_warm = false;
     const int roles = team_roles_predict(h, K);
     if constexpr (sizeof(T) == 4) {
@@ -683,6 +693,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     h->Bs = (batch + 63) / 64 * 64;
     if (const char* e = std::getenv("FBUS_BIG_RECORDS_MB")) h->big_records_mb = std::atoi(e);
     if (const char* e = std::getenv("FBUS_WARM_AFTER_CORRECT")) h->warm_after_correct = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FBUS_PREDICT_POLICY")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->predict_policy_force = v; }
     if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
     if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto

@@ -168,3 +168,61 @@ def marker_frame(lo, hi, frame, M, nominal0, params, seed=BASE_SEED, noise=1e-3)
     quat = hq + noise * z[..., 3:]
     quat /= np.linalg.norm(quat, axis=-1, keepdims=True)
     return mids[slot].astype(np.int32), pos, quat
+
+
+def pixel_wall_scene(B, slots, params, size, seed=9, nbase=256, depth=(1.2, 1.8), noise=5e-4):
+    """Scene for the reprojection-row update (fbus_ekf_correct_pixels) at batch scale, without the oracle: REPLACES the marker map
+    in `params` by a 4 x 4 wall of 16 markers (ids 0..15, 0.3 m pitch, the orientation of the reference's marker 0:
+    GetMarkerMap.m) and places `nbase` camera poses 1.2-1.8 m in front of it (repeated to B filters, positions jittered by 3 mm).
+    Returns (nominal (B,19), rot (B,9), ids (B,slots) with -1 padding, left (B,slots,8)): the markers in front of the left camera
+    and PIN-HOLE projections of their corners + noise as the measured image points.  The flat-port model is applied by the kernel
+    to the PREDICTED corners; its cost does not depend on the measured values, which is all a timing leg needs (parity tests use
+    the oracle's refractive projection instead, tests/util.py::pixel_scene)."""
+    rng = np.random.default_rng(seed)
+    _, mpos, mquat = marker_table(params)
+    R0 = np.array(list(params.marker_rot[0])).reshape(3, 3)
+    q0 = mquat[0].copy()
+    params.n_markers = 16
+    wall = np.zeros((16, 3))
+    for k in range(16):
+        wall[k] = mpos[0] + R0 @ np.array([0.3 * (k % 4 - 1.5), 0.3 * (k // 4 - 1.5), 0.0])
+        params.marker_id[k] = k
+        for i in range(3):
+            params.marker_pos[k][i] = float(wall[k][i])
+        for i in range(9):
+            params.marker_rot[k][i] = float(R0.ravel()[i])
+    R_IL, P_IL, Q_IL = camera_constants(params)
+    c = np.array([[0, 0, 0], [0, size, 0], [size, size, 0], [size, 0, 0.0]])
+    world = wall[:, None, :] + (R0 @ c.T).T[None]                     # (16, 4, 3) corners in the world
+    nom = np.zeros((nbase, 19))
+    nom[:, 16] = 9.8
+    ids = np.full((nbase, slots), -1, np.int32)
+    left = np.zeros((nbase, slots, 8))
+    for b in range(nbase):
+        while True:
+            k0 = int(rng.integers(16))
+            yq = np.array([0.0, 1.0, 0.0, 0.0]) + rng.normal(0, 0.15, 4)
+            yq /= np.linalg.norm(yq)
+            yp = np.array([rng.normal(0, 0.08), rng.normal(0, 0.08), rng.uniform(*depth)])
+            q = qmul(qmul(q0, yq * np.array([1.0, -1, -1, -1])), Q_IL)     # InitPositionAndQuaternion.m:52-72
+            q /= np.linalg.norm(q)
+            R = q2R(q)
+            p = -R @ R_IL.T @ yp + wall[k0] - R @ P_IL
+            cam = np.einsum("ij,kcj->kci", R_IL @ R.T, world - p - R @ P_IL)        # (16, 4, 3)
+            vis = (cam[:, :, 2].min(axis=1) > 0.25) & ((np.linalg.norm(cam[:, :, :2], axis=2) / cam[:, :, 2]).max(axis=1) < 0.8)
+            if vis[k0]:
+                break
+        nom[b, 0:3], nom[b, 6:10] = p, q
+        order = [k0] + [k for k in rng.permutation(16) if k != k0 and vis[k]]
+        for m, k in enumerate(order[:slots]):
+            ids[b, m] = k
+            left[b, m] = (cam[k, :, :2] / cam[k, :, 2:3]).ravel() + rng.normal(0, noise, 8)
+    rep = (B + nbase - 1) // nbase
+    nom = np.tile(nom, (rep, 1))[:B]
+    ids = np.tile(ids, (rep, 1))[:B]
+    left = np.tile(left, (rep, 1, 1))[:B]
+    nom[:, 0:3] += rng.normal(0, 0.003, (B, 3))
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    nom = r32(nom)
+    rot = r32(q2R(nom[:, 6:10]).reshape(B, 9))
+    return nom, rot, ids, r32(left)
