@@ -544,13 +544,30 @@ def main():
     w.windows = None
 
     # ---- the single end-of-run collective: gather the packed records (timed separately) ----
+    # Through the LIBRARY: fbus_ekf_gather issues ncclAllGather (equal shards) / a grouped ncclBroadcast per rank (ragged shards)
+    # on the handle's stream with the library's own communicator -- also with one rank, so that a 1-GPU run exercises the same
+    # call.  torch.distributed only carries the 128-byte unique id.  The gloo rehearsal on a shared GPU
+    # (FBUS_BENCH_DEBUG_SHARED_GPU) cannot use RCCL (two ranks on one device) and keeps the torch path.
+    gather_via = "torch.distributed"
+    sizes = shard.record_bytes_of_ranks(args.total_batch, world, w.bpf) if strong else None
+    if not shared and os.environ.get("FBUS_BENCH_TORCH_GATHER") != "1":
+        try:
+            shard.native_comm_init(flt, rank, world, dist, ctl_dev)
+            gather_via = "fbus_ekf_gather (RCCL inside the library)"
+        except Exception as e:                       # no RCCL on this box: say so, fall back
+            sys.stderr.write(f"bench.py: native RCCL communicator unavailable ({e}); gathering through torch.distributed\n")
     torch.cuda.synchronize()
     barrier()
     tg = time.perf_counter()
-    gathered = shard.gather_records(w.rec.cpu() if ctl_dev == "cpu" else w.rec, dist, world) if not strong else \
-        shard.gather_records_ragged(w.rec.cpu() if ctl_dev == "cpu" else w.rec, dist, world, ctl_dev)
+    if gather_via.startswith("fbus_ekf_gather"):
+        gathered = shard.gather_records_native(flt, w.rec, sizes, world)
+    else:
+        gathered = shard.gather_records(w.rec.cpu() if ctl_dev == "cpu" else w.rec, dist, world) if not strong else \
+            shard.gather_records_ragged(w.rec.cpu() if ctl_dev == "cpu" else w.rec, dist, world, ctl_dev)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - tg) * 1e3
+    if gather_via.startswith("fbus_ekf_gather"):
+        assert torch.equal(gathered[rank], w.rec), "gathered records differ from this rank's own"
     nomf, _, Pf, _ = flt.get_state()
     finite = bool(np.isfinite(nomf).all() and np.isfinite(Pf).all())
     finite = shard.max_over_ranks(0.0 if finite else 1.0, dist, world, ctl_dev) == 0.0
@@ -591,7 +608,7 @@ def main():
                              "note": "same steps, one launch per bench step (fbus_ekf_frames_fused_dev: 30 camera frames = 200 "
                                      "predicts + 30 corrects with the records resident in registers from the first load to the "
                                      "last store) -- the offline-replay form; beside, never instead of, the per-call number"},
-            "gather_ms": gather_ms, "gathered_bytes": int(sum(g.numel() for g in gathered)),
+            "gather_ms": gather_ms, "gathered_bytes": int(sum(g.numel() for g in gathered)), "gather_via": gather_via,
             "state_finite": finite,
         }
     flt.close()

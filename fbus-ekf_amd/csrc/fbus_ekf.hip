@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -107,6 +109,10 @@ struct fbus_ekf {
     int predict_ld = 0;               // record-load policy of the per-call predict: 0 auto (see launch_predict_t), 1 always nt, 2 always default
     int predict_policy_force = -1;    // FBUS_PREDICT_POLICY=0|1|2 (sweeps): nt / nt, default loads + nt stores, default / default
     int B = 0, Bs = 0, device = 0, dtype = 32, N = 18;
+    // RCCL communicator of the multi-GPU gather (fbus_ekf_comm_*): one rank per handle
+    void* comm = nullptr;
+    bool own_comm = false;
+    int comm_rank = 0, comm_world = 1;
     // team kernels (several waves per 64-filter tile, ekf_team.hpp): 0 = chosen per launch from the wave count, 1 = never,
     // 2..4 = always with that many roles (fbus_ekf_set_team, FBUS_TEAM_PREDICT / FBUS_TEAM_CORRECT at create)
     int team_predict = 0, team_correct = 0;
@@ -746,6 +752,7 @@ int fbus_ekf_destroy(fbus_ekf_t h)
     if (h->d_mk) (void)hipFree(h->d_mk);
     if (h->d_id2slot) (void)hipFree(h->d_id2slot);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
+    (void)fbus_ekf_comm_destroy(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return FBUS_OK;
@@ -857,6 +864,134 @@ int fbus_ekf_reset_cov(fbus_ekf_t h)
     DeviceGuard guard_(h);
     if (!h) return FBUS_ERR_INVALID;
     return do_reset_cov(h);
+}
+
+// ---------------------------------------------------------------------------------
+// multi-GPU: the one collective of the path, a gather of the packed records over RCCL
+// ---------------------------------------------------------------------------------
+// RCCL is bound at first use (dlopen by soname): a process that already holds an RCCL -- PyTorch-ROCm loads its own copy of
+// librccl.so.1 -- shares it, and the library still loads on a box without RCCL (the single-GPU path never touches it).
+namespace {
+struct Rccl {
+    using UniqueId = struct { char internal[128]; };
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool ok = false;
+};
+Rccl& rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        void* lib = nullptr;
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) { x.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return x; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p && x.err.empty()) x.err = std::string("RCCL symbol missing: ") + n; return p; };
+        x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
+        x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
+        x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+        x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
+        x.Broadcast = (decltype(x.Broadcast))sym("ncclBroadcast");
+        x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
+        x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
+        x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+        x.ok = x.err.empty();
+        return x;
+    }();
+    return r;
+}
+constexpr int kNcclUint8 = 1;       // ncclDataType_t (rccl.h): ncclInt8 = 0, ncclUint8 = 1
+int rccl_fail(fbus_ekf_t h, const char* what, int rc)
+{
+    Rccl& r = rccl();
+    return fail(h, FBUS_ERR_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error"));
+}
+}  // namespace
+
+int fbus_ekf_comm_unique_id(void* id128)
+{
+    if (!id128) return FBUS_ERR_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) return FBUS_ERR_UNSUPPORTED;
+    Rccl::UniqueId id;
+    if (r.GetUniqueId(&id) != 0) return FBUS_ERR_HIP;
+    std::memcpy(id128, &id, sizeof(id));
+    return FBUS_OK;
+}
+
+int fbus_ekf_comm_init(fbus_ekf_t h, const void* id128, int rank, int world)
+{
+    DeviceGuard guard_(h);
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return FBUS_ERR_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) return fail(h, FBUS_ERR_UNSUPPORTED, r.err);
+    (void)fbus_ekf_comm_destroy(h);
+    Rccl::UniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    void* comm = nullptr;
+    const int rc = r.CommInitRank(&comm, world, id, rank);         // binds to the current device = the handle's
+    if (rc != 0) return rccl_fail(h, "ncclCommInitRank", rc);
+    h->comm = comm; h->own_comm = true; h->comm_rank = rank; h->comm_world = world;
+    return FBUS_OK;
+}
+
+int fbus_ekf_comm_attach(fbus_ekf_t h, void* nccl_comm, int rank, int world)
+{
+    if (!h || !nccl_comm || world < 1 || rank < 0 || rank >= world) return FBUS_ERR_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) return fail(h, FBUS_ERR_UNSUPPORTED, r.err);
+    (void)fbus_ekf_comm_destroy(h);
+    h->comm = nccl_comm; h->own_comm = false; h->comm_rank = rank; h->comm_world = world;
+    return FBUS_OK;
+}
+
+int fbus_ekf_comm_destroy(fbus_ekf_t h)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    if (h->comm && h->own_comm) {
+        DeviceGuard guard_(h);
+        (void)hipStreamSynchronize(h->stream);
+        (void)rccl().CommDestroy(h->comm);
+    }
+    h->comm = nullptr; h->own_comm = false; h->comm_rank = 0; h->comm_world = 1;
+    return FBUS_OK;
+}
+
+int fbus_ekf_gather(fbus_ekf_t h, void* out_dev, const size_t* bytes_of_rank)
+{
+    DeviceGuard guard_(h);
+    if (!h || !out_dev) return FBUS_ERR_INVALID;
+    if (!h->comm) return fail(h, FBUS_ERR_INVALID, "fbus_ekf_gather: no communicator (fbus_ekf_comm_init / fbus_ekf_comm_attach first)");
+    Rccl& r = rccl();
+    const int W = h->comm_world;
+    bool equal = true;
+    if (bytes_of_rank) {
+        if (bytes_of_rank[h->comm_rank] != h->rec_bytes) return fail(h, FBUS_ERR_INVALID, "fbus_ekf_gather: bytes_of_rank[rank] is not this handle's record size");
+        for (int k = 0; k < W; ++k) equal = equal && bytes_of_rank[k] == h->rec_bytes;
+    }
+    if (equal) {
+        // equal shards (weak scaling, or a total that divides evenly): one all-gather of the packed records
+        const int rc = r.AllGather(h->recs, out_dev, h->rec_bytes, kNcclUint8, h->comm, h->stream);
+        if (rc != 0) return rccl_fail(h, "ncclAllGather", rc);
+        return FBUS_OK;
+    }
+    // ragged shards (a total batch cut into 64-aligned ranges): one grouped broadcast per rank = an all-gather-v, no padding
+    int rc = r.GroupStart();
+    size_t off = 0;
+    for (int k = 0; k < W && rc == 0; ++k) {
+        rc = r.Broadcast(h->recs, (char*)out_dev + off, bytes_of_rank[k], kNcclUint8, k, h->comm, h->stream);
+        off += bytes_of_rank[k];
+    }
+    const int rc2 = r.GroupEnd();
+    if (rc != 0 || rc2 != 0) return rccl_fail(h, "ncclBroadcast (grouped)", rc != 0 ? rc : rc2);
+    return FBUS_OK;
 }
 
 int fbus_ekf_records(fbus_ekf_t h, void** dev_ptr, size_t* bytes_per_filter, size_t* total_bytes)

@@ -99,6 +99,11 @@ def load_library():
         "fbus_ekf_reset_cov": ([H], C.c_int),
         "fbus_ekf_records": ([H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], C.c_int),
         "fbus_ekf_attach_records": ([H, vp, C.c_size_t], C.c_int),
+        "fbus_ekf_comm_unique_id": ([vp], C.c_int),
+        "fbus_ekf_comm_init": ([H, vp, C.c_int, C.c_int], C.c_int),
+        "fbus_ekf_comm_attach": ([H, vp, C.c_int, C.c_int], C.c_int),
+        "fbus_ekf_comm_destroy": ([H], C.c_int),
+        "fbus_ekf_gather": ([H, vp, C.POINTER(C.c_size_t)], C.c_int),
         "fbus_ekf_predict": ([H, vp, vp, vp, C.c_int], C.c_int),
         "fbus_ekf_predict_dev": ([H, vp, vp, vp, C.c_int], C.c_int),
         "fbus_ekf_predict_n": ([H, C.c_int, vp, vp, vp, C.c_int], C.c_int),

@@ -181,6 +181,29 @@ class BatchedFilter:
         self._check(self._lib.fbus_ekf_attach_records(self._h, self._p(dev_array), nbytes), "attach_records")
         self._records_owner = dev_array
 
+    # ---- multi-GPU: the one collective (RCCL inside the library) -------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte ncclUniqueId (bytes): rank 0 creates it, every rank passes it to comm_init"""
+        lib = capi.load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.fbus_ekf_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise capi.FbusError(rc, "comm_unique_id", lib.fbus_status_string(rc).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.fbus_ekf_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)), "comm_init")
+
+    def gather(self, out, bytes_of_rank=None):
+        """all ranks' packed records into the device array `out` (uint8, sum of the ranks' record bytes) on every rank"""
+        arr = None
+        if bytes_of_rank is not None:
+            arr = (C.c_size_t * len(bytes_of_rank))(*[int(x) for x in bytes_of_rank])
+        self._keep.append(out)
+        self._check(self._lib.fbus_ekf_gather(self._h, self._p(out), arr), "gather")
+
     # ---- predict == ImuUpdate -----------------------------------------------------
     def predict(self, accel, gyro, dt):
         return self.predict_n(accel, gyro, dt, K=1)

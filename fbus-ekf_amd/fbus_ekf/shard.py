@@ -68,3 +68,43 @@ def max_over_ranks(value, dist=None, world=1, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def record_bytes_of_ranks(total, world, bytes_per_filter):
+    """bytes of packed records each rank holds when `total` filters are cut with shard_range: whole 64-filter tiles"""
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        out.append((hi - lo + TILE - 1) // TILE * TILE * bytes_per_filter)
+    return out
+
+
+def native_comm_init(flt, rank, world, dist=None, device="cpu"):
+    """Creates the library's own RCCL communicator for the BatchedFilter `flt` (fbus_ekf_comm_init): rank 0 draws the
+    128-byte unique id, the others receive it over the control process group (a broadcast of 128 bytes -- the id is the only thing
+    that ever travels outside the library's own collective)."""
+    import torch
+    if rank == 0:
+        raw = flt.comm_unique_id()
+    else:
+        raw = bytes(128)
+    if dist is not None and world > 1:
+        t = torch.tensor(list(raw), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+    flt.comm_init(raw, rank, world)
+
+
+def gather_records_native(flt, local, bytes_of_rank=None, world=1):
+    """the end-of-run gather through the LIBRARY (fbus_ekf_gather: RCCL on the handle's stream): returns the per-rank views of one
+    device tensor holding every rank's records"""
+    import torch
+    sizes = list(bytes_of_rank) if bytes_of_rank is not None else [local.numel()] * world
+    out = torch.empty(sum(sizes), dtype=torch.uint8, device=local.device)
+    flt.gather(out, None if bytes_of_rank is None else sizes)
+    flt.sync()
+    views, off = [], 0
+    for n in sizes:
+        views.append(out[off:off + n])
+        off += n
+    return views

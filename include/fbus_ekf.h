@@ -162,6 +162,22 @@ int fbus_ekf_reset_cov(fbus_ekf_t h);
 /* The packed device-resident records (what a multi-GPU gather ships): base
  * pointer, bytes per filter and total bytes.  Layout: DESIGN.md section 3. */
 int fbus_ekf_records(fbus_ekf_t h, void** dev_ptr, size_t* bytes_per_filter, size_t* total_bytes);
+/* ---- multi-GPU: one process (rank) per GPU, one handle per rank, ONE collective -------------------------------
+ * No reference counterpart: the reference runs one filter on one CPU thread (filter.cpp:190-250).  Filters are independent, so
+ * the ranks step their shards with no communication; the single exchange of the path is the gather of the packed records at the
+ * end, over RCCL (xGMI inside a node).  RCCL is bound at first use (dlopen of librccl.so.1); the single-GPU path never needs it.
+ *   comm_unique_id  rank 0 creates the 128-byte ncclUniqueId and hands it to the other ranks (any out-of-band channel);
+ *   comm_init       every rank: ncclCommInitRank on the handle's device;
+ *   comm_attach     alternatively adopt an existing ncclComm_t of the caller's (not destroyed by the library);
+ *   gather          every rank's records into out_dev on every rank, on the handle's stream (asynchronous until
+ *                   fbus_ekf_sync).  bytes_of_rank = NULL: all ranks hold the same number of bytes (ncclAllGather, rank k at
+ *                   offset k * bytes); otherwise world entries (entry [rank] = this handle's fbus_ekf_records total): ragged
+ *                   shards, rank k at the running offset (grouped ncclBroadcast). */
+int fbus_ekf_comm_unique_id(void* id128);
+int fbus_ekf_comm_init(fbus_ekf_t h, const void* id128, int rank, int world);
+int fbus_ekf_comm_attach(fbus_ekf_t h, void* nccl_comm, int rank, int world);
+int fbus_ekf_comm_destroy(fbus_ekf_t h);
+int fbus_ekf_gather(fbus_ekf_t h, void* out_dev, const size_t* bytes_of_rank);
 /* Point the handle at caller-owned device storage of total_bytes (as reported
  * by fbus_ekf_records) so that a framework tensor can alias the records. */
 int fbus_ekf_attach_records(fbus_ekf_t h, void* dev_ptr, size_t total_bytes);

@@ -90,7 +90,7 @@ def test_ragged_gather_over_gloo():
 
 
 def _run_bench(extra, env):
-    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-leg"] + extra,
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-leg", "--no-extra-legs"] + extra,
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{") and "\"metric\"" in l]
@@ -107,6 +107,8 @@ def test_two_rank_rehearsal_weak_and_strong_scaling():
     assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["config"]["ranks_seen"] == 1
     assert one["state_finite"] and one["roofline"]["frac"] > 0 and one["roofline"]["launches"] > 0
     assert one["roofline"]["bytes_moved_per_launch"] == 1436 * 4096
+    # the metric names the run's own batch; the gather of a single rank already goes through the library's RCCL entry point
+    assert "batch=4096" in one["metric"] and one["gather_via"].startswith("fbus_ekf_gather") and one["gathered_bytes"] == 4096 * 800
     weak = _run_bench(["--gpus", "2", "--batch", "4096"], env)
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["ranks_seen"] == 2
     assert weak["config"]["total_filters"] == 8192 and weak["config"]["batch_per_gpu"] == 4096
@@ -127,3 +129,78 @@ def test_single_rank_through_rccl_itself():
     out = _run_bench(["--batch", "4096"], _env(FBUS_BENCH_FORCE_RCCL="1", MASTER_PORT="29547"))
     assert out["n_gpus"] == 1 and out["config"]["collective_backend"] == "nccl" and out["config"]["ranks_seen"] == 1
     assert out["gathered_bytes"] == 4096 * 800 and out["state_finite"] and out["gather_ms"] > 0
+    assert out["gather_via"].startswith("fbus_ekf_gather")          # the records travel through the library's own communicator
+
+
+@pytest.mark.gpu
+def test_native_gather_entry_point_single_rank():
+    """fbus_ekf_comm_unique_id / comm_init / gather with one rank (what a 1-GPU box can run of the N > 1 path): the equal-shard
+    form (ncclAllGather) and the ragged form (grouped ncclBroadcast) both return this rank's records bit for bit; a wrong
+    bytes_of_rank entry and a gather without a communicator are refused"""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
+    from fbus_ekf import BatchedFilter, capi, synth
+    B = 1000                                           # ragged: 15.6 tiles -> records are 16 tiles long
+    prm = capi.default_params(0)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18)
+    with BatchedFilter(B, prm) as flt:
+        flt.set_state(nom, rot, P, prev)
+        ptr, bpf, total = flt.records()
+        assert total == 1024 * bpf
+        rec = torch.empty(total, dtype=torch.uint8, device="cuda:0")
+        flt.attach_records(rec)
+        out = torch.zeros(total, dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(capi.FbusError):
+            flt.gather(out)                            # no communicator yet
+        flt.comm_init(BatchedFilter.comm_unique_id(), 0, 1)
+        flt.gather(out); flt.sync()
+        assert torch.equal(out, rec)
+        out.zero_()
+        flt.gather(out, [total]); flt.sync()
+        assert torch.equal(out, rec)
+        with pytest.raises(capi.FbusError):
+            flt.gather(out, [total - 64])
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_filter_gathers_through_the_library(tmp_path):
+    """include/fbus/sharded_filter.hpp (what INTEGRATION.md's 8-GPU driver is written against), compiled with plain g++ and run
+    as ONE rank on this box: the shard arithmetic, the communicator from a unique id, a predict on the shard and the gather --
+    the gathered bytes must be this rank's records (hipMemcpy'd back through the C ABI's device pointer)."""
+    libdir = os.path.join(ROOT, "fbus-ekf_amd", "lib")
+    src = tmp_path / "sharded.cpp"
+    src.write_text(r'''
+#include <fbus/sharded_filter.hpp>
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+int main() {
+    using SF = fbus::ShardedFilter<float>;
+    long lo, hi, covered = 0;
+    for (int r = 0; r < 8; ++r) { SF::shard_range(262144, r, 8, lo, hi); if (hi - lo != 32768 || lo % 64) return 2; covered += hi - lo; }
+    if (covered != 262144) return 3;
+    SF::shard_range(200, 2, 3, lo, hi); if (lo != 128 || hi != 200) return 4;
+    const long total = 1000;
+    SF f(total, 0, 1, SF::unique_id(), fbus::BatchedFilter<float>::defaults(FBUS_DIALECT_MATLAB), 0);
+    if (f.lo() != 0 || f.hi() != total || f.gathered_bytes() != 1024u * 800u || f.offset_of(0) != 0) return 5;
+    f.filter().reset_covariance();
+    std::vector<float> a(total * 3, 0.1f), w(total * 3, 0.01f);
+    f.filter().predict(a.data(), w.data(), 0.005f);
+    void *out = nullptr, *recs = nullptr; size_t tot = 0;
+    if (hipMalloc(&out, f.gathered_bytes()) != hipSuccess) return 6;
+    f.gather(out); f.filter().sync();
+    fbus_ekf_records(f.filter().handle(), &recs, nullptr, &tot);
+    std::vector<char> g(tot), mine(tot);
+    hipMemcpy(g.data(), out, tot, hipMemcpyDeviceToHost); hipMemcpy(mine.data(), recs, tot, hipMemcpyDeviceToHost);
+    std::printf("gathered %zu bytes equal %d\n", tot, int(std::memcmp(g.data(), mine.data(), tot) == 0));
+    return std::memcmp(g.data(), mine.data(), tot) == 0 ? 0 : 7;
+}
+''')
+    exe = tmp_path / "sharded"
+    subprocess.run(["g++", "-std=c++14", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    str(src), "-o", str(exe), "-L", libdir, "-lfbus_ekf", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "gathered 819200 bytes equal 1" in r.stdout
