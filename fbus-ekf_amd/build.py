@@ -112,6 +112,29 @@ def build(force=False, verbose=False, only=None, jobs=None):
     return OUT
 
 
+def build_host_asan(out=None):
+    """The library with the HOST half of fbus_ekf.hip (handle, argument checks, staging, parameter tables, RCCL binding) under
+    AddressSanitizer + UBSan: `-fsanitize=address,undefined -fno-gpu-sanitize` instruments host code only, the device code
+    objects are the normal ones (GPU ASan is not available on this pool).  Linked against the already built kernel objects.
+    Load it with LD_PRELOAD of clang's ASan runtime (tests/test_sanitizers_cpu.py)."""
+    build()
+    out = out or os.path.join(os.path.dirname(OUT), "libfbus_ekf_asan.so")
+    obj = os.path.join(OBJDIR, "main_asan.o")
+    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan"]
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fno-slp-vectorize", "-fPIC"] + san +
+                   ["-c", os.path.join(CSRC, "fbus_ekf.hip"), "-o", obj], check=True, capture_output=True)
+    objs = [os.path.join(OBJDIR, name + ".o") for name, _, _ in units() if name != "main"]
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + san + ["-o", out, obj] + objs, check=True, capture_output=True)
+    return out
+
+
+def asan_runtime():
+    """clang's shared ASan runtime (what LD_PRELOAD needs for build_host_asan's library)"""
+    import glob
+    c = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return c[-1] if c else None
+
+
 if __name__ == "__main__":
     only = None
     jobs = None
@@ -120,4 +143,7 @@ if __name__ == "__main__":
             only = sys.argv[i + 1].split(",")
         if a == "--jobs":
             jobs = int(sys.argv[i + 1])
+    if "--host-asan" in sys.argv:
+        print(build_host_asan())
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True, only=only, jobs=jobs))

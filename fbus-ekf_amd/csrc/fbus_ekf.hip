@@ -668,6 +668,25 @@ int fbus_params_default(fbus_params* prm, int dialect)
     return FBUS_OK;
 }
 
+int fbus_params_validate(const fbus_params* prm, char* msg, size_t msg_len)
+{
+    // everything fbus_ekf_create derives from the parameters on the HOST (no device needed): the camera constants, the marker
+    // table and the id -> slot map.  Also what the CPU sanitizer build exercises (tests/test_sanitizers_cpu.py).
+    if (msg && msg_len) msg[0] = 0;
+    if (!prm) return FBUS_ERR_INVALID;
+    std::string err;
+    if (prm->dialect != FBUS_DIALECT_MATLAB && prm->dialect != FBUS_DIALECT_CPP) err = "dialect must be FBUS_DIALECT_MATLAB or FBUS_DIALECT_CPP";
+    else if (prm->cov_form != FBUS_COV_SIMPLE && prm->cov_form != FBUS_COV_JOSEPH) err = "cov_form must be FBUS_COV_SIMPLE or FBUS_COV_JOSEPH";
+    else if (!(prm->r_pos > 0) || !(prm->r_quat > 0)) err = "measurement noise must be positive";
+    else {
+        HostConst hc;
+        (void)build_host_const(*prm, hc, err);
+    }
+    if (err.empty()) return FBUS_OK;
+    if (msg && msg_len) { std::strncpy(msg, err.c_str(), msg_len - 1); msg[msg_len - 1] = 0; }
+    return FBUS_ERR_INVALID;
+}
+
 int fbus_ekf_abi_version(void) { return FBUS_ABI_VERSION; }
 size_t fbus_params_size(void) { return sizeof(fbus_params); }
 
@@ -871,6 +890,7 @@ int fbus_ekf_reset_cov(fbus_ekf_t h)
 // ---------------------------------------------------------------------------------
 // RCCL is bound at first use (dlopen by soname): a process that already holds an RCCL -- PyTorch-ROCm loads its own copy of
 // librccl.so.1 -- shares it, and the library still loads on a box without RCCL (the single-GPU path never touches it).
+extern "C++" {
 namespace {
 struct Rccl {
     using UniqueId = struct { char internal[128]; };
@@ -914,6 +934,7 @@ int rccl_fail(fbus_ekf_t h, const char* what, int rc)
     return fail(h, FBUS_ERR_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error"));
 }
 }  // namespace
+}  // extern "C++"
 
 int fbus_ekf_comm_unique_id(void* id128)
 {

@@ -80,6 +80,7 @@ def load_library():
     H = C.c_void_p
     sig = {
         "fbus_params_default": ([C.POINTER(FbusParams), C.c_int], C.c_int),
+        "fbus_params_validate": ([C.POINTER(FbusParams), C.c_char_p, C.c_size_t], C.c_int),
         "fbus_ekf_abi_version": ([], C.c_int),
         "fbus_params_size": ([], C.c_size_t),
         "fbus_ekf_create_checked": ([C.POINTER(H), C.POINTER(FbusParams), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),

@@ -94,6 +94,9 @@ typedef struct fbus_params {
 /* Fills prm with the reference's constants for the given dialect
  * (FBUS_EKF.m / paramconfig.yml / camerainfo1.yml / GetMarkerMap.m). */
 int fbus_params_default(fbus_params* prm, int dialect);
+/* Host-side check of a parameter set (no device needed): dialect / cov_form values, positive noise, marker count and ids in
+ * range.  FBUS_OK, or FBUS_ERR_INVALID with the reason in msg (may be NULL).  fbus_ekf_create applies the same checks. */
+int fbus_params_validate(const fbus_params* prm, char* msg, size_t msg_len);
 
 /* ---- ABI version ---------------------------------------------------------- */
 /* fbus_params is passed by pointer and has grown (round 2 added r_pix); fbus_ekf_set_stream(h, NULL) changed

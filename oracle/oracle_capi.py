@@ -62,7 +62,9 @@ def load(native=False):
         return _libs[key]
     name = "libfbus_oracle_native.so" if native else "libfbus_oracle.so"
     path = os.path.join(_HERE, "_build", name)
-    if not os.path.exists(path):
+    if os.environ.get("FBUS_ORACLE_LIB"):          # e.g. the -fsanitize=address,undefined build (tests/test_sanitizers_cpu.py)
+        path = os.environ["FBUS_ORACLE_LIB"]
+    elif not os.path.exists(path):
         path = build(native)
     lib = C.CDLL(path)
     dp = C.POINTER(C.c_double)
