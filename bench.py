@@ -446,6 +446,15 @@ def pixels_leg(torch, dev, local_rank, args, capi, B=65536, SLOTS=16):
     return blk
 
 
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """the one JSON line, on the process's original stdout (see main)"""
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -456,6 +465,14 @@ def main():
     if world != args.gpus:
         sys.stderr.write(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch {args.gpus} ranks or pass --gpus {world}\n")
         sys.exit(2)
+
+    # stdout carries exactly ONE line, the JSON: everything else that libraries print there (RCCL's version banner at
+    # communicator creation sits in the C stdio buffer until exit, i.e. BEHIND the JSON line) is sent to stderr for the
+    # whole run, and the JSON line is written to the original stdout at the end.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from fbus_ekf import capi, shard
@@ -496,7 +513,7 @@ def main():
             dist.barrier()
 
     if args.only_pixels:
-        print(json.dumps({"compute_bound": pixels_leg(torch, dev, local_rank, args, capi)}), flush=True)
+        emit(json.dumps({"compute_bound": pixels_leg(torch, dev, local_rank, args, capi)}))
         return
     w = Workload(torch, dev, local_rank, lo, hi, args, POOL if args.tile == 1 else 2, with_cov=(hi - lo) <= 131072 and args.tile == 1,
                  tile=args.tile)
@@ -657,7 +674,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -3,7 +3,7 @@
 #   tools/pmc_sq.sh TAG ["extra bench.py arguments"]      e.g.  tools/pmc_sq.sh b262144 "--batch 262144"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-a}
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-leg --kernel-timing off ${2:-}"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-extra-legs --kernel-timing off ${2:-}"
 export OUT=gpurun_out/pmc_sq_$TAG
 mkdir -p $OUT
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p1 -- python3 bench.py $ARGS > $OUT/p1.log 2>&1

@@ -4,9 +4,10 @@
 # gpurun_out/prof_$TAG/summary.txt + digest.json (copy those into profiles/).
 #   tools/profile_gpu.sh r02_b65536  "--batch 65536 --steps 20 --warmup 5"
 #   tools/profile_gpu.sh r02_b262144 "--batch 262144 --steps 4 --warmup 1"
+#   tools/profile_gpu.sh r03_b1048576 "--batch 1048576 --tile 16 --steps 3 --warmup 1"     (839 MB of records: past the Infinity Cache)
 TAG=${1:-r02_b65536}
 ARGS=${2:-"--batch 65536 --steps 20 --warmup 5"}
-ARGS="$ARGS --no-cpu-baseline --no-hbm-leg"
+ARGS="$ARGS --no-cpu-baseline --no-hbm-leg --no-extra-legs"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT

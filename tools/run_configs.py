@@ -69,7 +69,9 @@ def run(B, dtype, M, what, K=1, mode=1, reps=200, n=18):
     return us, steps / us * 1e6, bytes_ / us * 1e-3
 
 
-print("config  case                                             us/launch     EKF steps/s   algorithmic GB/s")
+import json
+CASES = []
+print("config  case                                             us/launch     EKF steps/s   algorithmic GB/s   frac of 8 TB/s   (HIP-event bracket per launch: +2-3 us)")
 for name, args in (
     ("2", dict(B=4096, dtype=32, M=0, what="predict")),
     ("2", dict(B=4096, dtype=32, M=0, what="predict_n", K=8)),
@@ -90,4 +92,9 @@ for name, args in (
     us, sps, gbs = run(**args)
     desc = f"B={args['B']} fp{args['dtype']} {'N=15 ' if args.get('n') == 15 else ''}{args['what']}" + (f" K={args['K']}" if "K" in args else "") + \
            (f" M={args['M']} {'stacked' if args.get('mode', 1) else 'nearest'}" if args["what"].startswith("correct") else "")
-    print(f"{name:>4}    {desc:<48} {us:9.2f}   {sps:13.4g}   {gbs:10.0f}")
+    print(f"{name:>4}    {desc:<48} {us:9.2f}   {sps:13.4g}   {gbs:10.0f}   {gbs / 8000:14.2f}", flush=True)
+    CASES.append({"config": name, "desc": desc, "us_hip_events": us, "steps_per_launch": sps * us * 1e-6, "bytes_per_launch": gbs * us * 1e3})
+# sidecar for tools/run_configs_rocprof.py (kernel-trace durations of the same launches)
+out = os.environ.get("FBUS_RUN_CONFIGS_JSON")
+if out:
+    json.dump(CASES, open(out, "w"), indent=1)
