@@ -137,11 +137,12 @@ __device__ __forceinline__ void refraction_project(const VisConst<T>& vc, const 
     const T zw = z - vc.d_air - vc.d_glass;
     T t = rho / (vc.d_air + a0 * vc.d_glass + a1 * zw);
     constexpr int NEWTON_MAX = (sizeof(T) == 4) ? 7 : 10;
-    // fp32: a lane stops after a step of <= 1e-4 t (quadratic convergence: what is left is ~1e-8 t, below fp32 rounding).  With the
-    // wave-wide exit of round 2 the bound was 3e-4, but most lanes ran one step further for the sake of their slowest
-    // neighbour; per-lane convergence at 3e-4 lost that accidental step and with it accuracy (block-wise covariance figure
-    // of the 235-row stereo case 2.0e-3 -> 2.7e-3).
-    constexpr T NEWTON_TOL = (sizeof(T) == 4) ? T(1e-4) : T(1e-8);
+    // A lane stops after a step of <= NEWTON_TOL t (quadratic convergence: what is left is its square, ~1e-7 t for the
+    // slowest lane in fp32, far less for the others).  3e-4 is round 2's bound, so a wave runs as many steps as it did then;
+    // the difference is that a lane now FREEZES once it has converged instead of following its slowest neighbour (tighter
+    // bounds were measured: 1e-4 costs correct_pixels 15 %, 2e-5 11 % on another box, for figures that only move inside
+    // their noise band -- tests/test_pixels_gpu.py).
+    constexpr T NEWTON_TOL = (sizeof(T) == 4) ? T(3e-4) : T(1e-8);
     // Convergence is decided PER LANE: a lane that has converged keeps its t while the wave runs on for its slower
     // lanes (the vote only ends the loop).  A filter's iteration count, and with it the last bits of its result, must not
     // depend on which other filters share its wave -- the batch composition and the shard layout.
