@@ -873,6 +873,130 @@ __device__ __forceinline__ void marker_info(InfoAcc<T>& acc, const T* pqr, const
     for (int k = 0; k < 4; ++k) acc.add3(Hq + 3 * k, rq[k], w_quat);
 }
 
+// --------------------------------------------------------------------------------
+// The fold of the 7 pose rows of M markers, with what the rows of ALL markers share taken out of the per-marker work
+// (round 3; the same sums as marker_info row by row, regrouped -- exact algebra, results equal to rounding):
+//   * position rows: H(1:3, p) = Hpp = -R_IL R' is the same matrix for every marker, so
+//         Lam_pp = w n Hpp' Hpp          Lam_pt = w Hpp' (sum_m Hpt_m)          b_p = w Hpp' (sum_m rp_m)
+//     and only  sum Hpt_m,  sum rp_m,  sum Hpt_m' Hpt_m  and  sum Hpt_m' rp_m  are accumulated per marker;
+//   * quaternion rows: Hq = s Rq(Qm) [Lq(Q_IL) L2] Lq(q)(:,2:4), s = +-1/2, and Rq(Q)'Rq(Q) = |Q|^2 I, Lq(Q)'Lq(Q) = |Q|^2 I,
+//     L2'L2 = I, the last three columns of Lq(q) orthogonal with norm |q|: Hq'Hq = 1/4 |Qm|^2 |Q_IL|^2 |q|^2 I_3 EXACTLY,
+//     whatever the marker and the sign -- the four quaternion rows of a marker add an isotropic c_m |q|^2 w_quat to the theta
+//     diagonal (c_m = 1/4 |Q_IL|^2 |Qm|^2 sits in the map slot's 8th entry), and in the Matlab dialect (quaternion residual
+//     zeroed, MeasureUpdate.m:88) that is ALL they do: no Q_IL (x) q* (x) Qm, no sign test, no 4 x 3 Jacobian per marker.
+//     The C++ dialect still needs the residual: b_theta += w s M1' (Rq(Qm)' rq).
+// Per marker ~75 (Matlab) / ~135 (C++) instructions instead of ~275.
+// --------------------------------------------------------------------------------
+template <typename T, int N, int DIALECT>
+struct PoseFold {
+    T sH[9], sr[3], Ltt[6], bt[3], csum, cnt, btq[3];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sH[i] = T(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ltt[i] = T(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { sr[i] = T(0); bt[i] = T(0); btq[i] = T(0); }
+        csum = T(0); cnt = T(0);
+    }
+    static constexpr int NVAL = 26;                       // for exchanges: sH 9, sr 3, Ltt 6, bt 3, csum, cnt, btq 3
+    __device__ __forceinline__ T& at(int k)
+    {
+        return k < 9 ? sH[k] : (k < 12 ? sr[k - 9] : (k < 18 ? Ltt[k - 12] : (k < 21 ? bt[k - 18] : (k == 21 ? csum : (k == 22 ? cnt : btq[k - 23])))));
+    }
+    // one marker (map slot constants mk: position 3, quaternion 4, c_m), measured pose yp, yq
+    __device__ __forceinline__ void add(const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc, const T* __restrict__ mk,
+                                        const T* yp, const T* yq)
+    {
+        using L = Lay<N>;
+        const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
+        // hp = R_IL R' (Pm - p - R P_IL) ; H(1:3,7:9) = R_IL [R'(Pm - p)]x     MeasureUpdate.m:67,72-73 ; filter.cpp:684-685,691-692
+        T u[3], d[3], t[3], ru[3], Hpt[9], rp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { u[i] = mk[i] - p[i]; d[i] = u[i] - mc.RP[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            t[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
+            ru[i] = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
+            rp[i] = yp[i] - (l0 * t[0] + l1 * t[1] + l2 * t[2]);
+            Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
+            Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
+            Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sH[i] += Hpt[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            sr[i] += rp[i];
+            bt[i] += Hpt[i] * rp[0] + Hpt[3 + i] * rp[1] + Hpt[6 + i] * rp[2];
+        }
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) Ltt[o++] += Hpt[i] * Hpt[j] + Hpt[3 + i] * Hpt[3 + j] + Hpt[6 + i] * Hpt[6 + j];
+        csum += mk[7];
+        cnt += T(1);
+        if constexpr (DIALECT == DIALECT_CPP) {
+            // the quaternion residual is used (filter.cpp:698-706,718-721): b_theta += w s M1' (Rq(Qm)' rq)
+            const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
+            T hq[4];
+            quat_mul(mc.tq, Qm, hq);                                 // Q_IL (x) q* (x) Qm
+            T k1 = T(0), k2 = T(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { k1 += (yq[i] - hq[i]) * (yq[i] - hq[i]); k2 += (yq[i] + hq[i]) * (yq[i] + hq[i]); }
+            const T sq = (k1 > k2) ? T(-1) : T(1);
+            T rq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rq[i] = yq[i] - sq * hq[i];
+            // v = Rq(Qm)' rq   (Rq as in marker_rows: rows (w -x -y -z ; x w z -y ; y -z w x ; z y -x w))
+            const T v[4] = { Qm[0] * rq[0] + Qm[1] * rq[1] + Qm[2] * rq[2] + Qm[3] * rq[3],
+                             -Qm[1] * rq[0] + Qm[0] * rq[1] - Qm[3] * rq[2] + Qm[2] * rq[3],
+                             -Qm[2] * rq[0] + Qm[3] * rq[1] + Qm[0] * rq[2] - Qm[1] * rq[3],
+                             -Qm[3] * rq[0] - Qm[2] * rq[1] + Qm[1] * rq[2] + Qm[0] * rq[3] };
+            const T sg = T(0.5) * sq;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                btq[j] += sg * (mc.M1[j] * v[0] + mc.M1[3 + j] * v[1] + mc.M1[6 + j] * v[2] + mc.M1[9 + j] * v[3]);
+        }
+    }
+    // -> the 6 x 6 information matrix and vector of the stacked rows (what marker_info accumulates row by row)
+    __device__ __forceinline__ void finish(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc) const
+    {
+        using L = Lay<N>;
+        const T* q = pqr + L::OFF_Q;
+        const T wp = T(1) / dc.r_pos, wq = T(1) / dc.r_quat;
+        const T (&H)[9] = mc.Hpp;
+        const T wn = wp * cnt;
+        // Lam_pp = w n Hpp' Hpp
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) acc.Lam[lidx(i, j)] = wn * (H[i] * H[j] + H[3 + i] * H[3 + j] + H[6 + i] * H[6 + j]);
+        // Lam_pt = w Hpp' sum Hpt ;  b_p = w Hpp' sum rp
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc.Lam[lidx(i, 3 + j)] = wp * (H[i] * sH[j] + H[3 + i] * sH[3 + j] + H[6 + i] * sH[6 + j]);
+            acc.b[i] = wp * (H[i] * sr[0] + H[3 + i] * sr[1] + H[6 + i] * sr[2]);
+        }
+        // Lam_tt = w_pos sum Hpt'Hpt + w_quat |q|^2 (sum c_m) I ;  b_t = w_pos sum Hpt' rp (+ w_quat sum Hq' rq)
+        const T iso = wq * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]) * csum;
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = i; j < 3; ++j) { acc.Lam[lidx(3 + i, 3 + j)] = wp * Ltt[o] + (i == j ? iso : T(0)); ++o; }
+            acc.b[3 + i] = wp * bt[i] + (DIALECT == DIALECT_CPP ? wq * btq[i] : T(0));
+        }
+    }
+};
+
 // One equivalent scalar measurement: row = (0,..,0, 1, l[A+1..5]) in the J columns, information d, beta.
 //   s' = 1 + d h P h' ; dx += P h' (beta - d h dx) / s' ; P -= (d / s') (P h')(P h')'
 template <typename T, int N, int A, int COV, typename HOOK = NoRowHook>

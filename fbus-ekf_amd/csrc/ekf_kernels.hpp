@@ -296,7 +296,7 @@ struct MarkerGroup {
         for (int g = 0; g < G; ++g) {
             const T* m = t.mk + (slot[g] < 0 ? 0 : slot[g]) * MK_STRIDE;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) mk[g][k] = m[k];
+            for (int k = 0; k < 8; ++k) mk[g][k] = m[k];
         }
     }
 };
@@ -615,8 +615,8 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
         // all visible markers: their rows are folded into the 6x6 information matrix while the covariance is still
         // on its way in, then applied as six scalar updates (joint_update)
         InfoAcc<T> acc;
-        acc.clear();
-        const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+        PoseFold<T, N, DIALECT> fold;
+        fold.clear();
         MarkerCommon<T, N> mc;
         mc.build(nom, dc);
         auto fold_group = [&]() {
@@ -624,7 +624,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (mg.slot[g] < 0) continue;
-                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                fold.add(nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
                 ++used;
             }
         };
@@ -635,6 +635,7 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             mg.fetch(my_ids, my_pos, my_quat, i0, last, vec);
             fold_group();
         }
+        fold.finish(acc, nom, dc, mc);
         if constexpr (LEAN) {
             InfoFactors<T> fac;
             if (used > 0) joint_factor<T>(acc, fac);
@@ -700,10 +701,13 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
                 if (DIALECT == DIALECT_CPP) new_prev = min_id;                       // filter.cpp:675
                 T mk[MK_STRIDE];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
+                for (int k = 0; k < 8; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
                 MarkerCommon<T, N> mc;
                 mc.build(nom, dc);
-                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mk, min_y, min_y + 3, T(1) / dc.r_pos, T(1) / dc.r_quat);
+                PoseFold<T, N, DIALECT> fold;
+                fold.clear();
+                fold.add(nom, dc, mc, mk, min_y, min_y + 3);
+                fold.finish(acc, nom, dc, mc);
                 joint_factor<T>(acc, fac);
                 used = 1;
             }
@@ -712,13 +716,15 @@ correct_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, 
             if (DIALECT == DIALECT_CPP) new_prev = min_id;                           // filter.cpp:675
             T mk[MK_STRIDE];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
+            for (int k = 0; k < 8; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
             MarkerCommon<T, N> mc;
             mc.build(nom, dc);
             if constexpr (NEAREST_INFO) {
                 InfoAcc<T> acc;
-                acc.clear();
-                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mk, min_y, min_y + 3, T(1) / dc.r_pos, T(1) / dc.r_quat);
+                PoseFold<T, N, DIALECT> fold;
+                fold.clear();
+                fold.add(nom, dc, mc, mk, min_y, min_y + 3);
+                fold.finish(acc, nom, dc, mc);
                 if constexpr (STREAM_ST) joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_CORRECT_ST>{ rs, my_lane(), P });
                 else joint_update<T, N, COV>(P, dx, acc);
             } else {
@@ -809,10 +815,10 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     for (int i = 0; i < N; ++i) dx[i] = T(0);
     int used = 0;
     InfoAcc<T> acc;
+    PoseFold<T, N, DIALECT> fold;
     // the reference mode in the simple form goes through the information fold as well (see correct_kernel: NEAREST_INFO)
     constexpr bool joint = JOINT || COV == COV_SIMPLE;
-    const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
-    if (joint) acc.clear();
+    if (joint) fold.clear();
     MarkerCommon<T, N> mc;
     mc.build(nom, dc);
     for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
@@ -822,7 +828,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
 #pragma unroll
         for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
             if (mg.slot[g] < 0) continue;
-            if constexpr (joint) marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+            if constexpr (joint) fold.add(nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
             else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
             ++used;
         }
@@ -831,6 +837,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     bool streamed = false;
     if constexpr (joint) {
         if (used > 0) {
+            fold.finish(acc, nom, dc, mc);
             if constexpr (STREAM_ST) { joint_update<T, N, COV>(P, dx, acc, RowStore<T, N, FBUS_X_FRAME_ST>{ rs, my_lane(), P }); streamed = true; }
             else joint_update<T, N, COV>(P, dx, acc);
         }
@@ -919,9 +926,9 @@ frames_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __res
         for (int i = 0; i < N; ++i) dx[i] = T(0);
         int used = 0;
         InfoAcc<T> acc;
-        const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+        PoseFold<T, N, DIALECT> fold;
         constexpr bool INFO = JOINT || COV == COV_SIMPLE;      // reference mode, simple form: through the information fold too
-        if (INFO) acc.clear();
+        if (INFO) fold.clear();
         MarkerCommon<T, N> mc;
         mc.build(nom, dc);
         for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
@@ -931,13 +938,13 @@ frames_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __res
 #pragma unroll
             for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
                 if (mg.slot[g] < 0) continue;
-                if constexpr (INFO) marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                if constexpr (INFO) fold.add(nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
                 else marker_update<T, N, DIALECT, COV>(P, dx, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
                 ++used;
             }
         }
         if constexpr (INFO) {
-            if (used > 0) joint_update<T, N, COV>(P, dx, acc);
+            if (used > 0) { fold.finish(acc, nom, dc, mc); joint_update<T, N, COV>(P, dx, acc); }
         }
         if (used > 0) {
             inject<T, N>(nom, dx);
@@ -1014,8 +1021,8 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
         for (int c = 0; c < Park::NCHUNK; ++c) park.put(c, P + c * EPC, EPC);
         order_fence();
         InfoAcc<T> acc;
-        acc.clear();
-        const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
+        PoseFold<T, N, DIALECT> fold;
+        fold.clear();
         MarkerCommon<T, N> mc;
         mc.build(nom, dc);
         for (int i0 = 0; i0 < last; i0 += FBUS_MARKER_GROUP) {
@@ -1025,11 +1032,11 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
 #pragma unroll
             for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
                 if (mg.slot[g] < 0) continue;
-                marker_info<T, N, DIALECT>(acc, nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g], w_pos, w_quat);
+                fold.add(nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
                 ++used;
             }
         }
-        if (used > 0) joint_factor<T>(acc, fac);
+        if (used > 0) { fold.finish(acc, nom, dc, mc); joint_factor<T>(acc, fac); }
         order_fence();
 #pragma unroll
         for (int c = 0; c < Park::NCHUNK; ++c) park.get(c, P + c * EPC, EPC);

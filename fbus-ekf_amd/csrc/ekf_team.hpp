@@ -524,7 +524,7 @@ template <int N, int NR>
 struct CorrectXch {
     static constexpr int NN = CorrectPlan<N, NR>::NN;
     static constexpr int QW = (6 * NN + 3) / 4;                 // W, a-major [a][i]: 16-byte cells
-    static constexpr int NPART = 27;                            // Lam (21) + b (6)
+    static constexpr int NPART = 26;                            // PoseFold::NVAL: the partial sums of one role's markers
     u32x4* w;                                                   // [QW][64]
     float* part;                                                // [NR][NPART][64]
     float* pjj;                                                 // [21][64]
@@ -646,9 +646,9 @@ correct_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ 
 
     // ---- fold this role's markers (only p, q, R and the map are needed: the covariance is still on its way in) ----------
     InfoAcc<T> acc;
-    acc.clear();
+    PoseFold<T, N, DIALECT> fold;
+    fold.clear();
     int used = 0, new_prev = -1;
-    const T w_pos = T(1) / dc.r_pos, w_quat = T(1) / dc.r_quat;
     MarkerCommon<T, N> mc;
     mc.build(nom, dc);
     auto fold_one = [&](int id, const T* y) {
@@ -657,8 +657,8 @@ correct_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ 
         if (slot < 0) return;
         T mk[MK_STRIDE];
 #pragma unroll
-        for (int k2 = 0; k2 < 7; ++k2) mk[k2] = tbl.mk[slot * MK_STRIDE + k2];
-        marker_info<T, N, DIALECT>(acc, nom, dc, mc, mk, y, y + 3, w_pos, w_quat);
+        for (int k2 = 0; k2 < 8; ++k2) mk[k2] = tbl.mk[slot * MK_STRIDE + k2];
+        fold.add(nom, dc, mc, mk, y, y + 3);
         ++used;
     };
     if (JOINT) {
@@ -682,12 +682,10 @@ correct_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ 
         if (used > 0 && DIALECT == DIALECT_CPP) new_prev = min_id;   // filter.cpp:675
     }
 
-    // ---- exchange 1: partial information sums (stacked mode) and P_JJ ------------------------------------------------------
+    // ---- exchange 1: this role's partial sums of the fold (stacked mode) and P_JJ ---------------------------------------------
     if (JOINT) {
 #pragma unroll
-        for (int i = 0; i < 21; ++i) xc.part[((int)role * XC::NPART + i) * 64] = acc.Lam[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) xc.part[((int)role * XC::NPART + 21 + i) * 64] = acc.b[i];
+        for (int i = 0; i < PoseFold<T, N, DIALECT>::NVAL; ++i) xc.part[((int)role * XC::NPART + i) * 64] = fold.at(i);
     }
     auto put_pjj = [&](auto r_) {
         constexpr int R = decltype(r_)::value;
@@ -706,18 +704,16 @@ correct_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ 
     else if (NR > 3) put_pjj(std::integral_constant<int, (NR > 3 ? 3 : 0)>{});
     team_barrier();
     if (JOINT) {
-        // every role sums the partials in role order: the same Lam, b in every role, bit for bit
-        acc.clear();
+        // every role sums the partials in role order: the same sums in every role, bit for bit
+        fold.clear();
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
 #pragma unroll
-            for (int i = 0; i < 21; ++i) acc.Lam[i] += xc.part[(r * XC::NPART + i) * 64];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc.b[i] += xc.part[(r * XC::NPART + 21 + i) * 64];
+            for (int i = 0; i < PoseFold<T, N, DIALECT>::NVAL; ++i) fold.at(i) += xc.part[(r * XC::NPART + i) * 64];
         }
-        // any marker folded by any role?  every marker adds w_quat |Hq column|^2 > 0 to the theta diagonal of Lam
-        used = (acc.Lam[lidx(3, 3)] + acc.Lam[lidx(4, 4)] + acc.Lam[lidx(5, 5)] > T(0)) ? 1 : 0;
+        used = (int)fold.cnt;
     }
+    fold.finish(acc, nom, dc, mc);
     T PJ[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) PJ[i] = xc.pjj[i * 64];

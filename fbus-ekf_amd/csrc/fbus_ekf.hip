@@ -93,6 +93,9 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
         double q[4];
         rotmat_to_quat(prm.marker_rot[k], q);
         for (int i = 0; i < 4; ++i) m[3 + i] = q[i];
+        // c_m = 1/4 |Q_IL|^2 |Qm|^2: the isotropic information of the marker's four quaternion rows per unit weight and |q|^2
+        // (PoseFold, ekf_device.hpp)
+        m[7] = 0.25 * (w * w + x * x + y * y + z * z) * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     }
     return true;
 }

@@ -221,3 +221,57 @@ def test_transition_check_is_sharp():
         assert np.abs(J - bad).max() > 50 * dt * dt
     bad = Fx.copy(); bad[3:6, 6:9] = bad[3:6, 6:9].T
     assert np.abs(J - bad).max() > 50 * dt * dt
+
+
+def test_regrouped_fold_equals_the_row_by_row_information_sums():
+    """The kernels fold the 7 pose rows of M markers with the marker-independent factors taken out (PoseFold, ekf_device.hpp):
+    Lam_pp = w n Hpp'Hpp, Lam_pt = w Hpp' sum Hpt, and the four quaternion rows of a marker as the ISOTROPIC
+    w_quat 1/4 |Q_IL|^2 |Qm|^2 |q|^2 I_3 (Rq(Q)'Rq(Q) = |Q|^2 I, Lq(Q)'Lq(Q) = |Q|^2 I).  Checked here against the oracle's own
+    Jacobian rows (MeasureUpdate.m:71-75 / filter.cpp:689-694 restated): the information matrix and vector summed row by row
+    equal the regrouped expressions to 1e-12 -- for a non-unit quaternion state too (the |q|^2 factor is part of the identity)."""
+    from fbus_ekf import capi, synth          # tests/conftest.py puts fbus-ekf_amd/ on the path
+    rng = np.random.default_rng(12)
+    J = [0, 1, 2, 6, 7, 8]
+    for dialect in (0, 1):
+        prm = capi.default_params(dialect)
+        orc = oc.Oracle(dialect, 18)
+        R_IL, P_IL, Q_IL = synth.camera_constants(prm)
+        mids, mpos, mquat = synth.marker_table(prm)
+        w_pos, w_quat = 1.0 / prm.r_pos, 1.0 / prm.r_quat
+        for trial in range(20):
+            nom = np.zeros(19)
+            nom[0:3] = rng.uniform(-1, 1, 3)
+            q = rng.normal(size=4)
+            q *= (1.0 if trial % 2 == 0 else 1.0 + 3e-3) / np.linalg.norm(q)        # also a state quaternion that is not quite unit
+            nom[6:10] = q
+            nom[16] = 9.8
+            rot = synth.q2R(q / np.linalg.norm(q)).ravel() + rng.normal(0, 1e-6, 9)   # the carried rotation is its own variable
+            sel = rng.choice(len(mids), 5, replace=False)
+            Lam, b = np.zeros((6, 6)), np.zeros(6)
+            sH, sr, Ltt, bt, csum, btq = np.zeros((3, 3)), np.zeros(3), np.zeros((3, 3)), np.zeros(3), 0.0, np.zeros(3)
+            for k in sel:
+                yp = rng.uniform(-0.3, 0.3, 3) + np.array([0, 0, 0.8])
+                yq = rng.normal(size=4); yq /= np.linalg.norm(yq)
+                h, H, r = orc.measurement(nom, rot, int(mids[k]), yp, yq)
+                w = np.array([w_pos] * 3 + [w_quat] * 4)
+                Lam += (H[:, J].T * w) @ H[:, J]
+                b += (H[:, J].T * w) @ r
+                Hpp, Hpt, Hq = H[0:3, 0:3], H[0:3, 6:9], H[3:7, 6:9]
+                assert np.abs(H[3:7, 0:3]).max() == 0
+                sH += Hpt; sr += r[0:3]; Ltt += Hpt.T @ Hpt; bt += Hpt.T @ r[0:3]
+                cm = 0.25 * (Q_IL @ Q_IL) * (mquat[k] @ mquat[k])
+                assert np.allclose(Hq.T @ Hq, cm * (q @ q) * np.eye(3), rtol=0, atol=1e-13)       # the identity itself
+                csum += cm
+                btq += Hq.T @ r[3:7]
+            n = len(sel)
+            Lam2, b2 = np.zeros((6, 6)), np.zeros(6)
+            Lam2[0:3, 0:3] = w_pos * n * Hpp.T @ Hpp
+            Lam2[0:3, 3:6] = w_pos * Hpp.T @ sH
+            Lam2[3:6, 0:3] = Lam2[0:3, 3:6].T
+            Lam2[3:6, 3:6] = w_pos * Ltt + w_quat * (q @ q) * csum * np.eye(3)
+            b2[0:3] = w_pos * Hpp.T @ sr
+            b2[3:6] = w_pos * bt + w_quat * btq
+            assert np.abs(Lam - Lam2).max() <= 1e-12 * np.abs(Lam).max()
+            assert np.abs(b - b2).max() <= 1e-12 * max(np.abs(b).max(), 1.0)
+            if dialect == 0:
+                assert np.abs(btq).max() == 0            # Matlab zeroes the quaternion residual (MeasureUpdate.m:88)
