@@ -568,11 +568,15 @@ def main():
     gather_via = "torch.distributed"
     sizes = shard.record_bytes_of_ranks(args.total_batch, world, w.bpf) if strong else None
     if not shared and os.environ.get("FBUS_BENCH_TORCH_GATHER") != "1":
+        failed = 0.0
         try:
             shard.native_comm_init(flt, rank, world, dist, ctl_dev)
-            gather_via = "fbus_ekf_gather (RCCL inside the library)"
         except Exception as e:                       # no RCCL on this box: say so, fall back
-            sys.stderr.write(f"bench.py: native RCCL communicator unavailable ({e}); gathering through torch.distributed\n")
+            failed = 1.0
+            sys.stderr.write(f"bench.py: native RCCL communicator unavailable on rank {rank} ({e}); gathering through torch.distributed\n")
+        # the choice is collective: one rank without the communicator and everybody takes the torch path
+        if shard.max_over_ranks(failed, dist, world, ctl_dev) == 0.0:
+            gather_via = "fbus_ekf_gather (RCCL inside the library)"
     torch.cuda.synchronize()
     barrier()
     tg = time.perf_counter()

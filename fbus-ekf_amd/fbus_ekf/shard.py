@@ -84,14 +84,19 @@ def native_comm_init(flt, rank, world, dist=None, device="cpu"):
     128-byte unique id, the others receive it over the control process group (a broadcast of 128 bytes -- the id is the only thing
     that ever travels outside the library's own collective)."""
     import torch
+    raw, ok, why = bytes(128), 1, ""
     if rank == 0:
-        raw = flt.comm_unique_id()
-    else:
-        raw = bytes(128)
+        try:
+            raw = flt.comm_unique_id()
+        except Exception as e:                      # no RCCL here: the other ranks must still get their broadcast
+            ok, why = 0, str(e)
     if dist is not None and world > 1:
-        t = torch.tensor(list(raw), dtype=torch.uint8, device=device)
+        t = torch.tensor([ok] + list(raw), dtype=torch.uint8, device=device)
         dist.broadcast(t, src=0)
-        raw = bytes(t.cpu().tolist())
+        vals = t.cpu().tolist()
+        ok, raw = vals[0], bytes(vals[1:])
+    if not ok:
+        raise RuntimeError("rank 0 could not create an RCCL unique id" + (f": {why}" if why else ""))
     flt.comm_init(raw, rank, world)
 
 

@@ -148,3 +148,35 @@ def test_recording_files_round_trip_and_fusion_trace_format(tmp_path):
     with pytest.raises(ValueError):
         np.savetxt(tmp_path / "image.txt", g["image"][:, :8], fmt="%.9f")
         replay.load_recording(str(tmp_path))
+
+
+def test_cpp_shard_arithmetic_matches_python(tmp_path):
+    """include/fbus/sharded_filter.hpp::shard_range (what a C++ multi-GPU driver cuts the batch with) against fbus_ekf.shard.shard_range
+    (what bench.py uses) over many (total, world): the same contiguous 64-aligned ranges, and record_bytes_of_ranks = whole tiles."""
+    import subprocess
+    from fbus_ekf import shard
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    src = tmp_path / "sr.cpp"
+    src.write_text(r'''
+#include <fbus/sharded_filter.hpp>
+#include <cstdio>
+int main() {
+    const long totals[] = {1, 63, 64, 65, 200, 1000, 4096, 65536, 262144, 262145, 1048576};
+    for (long t : totals) for (int w = 1; w <= 8; ++w) for (int r = 0; r < w; ++r) {
+        long lo, hi; fbus::ShardedFilter<float>::shard_range(t, r, w, lo, hi);
+        std::printf("%ld %d %d %ld %ld\n", t, w, r, lo, hi);
+    }
+}
+''')
+    exe = tmp_path / "sr"
+    subprocess.run(["g++", "-std=c++14", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    rows = np.array(out, dtype=np.int64).reshape(-1, 5)
+    assert len(rows) == 11 * 36
+    for t, w, r, lo, hi in rows:
+        assert shard.shard_range(int(t), int(r), int(w)) == (lo, hi)
+    for t in (200, 1000, 262145):
+        for w in (1, 3, 8):
+            b = shard.record_bytes_of_ranks(t, w, 800)
+            assert sum(b) >= t * 800 and all(x % (64 * 800) == 0 for x in b)
+            assert sum(x // 800 for x in b) - t < 64 * w
