@@ -12,10 +12,11 @@
 //   predict  (ImuUpdate.m:63-81 ; filter.cpp:588-616)  F P F' is three in-place congruences -- rows p, rows v, rows theta
 //            (cov_stage_p / _v / _th).  Each of them READS ONLY PRE-STEP VALUES of the rows it does not own (that is why the
 //            one-wave kernel may run them in this order in place), so three roles can run them side by side on private
-//            copies of the rows they read, with no exchange at all, and store disjoint parts of the record.  Same device
+//            copies of the rows they read, with no exchange of data -- only one barrier between the loads and the first store
+//            (a role must not store rows another role has yet to read) -- and store disjoint parts of the record.  Same device
 //            functions on the same inputs: the results equal the one-wave kernel's up to the compiler's FMA contraction
 //            (which product of an a*b + c*d gets fused differs between the specialised kernels: measured 1 ulp on 5 of the
-//            171 covariance elements of 17 of 311 filters, the nominal state bit-equal).
+//            171 covariance elements of 17 of 311 filters, 1 ulp on single components of the nominal state).
 //   predict_n  the same roles over K samples; between two steps role v hands its new rows to role p, role theta its new
 //            rows to role v, and the nominal role its coefficient blocks to everybody through LDS (one barrier per step).
 //   correct  (MeasureUpdate.m:84-102 ; filter.cpp:709-739)  every row of every marker has its non-zeros in the six
@@ -181,8 +182,9 @@ predict_team_kernel(T* __restrict__ recs, int B, const T* __restrict__ accel, co
     const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned tile = blockIdx.x;
-    const int b = (int)(tile * 64u + lane);
-    if (b >= B) return;                                 // no barrier in this kernel
+    const int b0 = (int)(tile * 64u + lane);
+    const bool live = b0 < B;
+    const int b = live ? b0 : (int)(tile * 64u);       // lanes past B run along on the tile's first filter and store nothing
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
     const size_t o = (size_t)b * 3;
     const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
@@ -195,23 +197,28 @@ predict_team_kernel(T* __restrict__ recs, int B, const T* __restrict__ accel, co
         load_stage_chunks<T, N, job_stage_mask(JOBS), LD>(rs, lane, P);
         PredictCoef<T> k;
         predict_nominal<T, N, DIALECT>(nom, a, w, h, k);
+        // "No exchange" does not mean "no ordering": a stage reads the PRE-step values of rows another role owns, so no role may
+        // store before every role's loads have landed.  One barrier behind the loads (vmcnt(0): the data is in registers);
+        // without it the kernel was right at 4096 / 16 384 filters and wrong at 32 768 (block-wise covariance error 3e-2:
+        // role p's loads of rows v, queued behind a busy memory system, came back with what role v had already stored).
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if constexpr ((JOBS & JOB_NOM) != 0) {
-            store_chunks<T, N, 0, RC::CH_KIN, ST>(rs, lane, nom);
+            if (live) store_chunks<T, N, 0, RC::CH_KIN, ST>(rs, lane, nom);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr ((JOBS & JOB_P) != 0) {
             cov_stage_p<T, N>(P, k);
-            store_stage<T, N, 0, ST>(rs, lane, P);
+            if (live) store_stage<T, N, 0, ST>(rs, lane, P);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr ((JOBS & JOB_V) != 0) {
             cov_stage_v<T, N>(P, k, dc.qd);
-            store_stage<T, N, 1, ST>(rs, lane, P);
+            if (live) store_stage<T, N, 1, ST>(rs, lane, P);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr ((JOBS & JOB_TH) != 0) {
             cov_stage_th<T, N>(P, k, dc.qd);
-            store_stage<T, N, 2, ST>(rs, lane, P);
+            if (live) store_stage<T, N, 2, ST>(rs, lane, P);
         }
     };
     if (role == 0) run(std::integral_constant<int, predict_jobs<NR>(0)>{});

@@ -242,10 +242,10 @@ void timing_end(fbus_ekf_t h, int i)
 // How many waves should share one 64-filter tile?  One wave per tile (the lane-per-filter kernels) fills the chip from
 // 1024 tiles on; below that the SIMDs that would idle can take a share of every filter's work instead (ekf_team.hpp).
 // Measured (rocprofv3 kernel trace, profiles/r03_team_kernels.txt), one-wave -> team:
-//   predict    4096 filters 4.96 -> 4.12 us (3 roles), 16 384: 5.88 -> 4.84, 32 768: 7.12 -> 8.3 (the roles' overlapping loads cost
+//   predict    4096 filters 4.52 -> 4.00 us (3 roles), 16 384: 4.80 -> 4.52, 32 768: 6.4 -> 8.8 (the roles' overlapping loads cost
 //              more than the shorter instruction streams save once the launch moves 47 MB)            => up to 256 tiles
-//   predict_n  K = 8: 4096 filters 18.9 -> 10.4 us, 16 384: 20.8 -> 16.7, 32 768: 23.1 -> 22.2                 => up to 512 tiles
-//   correct    4096 filters 7.7 -> 8.1 us, 16 384: 8.6 -> 9.5, 32 768: 10.2 -> 18: the one-wave kernel folds its markers under
+//   predict_n  K = 8: 4096 filters 18.8 -> 10.3 us, 16 384: 20.7 -> 17.5, 32 768: 23.2 -> 20.9                 => up to 512 tiles
+//   correct    4096 filters 6.4 -> 7.6 us, 16 384: 7.2 -> 9.2, 32 768: 10.0 -> 18: the one-wave kernel folds its markers under
 //              the load latency and the team pays two exchanges and a redundant 6 x 6 solve per role       => never by default
 int team_roles_predict(const fbus_ekf* h, int K)
 {
