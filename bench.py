@@ -213,7 +213,11 @@ def cpu_baseline(args, seconds):
     m = capi.MODE_STACKED if args.mode == "stacked" else capi.MODE_NEAREST
     same_v, same_1, same_s = leg(d, m, seconds * 0.5)
     flags = "-march=native" if native else "generic x86-64"
-    return {"value": ref_v, "unit": "EKF steps/s", "cores": cores, "kind": "port",
+    # "if Eigen3 is found on the box, additionally build an Eigen-typed twin" -- say whether it was
+    eigen_dirs = [d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/rocm/include/eigen3") if os.path.isdir(os.path.join(d, "Eigen"))]
+    eigen = (f"Eigen headers at {eigen_dirs[0]}, but no Eigen-typed twin is built: the dense C port stands in for the reference's "
+             "Eigen path") if eigen_dirs else "Eigen3 not found on this box (the reference's own build needs it): no Eigen-typed twin, the dense C port stands in"
+    return {"value": ref_v, "unit": "EKF steps/s", "cores": cores, "kind": "port", "eigen": eigen,
             "path": "reference CPU path restated: C++ dialect, UpdateCovariance+UpdateNominalState (filter.cpp:533-616) per "
                     "IMU sample, ObservationUpdate (filter.cpp:622-741) per frame = nearest marker with hysteresis, 7 rows, LDLT",
             "sample": f"{ref_s}, fp64 dense oracle port, {cores} threads, {flags}",
