@@ -204,3 +204,41 @@ int main() {
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "gathered 819200 bytes equal 1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_gather_with_a_callers_own_communicator():
+    """fbus_ekf_comm_attach: the caller creates the ncclComm_t itself (here through ctypes on the same librccl the library binds),
+    the library only uses it -- and does not destroy it"""
+    import ctypes as C
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "fbus-ekf_amd"))
+    from fbus_ekf import BatchedFilter, capi, synth
+    rccl = C.CDLL("librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    B = 640
+    prm = capi.default_params(0)
+    nom, rot, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18)
+    with BatchedFilter(B, prm) as flt:
+        flt.set_state(nom, rot, P, prev)
+        _, bpf, total = flt.records()
+        rec = torch.empty(total, dtype=torch.uint8, device="cuda:0")
+        flt.attach_records(rec)
+        lib = capi.load_library()
+        assert lib.fbus_ekf_comm_attach(flt._h, comm, 0, 1) == 0
+        out = torch.zeros(total, dtype=torch.uint8, device="cuda:0")
+        flt.gather(out); flt.sync()
+        assert torch.equal(out, rec)
+        assert lib.fbus_ekf_comm_destroy(flt._h) == 0          # detaches; the communicator is still the caller's
+        with pytest.raises(capi.FbusError):
+            flt.gather(out)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclCommDestroy(comm) == 0
