@@ -159,7 +159,7 @@ __device__ __forceinline__ void team_barrier()
 }
 
 // =================================================================================
-// predict, one step per launch: independent stage roles, no exchange
+// predict, one step per launch: independent stage roles, no exchange of data (one barrier between loads and stores)
 // =================================================================================
 //   NR = 2:  { rows v }  { nominal state, rows p, rows theta }
 //   NR = 3:  { rows v }  { rows p, rows theta }  { nominal state }
@@ -240,11 +240,11 @@ predict_team_kernel(T* __restrict__ recs, int B, const T* __restrict__ accel, co
 // Same device functions, same operands as the one-wave predict_n (equal up to FMA contraction, see above).
 template <typename T, int N>
 struct StepXch {
-    static constexpr int NCOEF = 28, QC = 7;                 // coefficient blocks: 7 x 16 bytes
+    static constexpr int QC = 7;                             // the 28 coefficients (A, Bm, Th, dt): 7 x 16 bytes
     static constexpr int E_V0 = cov_final_before_row<N>(3) / 4 * 4, E_V1 = (cov_final_before_row<N>(6) + 3) / 4 * 4;   // chunk-aligned cover of rows v
     static constexpr int E_T0 = cov_final_before_row<N>(6) / 4 * 4, E_T1 = (cov_final_before_row<N>(9) + 3) / 4 * 4;   // ... of rows theta
     static constexpr int QV = (E_V1 - E_V0) / 4, QT = (E_T1 - E_T0) / 4;
-    // odd-row diagonals live behind the rows (even N): they travel as one more 16-byte slot each
+    // even N: the odd-row diagonals (3,3), (5,5) / (7,7) live behind the rows and travel in one more 16-byte cell each
     static constexpr bool DIAG_APART = (N % 2 == 0);
     static constexpr int QVX = QV + (DIAG_APART ? 1 : 0), QTX = QT + (DIAG_APART ? 1 : 0);
     static constexpr int PER_SLOT = QC + QVX + QTX;          // 16-byte cells per buffer and lane
@@ -292,7 +292,6 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
         for (int i = 0; i < 9; ++i) { k.A[i] = c[i]; k.Bm[i] = c[9 + i]; k.Th[i] = c[18 + i]; }
         k.dt = c[27];
     };
-    // the odd-row diagonals of a row group (even N): (1,1) / (3,3),(5,5) / (7,7)
     if (role == 3) {
         // ---- nominal role: one step ahead of the covariance roles -------------------------------------------------
         load_chunks<T, N, 0, CN, AUX_NT>(rs, lane, nom);
@@ -346,7 +345,7 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int e = X::E_T0 + 4 * q + i;
-                        if (e < RC::NCOVP - 0 && e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
+                        if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
                     }
                 }
                 if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QVX + X::QT, d); P[pidx<N>(7, 7)] = d[0]; }
