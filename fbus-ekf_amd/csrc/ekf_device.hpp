@@ -905,16 +905,16 @@ struct PoseFold {
     {
         return k < 9 ? sH[k] : (k < 12 ? sr[k - 9] : (k < 18 ? Ltt[k - 12] : (k < 21 ? bt[k - 18] : (k == 21 ? csum : (k == 22 ? cnt : btq[k - 23])))));
     }
-    // one marker (map slot constants mk: position 3, quaternion 4, c_m), measured pose yp, yq
-    __device__ __forceinline__ void add(const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc, const T* __restrict__ mk,
-                                        const T* yp, const T* yq)
+    // three position-type rows of ONE world point Pw seen at y in the left camera (a marker's origin, or one of its corners):
+    // h = R_IL R'(Pw - p - R P_IL), H(:, p) = Hpp, H(:, theta) = R_IL [R'(Pw - p)]x
+    // (MeasureUpdate.m:67,72-73 ; filter.cpp:684-685,691-692)
+    __device__ __forceinline__ void add_point(const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc, const T* Pw, const T* y)
     {
         using L = Lay<N>;
         const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
-        // hp = R_IL R' (Pm - p - R P_IL) ; H(1:3,7:9) = R_IL [R'(Pm - p)]x     MeasureUpdate.m:67,72-73 ; filter.cpp:684-685,691-692
         T u[3], d[3], t[3], ru[3], Hpt[9], rp[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { u[i] = mk[i] - p[i]; d[i] = u[i] - mc.RP[i]; }
+        for (int i = 0; i < 3; ++i) { u[i] = Pw[i] - p[i]; d[i] = u[i] - mc.RP[i]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             t[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
@@ -923,7 +923,7 @@ struct PoseFold {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
-            rp[i] = yp[i] - (l0 * t[0] + l1 * t[1] + l2 * t[2]);
+            rp[i] = y[i] - (l0 * t[0] + l1 * t[1] + l2 * t[2]);
             Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
             Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
             Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
@@ -940,8 +940,29 @@ struct PoseFold {
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = i; j < 3; ++j) Ltt[o++] += Hpt[i] * Hpt[j] + Hpt[3 + i] * Hpt[3 + j] + Hpt[6 + i] * Hpt[6 + j];
-        csum += mk[7];
         cnt += T(1);
+    }
+    // the four triangulated corners C[12] of one marker as 12 position-type rows (north-star extension, no reference counterpart):
+    // corner k of the marker frame of vision.cpp:736-759, c_k = {(0,0,0),(0,s,0),(s,s,0),(s,0,0)}, in the world: P_m + R_m c_k
+    __device__ __forceinline__ void add_corners(const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc, const T* __restrict__ mk,
+                                                const T* C, T size)
+    {
+        T Rm[9];
+        const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
+        quat_to_rotmat_m(Qm, Rm);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T cx = (k >= 2) ? size : T(0), cy = (k == 1 || k == 2) ? size : T(0);
+            const T Pw[3] = { mk[0] + Rm[0] * cx + Rm[1] * cy, mk[1] + Rm[3] * cx + Rm[4] * cy, mk[2] + Rm[6] * cx + Rm[7] * cy };
+            add_point(pqr, dc, mc, Pw, C + 3 * k);
+        }
+    }
+    // one marker (map slot constants mk: position 3, quaternion 4, c_m), measured pose yp, yq: 3 position rows + 4 quaternion rows
+    __device__ __forceinline__ void add(const T* pqr, const DevConst<T>& dc, const MarkerCommon<T, N>& mc, const T* __restrict__ mk,
+                                        const T* yp, const T* yq)
+    {
+        add_point(pqr, dc, mc, mk, yp);
+        csum += mk[7];
         if constexpr (DIALECT == DIALECT_CPP) {
             // the quaternion residual is used (filter.cpp:698-706,718-721): b_theta += w s M1' (Rq(Qm)' rq)
             const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
@@ -1297,60 +1318,6 @@ __device__ __forceinline__ void joint_apply_late(T* P, T* dx, const LateStash<T,
         }
     });
 #undef PS
-}
-
-// Corner-row measurement model (north-star extension, no reference counterpart): the four triangulated
-// corner positions C[12] of one marker as 12 scalar rows.  h_k = R_IL R'(P_m + R_m c_k - p - R P_IL) with
-// c_k = {(0,0,0),(0,s,0),(s,s,0),(s,0,0)} (marker frame of vision.cpp:736-759); Jacobian blocks as the
-// reference's position rows (MeasureUpdate.m:72-73) with the corner in place of the marker origin.
-// The 12 rows go into the information accumulator (same column support as the marker rows), so any number of
-// markers is again six scalar updates (joint_update).
-template <typename T, int N>
-__device__ __forceinline__ void corner_info(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc,
-                                            const T* __restrict__ mk, const T* C, T size, T w_pos)
-{
-    using L = Lay<N>;
-    const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
-    T Rm[9];
-    {
-        const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
-        quat_to_rotmat_m(Qm, Rm);
-    }
-    // H(:,1:3) = -R_IL R' is the same for every corner
-    T Hpp[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            Hpp[3 * i + j] = -(dc.R_IL[3 * i] * R[3 * j] + dc.R_IL[3 * i + 1] * R[3 * j + 1] + dc.R_IL[3 * i + 2] * R[3 * j + 2]);
-    T RP[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) RP[i] = R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const T cx = (k >= 2) ? size : T(0), cy = (k == 1 || k == 2) ? size : T(0);
-        T u[3], d[3], ru[3], t[3], hp[3], Hpt[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            u[i] = mk[i] + Rm[3 * i] * cx + Rm[3 * i + 1] * cy - p[i];      // corner in the world, minus p
-            d[i] = u[i] - RP[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            t[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
-            ru[i] = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
-            hp[i] = l0 * t[0] + l1 * t[1] + l2 * t[2];
-            Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
-            Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
-            Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) acc.add6(Hpp + 3 * a, Hpt + 3 * a, C[3 * k + a] - hp[a], w_pos);
-    }
 }
 
 // State injection   MeasureUpdate.m:92-98 ; filter.cpp:726-733.  R is NOT refreshed.

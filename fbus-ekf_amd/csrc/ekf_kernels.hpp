@@ -1116,8 +1116,10 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     if (!live) { if (b < B) applied[b] = 0; return; }
     int used = 0, new_prev = -1;
     InfoAcc<T> acc;
-    acc.clear();
-    const T w_pos = T(1) / dc.r_pos;
+    PoseFold<T, N, DIALECT_MATLAB> fold;                 // position-type rows only: the dialect-dependent quaternion part is not used
+    fold.clear();
+    MarkerCommon<T, N> mc;
+    mc.build(pqr, dc);
     // The rows of all markers are folded into the 6x6 information matrix BEFORE the covariance is requested: the 16
     // ray intersections per marker are hundreds of live values, and with the 171 covariance registers reserved as load
     // targets at the same time the fp64 instantiation spilled 600-800 bytes per lane to scratch (fp32: 20 bytes in
@@ -1132,7 +1134,7 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         T C[12];
 #pragma unroll
         for (int c = 0; c < 4; ++c) corner(m, c, C + 3 * c);
-        corner_info<T, N>(acc, pqr, dc, mk, C, size, w_pos);
+        fold.add_corners(pqr, dc, mc, mk, C, size);
         return true;
     };
     if (mode == MODE_NEAREST) {
@@ -1173,6 +1175,7 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     using Hook = RowStore<T, N, AUX_DEFAULT>;
     __shared__ T stash_mem[LEAN ? Stash::NVAL * BLOCK : 1];
     InfoFactors<T> fac;
+    fold.finish(acc, pqr, dc, mc);
     joint_factor<T>(acc, fac);
     order_fence();
     T P[RC::NCOVP];
@@ -1204,7 +1207,7 @@ correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
 }
 
 // Pixel rows of one marker into the information accumulator (north-star extension, no reference counterpart):
-// for each of the four corners the predicted position X in the left camera frame (the geometry of corner_info), its
+// for each of the four corners the predicted position X in the left camera frame (the geometry of PoseFold::add_corners), its
 // flat-port projection into the left (and right) camera with the closed-form 2 x 3 Jacobian, and 2 (4) rows
 // (d pi/dX) [ -R_IL R' | R_IL [R'(c_w - p)]x ] with the pixel residuals.
 template <typename T, int N>
