@@ -18,12 +18,15 @@
 
 namespace fbus {
 
-// From this many filters on a launch has >= 2048 waves, two per SIMD, and the instantiations written for at most 256
-// registers (row-split correct, parked predict_n / frame) are the faster ones; below it every SIMD holds one wave
-// whatever the register count, and the one-wave forms win.  FBUS_TWO_WAVE_MIN_B moves the threshold (A/B runs, tests).
+// From this many filters on a launch has more waves than the chip has SIMDs (1024): some SIMDs hold two, and the
+// instantiations written for at most 256 registers (row-split correct, parked predict_n / frame) let them run side by
+// side instead of one after the other; up to 1024 waves every SIMD holds one wave whatever the register count, and the
+// one-wave forms win.  r2 switched at 2048 waves; r3 measured the range in between (tools/r3_tail.sh,
+// profiles/logs/r03_tail_sweep.txt): stacked correct at 73 728 filters 24.9 -> 21.4 us, fused frame +20 % from 69 632 to
+// 114 688 filters.  FBUS_TWO_WAVE_MIN_B moves the threshold (A/B runs, tests).
 static int two_wave_min_b()
 {
-    static const int v = [] { const char* e = getenv("FBUS_TWO_WAVE_MIN_B"); return e ? atoi(e) : 2048 * BLOCK; }();
+    static const int v = [] { const char* e = getenv("FBUS_TWO_WAVE_MIN_B"); return e ? atoi(e) : 1024 * BLOCK + 1; }();
     return v;
 }
 
@@ -77,7 +80,7 @@ void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
 #define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                              \
     hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, pos, quat, \
                        mode, skip, applied, dc)
-    // fp32, stacked, simple form: from 2048 waves on (two per SIMD) the row-split instantiation (194 registers) is the
+    // fp32, stacked, simple form: from 1025 waves on (two on some SIMDs) the row-split instantiation (194 registers) is the
     // faster one -- see the LEAN comment in correct_kernel
     if (sizeof(T) == 4 && joint && !joseph && B >= two_wave_min_b()) {
         hipLaunchKernelGGL((correct_kernel<T, N, D, COV_SIMPLE, true, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
@@ -107,7 +110,7 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
                        dt_stride, M, ids, pos, quat, mode, skip, applied, dc)
     // (Joseph form, nearest marker) is not built as a fused kernel (7 Joseph rank-2 passes with the record resident
     // spilled 280 bytes per lane): fbus_ekf.hip runs that combination as predict_n + correct
-    // stacked mode, simple form, >= 2048 waves: the two-waves-per-SIMD kernel (see frame2_kernel)
+    // stacked mode, simple form, > 1024 waves: the two-waves-per-SIMD kernel (see frame2_kernel)
     if (joint && !joseph && B >= two_wave_min_b()) {
         hipLaunchKernelGGL((frame2_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, dt_stride, M, ids,
                            pos, quat, skip, applied, dc);
