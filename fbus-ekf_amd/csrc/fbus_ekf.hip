@@ -915,7 +915,11 @@ Rccl& rccl()
         void* lib = nullptr;
         for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
             if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!lib) { x.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return x; }
+        if (!lib) {
+            const char* why = dlerror();            // one call: dlerror() clears the message it returns
+            x.err = std::string("librccl.so.1 not found: ") + (why ? why : "");
+            return x;
+        }
         auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p && x.err.empty()) x.err = std::string("RCCL symbol missing: ") + n; return p; };
         x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
