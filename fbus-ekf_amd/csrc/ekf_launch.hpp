@@ -48,6 +48,10 @@ template <typename T, int N, int D>
 void launch_predict_team_k(hipStream_t s, T* recs, int B, int K, int roles, int policy, const T* accel, const T* gyro,
                            const T* dt, int dt_stride, const DevConst<T>& dc);
 template <typename T, int N, int D>
+void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro,
+                          const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode,
+                          const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
+template <typename T, int N, int D>
 void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode, int roles,
                            const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
 

@@ -390,6 +390,361 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
 }
 
 // =================================================================================
+// frame window: F x { K_f ImuUpdates, one MeasureUpdate } per launch, the predict pipeline of predict_n_team_kernel with
+// the correct on the nominal role
+// =================================================================================
+// The fused frame / frame window kernels of ekf_kernels.hpp keep one filter's whole record in one lane from the first load
+// to the last store; below 1024 tiles most SIMDs idle while each wave walks through ~1150 instructions per ImuUpdate.
+// Here the K_f predict steps of a frame run as the four-role pipeline above.  Behind the last step of a frame every
+// covariance role leaves the rows it owns in LDS; the nominal role -- which finished its last predict_nominal one iteration
+// earlier and folded the frame's markers while the others were still busy -- collects them next to the predict-invariant
+// part it loaded at entry, runs the MeasureUpdate exactly as the one-wave kernels do (PoseFold -> joint_update: same
+// device functions, same operands), and hands the posterior back through LDS for the next frame (or streams it to the
+// record after the last one).  Per frame: K_f + 3 barriers, 43 + 43 16-byte cells per lane through LDS.
+//
+// LDS: the two exchange buffers of the predict pipeline (2 x 30 cells per lane).  The 43 gather cells are laid over them
+// but around the 7 coefficient cells at the head of each buffer -- the nominal role writes the next frame's first
+// coefficients while the covariance roles are still reading the posterior.
+template <typename T, int N>
+struct FrameXch {
+    using X = StepXch<T, N>;
+    static constexpr int NCC = Rec<T, N>::NCOVP / 4;
+    static constexpr int HALF = X::PER_SLOT - X::QC;                       // free cells per buffer behind the coefficients
+    static_assert(NCC <= 2 * HALF, "the gather cells do not fit around the coefficient cells");
+    static constexpr int cell(int cc) { return cc < HALF ? X::QC + cc : X::PER_SLOT + X::QC + (cc - HALF); }
+};
+
+// the elements stage S owns -> their gather cells (whole chunks as one 16-byte write)
+template <typename T, int N, int S>
+__device__ __forceinline__ void gather_put_stage(u32x4* mem, const T* P)
+{
+    using TR = TeamRec<T, N>;
+    static_for<0, TR::NCC>([&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        constexpr int m = TR::write_mask(S, cc);
+        if constexpr (m != 0) {
+            u32x4* c = mem + FrameXch<T, N>::cell(cc) * 64;
+            const unsigned* w = reinterpret_cast<const unsigned*>(P + 4 * cc);
+            if constexpr (m == 0xF) *c = u32x4{ w[0], w[1], w[2], w[3] };
+            else {
+                unsigned* e = reinterpret_cast<unsigned*>(c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((m >> k) & 1) e[k] = w[k];
+            }
+        }
+    });
+}
+// everything the three stages own, from the gather cells into the full covariance (the rest of P stays as it is)
+template <typename T, int N>
+__device__ __forceinline__ void gather_get_predicted(const u32x4* mem, T* P)
+{
+    using TR = TeamRec<T, N>;
+    static_for<0, TR::NCC>([&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        constexpr int m = TR::write_mask(0, cc) | TR::write_mask(1, cc) | TR::write_mask(2, cc);
+        if constexpr (m != 0) {
+            const u32x4 v = mem[FrameXch<T, N>::cell(cc) * 64];
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((m >> k) & 1) P[4 * cc + k] = e[k];
+        }
+    });
+}
+// the whole covariance -> gather cells (nominal role, behind the correct) and the chunks a stage set reads <- gather cells
+template <typename T, int N>
+__device__ __forceinline__ void gather_put_all(u32x4* mem, const T* P)
+{
+    static_for<0, TeamRec<T, N>::NCC>([&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        const unsigned* w = reinterpret_cast<const unsigned*>(P + 4 * cc);
+        mem[FrameXch<T, N>::cell(cc) * 64] = u32x4{ w[0], w[1], w[2], w[3] };
+    });
+}
+template <typename T, int N, int STAGES>
+__device__ __forceinline__ void gather_get_stage_chunks(const u32x4* mem, T* P)
+{
+    using TR = TeamRec<T, N>;
+    static_for<0, TR::NCC>([&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        if constexpr (TR::reads_chunk(STAGES, cc)) {
+            const u32x4 v = mem[FrameXch<T, N>::cell(cc) * 64];
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P[4 * cc + k] = e[k];
+        }
+    });
+}
+
+template <typename T, int N, int DIALECT>
+__global__ void __launch_bounds__(256)
+frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __restrict__ accel, const T* __restrict__ gyro,
+                   const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+                   const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
+                   unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    using X = StepXch<T, N>;
+    constexpr int CN = RC::CH_NOM;
+    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned tile = blockIdx.x;
+    const int b0 = (int)(tile * 64u + lane);
+    const bool live = b0 < B;
+    const int b = live ? b0 : (int)(tile * 64u);          // lanes past B run along on the tile's first filter, store nothing
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    __shared__ u32x4 xmem[2 * X::PER_SLOT * 64];
+    __shared__ MarkerLDS<T> tbl;
+    const X xch{ xmem + lane };
+    u32x4* const gmem = xmem + lane;
+    T nom[L::NNOM], P[RC::NCOVP];
+    PredictCoef<T> k;
+    auto put4 = [&](int buf, int q, const T* src) {
+        u32x4 v;
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = src[i];
+        *xch.cell(buf, q) = v;
+    };
+    auto get4 = [&](int buf, int q, T* dst) {
+        const u32x4 v = *xch.cell(buf, q);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = e[i];
+    };
+    auto get_coef = [&](int buf) {
+        T c[28];
+#pragma unroll
+        for (int q = 0; q < X::QC; ++q) get4(buf, q, c + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { k.A[i] = c[i]; k.Bm[i] = c[9 + i]; k.Th[i] = c[18 + i]; }
+        k.dt = c[27];
+    };
+    if (role == 3) {
+        // ---- nominal state + MeasureUpdate ----------------------------------------------------------------------------
+        {
+            // the marker map -> LDS by this wave alone (it is the only reader; LDS operations of one wave are in order)
+            constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(T) * FBUS_MAX_MARKERS * MK_STRIDE / 16;
+            constexpr int PI = (NI + 63) / 64, PM = (NM + 63) / 64;
+            const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
+            const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
+            u32x4 vi[PI], vm[PM];
+#pragma unroll
+            for (int q = 0; q < PI; ++q) { const int i = (int)lane + q * 64; vi[q] = si[i < NI ? i : 0]; }
+#pragma unroll
+            for (int q = 0; q < PM; ++q) { const int i = (int)lane + q * 64; vm[q] = sm[i < NM ? i : 0]; }
+            order_fence();
+            load_chunks<T, N, 0, CN, AUX_NT>(rs, lane, nom);
+            load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, lane, P);
+            order_fence();
+            u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
+            u32x4* dm = reinterpret_cast<u32x4*>(tbl.mk);
+#pragma unroll
+            for (int q = 0; q < PI; ++q) { const int i = (int)lane + q * 64; if (i < NI) di[i] = vi[q]; }
+#pragma unroll
+            for (int q = 0; q < PM; ++q) { const int i = (int)lane + q * 64; if (i < NM) dm[i] = vm[q]; }
+            order_fence();
+        }
+        int k0 = 0, last_used = 0;
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            const T* fa = accel + (size_t)k0 * B * 3;
+            const T* fg = gyro + (size_t)k0 * B * 3;
+            const T* fd = dt + (size_t)k0 * (dt_stride ? B : 1);
+            k0 += K;
+            ImuSample<T> cur;
+            if (K > 0) cur.load(fa, fg, fd, dt_stride, 0, B, b);
+            // the frame's measurements (FBUS_EKF.m:193-204 ; filter.cpp:232-235): chosen and folded in iteration K below
+            const size_t fo = (size_t)f * B + b;
+            int first = 0, last = (M > 0 && live && !(skip && skip[fo])) ? M : 0;
+            int new_prev = -1, used = 0;
+            const int* my_ids = ids + fo * M;
+            const T* my_pos = pos + fo * M * 3;
+            const T* my_quat = quat + fo * M * 4;
+            InfoAcc<T> acc;
+            PoseFold<T, N, DIALECT> fold;
+            fold.clear();
+            MarkerCommon<T, N> mc;
+#pragma unroll 1
+            for (int t = 0; t <= K; ++t) {
+                if (t < K) {
+                    predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, k);
+                    if (t + 1 < K) cur.load(fa, fg, fd, dt_stride, t + 1, B, b);
+                    T c[28];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { c[i] = k.A[i]; c[9 + i] = k.Bm[i]; c[18 + i] = k.Th[i]; }
+                    c[27] = k.dt;
+#pragma unroll
+                    for (int q = 0; q < X::QC; ++q) put4(t & 1, q, c + 4 * q);
+                } else {
+                    // the nominal state is final: marker choice (MeasureUpdate.m:51-60 ; filter.cpp:639-664) and the fold of
+                    // the rows, while the covariance roles run the frame's last step
+                    if (last > 0 && mode == MODE_NEAREST) {
+                        const int prev_id = (DIALECT == DIALECT_CPP) ? (int)P[L::OFF_PREV - L::OFF_COV] : 0;
+                        int min_i = -1, prev_i = -1;
+                        T min_d = T(10), prev_d = T(0);
+                        for (int i = 0; i < M; ++i) {
+                            const int id = my_ids[i];
+                            if (id < 0) continue;
+                            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
+                            const T dist = fb_sqrt(x * x + y * y + z * z);
+                            if (dist < min_d) { min_d = dist; min_i = i; }
+                            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+                        }
+                        if (min_i >= 0 && DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0))
+                            min_i = prev_i;
+                        int slot = -1, id = -1;
+                        if (min_i >= 0) {
+                            id = my_ids[min_i];
+                            slot = (id >= 0 && id <= FBUS_MAX_MARKER_ID) ? (int)tbl.id2slot[id] : -1;
+                        }
+                        if (slot < 0) { first = last = 0; }
+                        else {
+                            if (DIALECT == DIALECT_CPP) new_prev = id;
+                            first = min_i; last = min_i + 1;
+                        }
+                    }
+                    mc.build(nom, dc);
+                    for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
+                        MarkerGroup<T, FBUS_MARKER_GROUP> mg;
+                        mg.fetch(my_ids, my_pos, my_quat, i0, last);
+                        mg.resolve(tbl);
+#pragma unroll
+                        for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
+                            if (mg.slot[g] < 0) continue;
+                            fold.add(nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
+                            ++used;
+                        }
+                    }
+                    if (used > 0) fold.finish(acc, nom, dc, mc);
+                }
+                team_barrier();
+            }
+            team_barrier();                                          // the predicted rows are in the gather cells
+            gather_get_predicted<T, N>(gmem, P);
+            const bool last_frame = f + 1 == F;
+            T dx[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) dx[i] = T(0);
+            if (used > 0) {
+                joint_update<T, N, COV_SIMPLE>(P, dx, acc);
+                inject<T, N>(nom, dx);
+                if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+            }
+            last_used = used;
+            if (!last_frame) {
+                gather_put_all<T, N>(gmem, P);
+                team_barrier();                                      // the posterior is in the gather cells
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (live) {
+            if (M > 0 && F > 0) applied[b0] = last_used > 0 ? 1 : 0;
+            store_chunks<T, N, 0, CN, FBUS_X_FRAME_ST>(rs, lane, nom);
+            store_chunks<T, N, CN, RC::NCH, FBUS_X_FRAME_ST>(rs, lane, P);
+        }
+    } else if (role == 2) {
+        // ---- rows theta (+ Q diagonals) ---------------------------------------------------------------------------------
+        load_stage_chunks<T, N, 4, AUX_NT>(rs, lane, P);
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            team_barrier();                                                  // iteration 0
+#pragma unroll 1
+            for (int t = 1; t <= K; ++t) {
+                get_coef((t - 1) & 1);
+                cov_stage_th<T, N>(P, k, dc.qd);
+                if (t < K) {
+#pragma unroll
+                    for (int q = 0; q < X::QT; ++q) put4(t & 1, X::QC + X::QVX + q, P + X::E_T0 + 4 * q);
+                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(7, 7)], T(0), T(0), T(0) }; put4(t & 1, X::QC + X::QVX + X::QT, d); }
+                }
+                team_barrier();
+            }
+            gather_put_stage<T, N, 2>(gmem, P);
+            team_barrier();
+            if (f + 1 == F) break;
+            team_barrier();
+            gather_get_stage_chunks<T, N, 4>(gmem, P);
+        }
+    } else if (role == 0) {
+        // ---- rows v -----------------------------------------------------------------------------------------------------
+        load_stage_chunks<T, N, 2, AUX_NT>(rs, lane, P);
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            team_barrier();
+#pragma unroll 1
+            for (int t = 1; t <= K; ++t) {
+                get_coef((t - 1) & 1);
+                if (t > 1) {
+#pragma unroll
+                    for (int q = 0; q < X::QT; ++q) {
+                        T v4[4];
+                        get4((t - 1) & 1, X::QC + X::QVX + q, v4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int e = X::E_T0 + 4 * q + i;
+                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
+                        }
+                    }
+                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QVX + X::QT, d); P[pidx<N>(7, 7)] = d[0]; }
+#pragma unroll
+                    for (int i = 9; i < 12; ++i) P[pidx<N>(i, i)] += dc.qd[2];
+                }
+                cov_stage_v<T, N>(P, k, dc.qd);
+                if (t < K) {
+#pragma unroll
+                    for (int q = 0; q < X::QV; ++q) put4(t & 1, X::QC + q, P + X::E_V0 + 4 * q);
+                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(3, 3)], P[pidx<N>(5, 5)], T(0), T(0) }; put4(t & 1, X::QC + X::QV, d); }
+                }
+                team_barrier();
+            }
+            gather_put_stage<T, N, 1>(gmem, P);
+            team_barrier();
+            if (f + 1 == F) break;
+            team_barrier();
+            gather_get_stage_chunks<T, N, 2>(gmem, P);
+        }
+    } else {
+        // ---- rows p -----------------------------------------------------------------------------------------------------
+        load_stage_chunks<T, N, 1, AUX_NT>(rs, lane, P);
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            team_barrier();
+#pragma unroll 1
+            for (int t = 1; t <= K; ++t) {
+                get_coef((t - 1) & 1);
+                if (t > 1) {
+#pragma unroll
+                    for (int q = 0; q < X::QV; ++q) {
+                        T v4[4];
+                        get4((t - 1) & 1, X::QC + q, v4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int e = X::E_V0 + 4 * q + i;
+                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 3 && cov_row<N>(e) < 6) P[e] = v4[i];
+                        }
+                    }
+                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QV, d); P[pidx<N>(3, 3)] = d[0]; P[pidx<N>(5, 5)] = d[1]; }
+                }
+                cov_stage_p<T, N>(P, k);
+                team_barrier();
+            }
+            gather_put_stage<T, N, 0>(gmem, P);
+            team_barrier();
+            if (f + 1 == F) break;
+            team_barrier();
+            gather_get_stage_chunks<T, N, 1>(gmem, P);
+        }
+    }
+}
+
+// =================================================================================
 // correct: one-shot information form, roles share the fold, the rows of W and the elements of P
 // =================================================================================
 // Lam, b -> Z (6 x 6, row-major) and gamma (6):  Lam = Lc Lc' (a pivot that is not clearly positive relative to its

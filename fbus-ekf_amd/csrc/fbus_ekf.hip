@@ -119,6 +119,7 @@ struct fbus_ekf {
     // team kernels (several waves per 64-filter tile, ekf_team.hpp): 0 = chosen per launch from the wave count, 1 = never,
     // 2..4 = always with that many roles (fbus_ekf_set_team, FBUS_TEAM_PREDICT / FBUS_TEAM_CORRECT at create)
     int team_predict = 0, team_correct = 0;
+    int team_frame = 0;               // FBUS_TEAM_FRAME: 0 = follows team_predict, 1 = never, 2 = always
     fbus_params prm{};
     HostConst hc;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -255,6 +256,17 @@ int team_roles_predict(const fbus_ekf* h, int K)
     if (K > 1) return tiles <= 512 ? 4 : 1;
     return tiles <= 256 ? 3 : 1;
 }
+// fused frame / frame window (frames_team_kernel: the predict_n pipeline + the correct on the nominal role).  Follows the predict
+// setting (fbus_ekf_set_team: 1 = never, 2..4 = always); FBUS_TEAM_FRAME=1|2 overrides.  One workgroup of four waves holds a
+// whole CU's registers, so the automatic choice ends where the tiles outnumber the CUs.
+bool team_frames(const fbus_ekf* h, int mode)
+{
+    if (h->dtype != 32 || h->prm.cov_form == FBUS_COV_JOSEPH) return false;
+    if (mode != MODE_NEAREST && mode != MODE_STACKED) return false;
+    if (h->team_frame == 1 || (h->team_frame == 0 && h->team_predict == 1)) return false;
+    if (h->team_frame == 2 || h->team_predict >= 2) return true;
+    return (h->B + 63) / 64 <= 256;
+}
 int team_roles_correct(const fbus_ekf* h, int mode)
 {
     if (h->dtype != 32 || h->team_correct <= 1 || h->prm.cov_form == FBUS_COV_JOSEPH) return 1;
@@ -364,6 +376,12 @@ int launch_frame_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, con
     if constexpr (sizeof(T) == 4) {
     const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
     h->records_warm = true;
+    if (team_frames(h, mode) && K <= 255) {
+        const unsigned char kc1 = (unsigned char)K;
+        launch_frames_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, 1, &kc1, (const T*)accel, (const T*)gyro, (const T*)dt,
+                                      dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+                                      (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+    } else
     launch_frame_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, (const T*)accel, (const T*)gyro, (const T*)dt,
                             dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
                             h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
@@ -386,6 +404,11 @@ int launch_frames_t(fbus_ekf_t h, int F, const unsigned char* kc, const void* ac
     if constexpr (sizeof(T) == 4) {
         const int ev = timing_begin(h, FBUS_KERNEL_FRAME, F);
         h->records_warm = true;
+        if (team_frames(h, mode))
+            launch_frames_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, F, kc, (const T*)accel, (const T*)gyro, (const T*)dt,
+                                          dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+                                          (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+        else
         launch_frames_k<T, N, D>(h->stream, (T*)h->recs, h->B, F, kc, (const T*)accel, (const T*)gyro, (const T*)dt,
                                  dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
                                  h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
@@ -724,6 +747,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (const char* e = std::getenv("FBUS_PREDICT_POLICY")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->predict_policy_force = v; }
     if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
     if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
+    if (const char* e = std::getenv("FBUS_TEAM_FRAME")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->team_frame = v; }
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
     h->device = device;

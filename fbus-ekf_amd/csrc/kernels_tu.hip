@@ -228,7 +228,23 @@ void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids,
     else { if (joint) FBUS_LAUNCH_CT(true, 4); else FBUS_LAUNCH_CT(false, 4); }
 #undef FBUS_LAUNCH_CT
 }
+template <typename T, int N, int D>
+void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro,
+                          const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode,
+                          const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
+{
+    const int tiles = (B + 63) / 64;
+    FrameCounts kc;
+    for (int f = 0; f < FBUS_MAX_WINDOW_FRAMES; ++f) kc.k[f] = f < F ? kcount[f] : 0;
+    hipLaunchKernelGGL((frames_team_kernel<T, N, D>), dim3(tiles), dim3(256), 0, s, recs, B, F, kc, accel, gyro, dt, dt_stride, M,
+                       ids, pos, quat, mode, skip, applied, dc);
+}
 #define FBUS_INST(D)                                                                                                   \
+    template void launch_frames_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const unsigned char*, \
+                                                                const FBUS_TU_T*, const FBUS_TU_T*, const FBUS_TU_T*, int, \
+                                                                int, const int*, const FBUS_TU_T*, const FBUS_TU_T*, int, \
+                                                                const unsigned char*, unsigned char*,                  \
+                                                                const DevConst<FBUS_TU_T>&);                           \
     template void launch_predict_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, int, int, const FBUS_TU_T*, \
                                                                  const FBUS_TU_T*, const FBUS_TU_T*, int,              \
                                                                  const DevConst<FBUS_TU_T>&);                          \

@@ -234,3 +234,112 @@ def test_team_kernels_parity_at_the_config_batch_sizes(B):
     for i in (2, 3):
         e = parity_errors(team[i], one[i])
         assert e["literal"] < 3e-6 and e["sigma"] < 1e-5 and e["cov_block"] < 1e-5 and e["prev_equal"], (B, i, e)
+
+
+def _window_inputs(B, dialect, n, M, kcount, seed_off=0):
+    prm, nom, rot, P, prev = _batch(B, dialect, n, seed_off)
+    Kt = sum(kcount)
+    acc, gyr = synth.imu_samples(seed_off, seed_off + B, 0, Kt, nom)
+    frames = [synth.marker_frame(seed_off, seed_off + B, f, M, nom, prm) for f in range(len(kcount))]
+    ids = np.stack([f[0] for f in frames]); pos = _r32(np.stack([f[1] for f in frames])); quat = _r32(np.stack([f[2] for f in frames]))
+    return prm, nom, rot, P, prev, _r32(acc), _r32(gyr), ids, pos, quat
+
+
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("mode", [capi.MODE_NEAREST, capi.MODE_STACKED])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_team_frame_window_equals_one_wave_window(dialect, mode, n):
+    """frames_team_kernel (predict_n pipeline on four roles, MeasureUpdate on the nominal role, rows handed over in LDS) against
+    the one-wave frame-window kernel on the same window -- ragged batch, a frame without IMU samples, an invisible marker, an
+    unknown marker id, masked filters -- to FMA-contraction level; the one-wave result goes through the oracle gate; and the same
+    window as F single-frame launches of the team kernel (records through HBM instead of LDS in between) is bit-equal"""
+    import torch
+    B, M = 7 * 64 - 5, 4
+    kcount = [7, 0, 6, 3]
+    F, Kt = len(kcount), sum(kcount)
+    prm, nom, rot, P, prev, acc, gyr, ids, pos, quat = _window_inputs(B, dialect, n, M, kcount, seed_off=5)
+    ids[1, 5] = -1
+    ids[2, 6, :] = 9
+    skip = np.zeros((F, B), np.uint8); skip[2, 11] = 1; skip[3, 12] = 1
+    dev = torch.device("cuda:0")
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_acc, d_gyr, d_dt = dd(acc), dd(gyr), dd(np.full(Kt, DT[0]))
+    d_ids, d_pos, d_quat, d_skip = torch.from_numpy(ids).to(dev), dd(pos), dd(quat), torch.from_numpy(skip).to(dev)
+    out, app = {}, {}
+    for what in ("one-wave", "team", "team-by-frame"):
+        with BatchedFilter(B, prm, nstate=n) as flt:
+            flt.set_team(1 if what == "one-wave" else 4, 1)
+            flt.set_state(nom, rot, P, prev)
+            if what == "team-by-frame":
+                k0 = 0
+                for f, K in enumerate(kcount):
+                    flt.frame(d_acc[k0:k0 + K] if K else None, d_gyr[k0:k0 + K] if K else None, d_dt[k0:k0 + K] if K else None,
+                              d_ids[f], d_pos[f], d_quat[f], mode, skip=d_skip[f], fused=True)
+                    k0 += K
+            else:
+                flt.frames(kcount, d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, mode, skip=d_skip)
+            flt.sync()
+            out[what], app[what] = flt.get_state(), flt.applied().copy()
+    assert np.array_equal(app["team"], app["one-wave"]) and np.array_equal(app["team-by-frame"], app["one-wave"])
+    for k in range(4):
+        assert np.array_equal(out["team"][k], out["team-by-frame"][k]), f"window vs frame by frame, element {k}"
+    eng = OracleEngine(B, dialect, n)
+    eng.set_state(nom, rot, P, prev)
+    k0 = 0
+    for f, K in enumerate(kcount):
+        for k in range(K):
+            eng.predict(acc[k0 + k], gyr[k0 + k], DT)
+        k0 += K
+        ids_f = ids[f].copy(); ids_f[skip[f] == 1] = -1
+        eng.correct(ids_f, pos[f], quat[f], mode)
+    for what in ("one-wave", "team"):
+        e = parity_errors(out[what], eng.get_state())
+        print(f"[parity] {what} frame window d{dialect} mode {mode} N {n}: literal {e['literal']:.2e} sigma {e['sigma']:.2e} "
+              f"plain {e['plain']:.2e} cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
+        assert e["literal"] <= 5e-5 and e["sigma"] <= 5e-5 and e["plain"] <= 2e-2, (what, e)
+        assert e["cov"] <= 2e-5 and e["cov_block"] <= 2e-4 and e["asym"] == 0 and e["prev_equal"], (what, e)
+    # team against one-wave: contraction differences of single steps (1 ulp), carried through 16 ImuUpdates and 4 MeasureUpdates
+    e = parity_errors(out["team"], out["one-wave"])
+    print(f"[team vs one-wave] literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} cov {e['cov']:.2e} "
+          f"cov block-wise {e['cov_block']:.2e}")
+    assert e["literal"] <= 5e-5 and e["sigma"] <= 5e-5 and e["cov"] <= 1e-5 and e["cov_block"] <= 1e-4 and e["prev_equal"], e
+
+
+def test_team_frame_is_the_default_for_small_batches_and_long_windows():
+    """the launcher's choice: up to 256 tiles the fused frame / frame window entry points run the team kernel (bit-equal to the
+    forced team run); a full 64-frame window with per-filter dt, K up to 9, against the oracle on a strided subset"""
+    import torch
+    B, M, n, dialect = 16384, 4, 18, 0
+    rng = np.random.default_rng(11)
+    kcount = [int(x) for x in rng.integers(0, 10, 64)]
+    F, Kt = len(kcount), sum(kcount)
+    prm, nom, rot, P, prev, acc, gyr, ids, pos, quat = _window_inputs(B, dialect, n, M, kcount, seed_off=9)
+    dtb = _r32(rng.uniform(0.003, 0.007, (Kt, B)))
+    dev = torch.device("cuda:0")
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_acc, d_gyr, d_dt = dd(acc), dd(gyr), dd(dtb)
+    d_ids, d_pos, d_quat = torch.from_numpy(ids).to(dev), dd(pos), dd(quat)
+    out = {}
+    for what in ("default", "team"):
+        with BatchedFilter(B, prm, nstate=n) as flt:
+            if what == "team":
+                flt.set_team(4, 1)
+            flt.set_state(nom, rot, P, prev)
+            flt.frames(kcount, d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, capi.MODE_STACKED)
+            flt.sync()
+            out[what] = flt.get_state()
+    for k in range(4):
+        assert np.array_equal(out["default"][k], out["team"][k]), "default policy at 16 384 filters is not the team frame kernel"
+    sub = np.arange(0, B, B // 61)
+    eng = OracleEngine(len(sub), dialect, n)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    k0 = 0
+    for f, K in enumerate(kcount):
+        for k in range(K):
+            eng.predict(acc[k0 + k][sub], gyr[k0 + k][sub], dtb[k0 + k][sub])
+        k0 += K
+        eng.correct(ids[f][sub], pos[f][sub], quat[f][sub], capi.MODE_STACKED)
+    e = parity_errors(tuple(x[sub] for x in out["team"]), eng.get_state())
+    print(f"[parity] team frame window, 64 frames / {Kt} steps: literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} "
+          f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
+    assert e["literal"] <= 2e-4 and e["sigma"] <= 2e-4 and e["cov"] <= 5e-5 and e["asym"] == 0 and e["prev_equal"], e
