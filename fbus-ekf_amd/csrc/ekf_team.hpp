@@ -390,361 +390,6 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
 }
 
 // =================================================================================
-// frame window: F x { K_f ImuUpdates, one MeasureUpdate } per launch, the predict pipeline of predict_n_team_kernel with
-// the correct on the nominal role
-// =================================================================================
-// The fused frame / frame window kernels of ekf_kernels.hpp keep one filter's whole record in one lane from the first load
-// to the last store; below 1024 tiles most SIMDs idle while each wave walks through ~1150 instructions per ImuUpdate.
-// Here the K_f predict steps of a frame run as the four-role pipeline above.  Behind the last step of a frame every
-// covariance role leaves the rows it owns in LDS; the nominal role -- which finished its last predict_nominal one iteration
-// earlier and folded the frame's markers while the others were still busy -- collects them next to the predict-invariant
-// part it loaded at entry, runs the MeasureUpdate exactly as the one-wave kernels do (PoseFold -> joint_update: same
-// device functions, same operands), and hands the posterior back through LDS for the next frame (or streams it to the
-// record after the last one).  Per frame: K_f + 3 barriers, 43 + 43 16-byte cells per lane through LDS.
-//
-// LDS: the two exchange buffers of the predict pipeline (2 x 30 cells per lane).  The 43 gather cells are laid over them
-// but around the 7 coefficient cells at the head of each buffer -- the nominal role writes the next frame's first
-// coefficients while the covariance roles are still reading the posterior.
-template <typename T, int N>
-struct FrameXch {
-    using X = StepXch<T, N>;
-    static constexpr int NCC = Rec<T, N>::NCOVP / 4;
-    static constexpr int HALF = X::PER_SLOT - X::QC;                       // free cells per buffer behind the coefficients
-    static_assert(NCC <= 2 * HALF, "the gather cells do not fit around the coefficient cells");
-    static constexpr int cell(int cc) { return cc < HALF ? X::QC + cc : X::PER_SLOT + X::QC + (cc - HALF); }
-};
-
-// the elements stage S owns -> their gather cells (whole chunks as one 16-byte write)
-template <typename T, int N, int S>
-__device__ __forceinline__ void gather_put_stage(u32x4* mem, const T* P)
-{
-    using TR = TeamRec<T, N>;
-    static_for<0, TR::NCC>([&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-        constexpr int m = TR::write_mask(S, cc);
-        if constexpr (m != 0) {
-            u32x4* c = mem + FrameXch<T, N>::cell(cc) * 64;
-            const unsigned* w = reinterpret_cast<const unsigned*>(P + 4 * cc);
-            if constexpr (m == 0xF) *c = u32x4{ w[0], w[1], w[2], w[3] };
-            else {
-                unsigned* e = reinterpret_cast<unsigned*>(c);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if ((m >> k) & 1) e[k] = w[k];
-            }
-        }
-    });
-}
-// everything the three stages own, from the gather cells into the full covariance (the rest of P stays as it is)
-template <typename T, int N>
-__device__ __forceinline__ void gather_get_predicted(const u32x4* mem, T* P)
-{
-    using TR = TeamRec<T, N>;
-    static_for<0, TR::NCC>([&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-        constexpr int m = TR::write_mask(0, cc) | TR::write_mask(1, cc) | TR::write_mask(2, cc);
-        if constexpr (m != 0) {
-            const u32x4 v = mem[FrameXch<T, N>::cell(cc) * 64];
-            const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((m >> k) & 1) P[4 * cc + k] = e[k];
-        }
-    });
-}
-// the whole covariance -> gather cells (nominal role, behind the correct) and the chunks a stage set reads <- gather cells
-template <typename T, int N>
-__device__ __forceinline__ void gather_put_all(u32x4* mem, const T* P)
-{
-    static_for<0, TeamRec<T, N>::NCC>([&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-        const unsigned* w = reinterpret_cast<const unsigned*>(P + 4 * cc);
-        mem[FrameXch<T, N>::cell(cc) * 64] = u32x4{ w[0], w[1], w[2], w[3] };
-    });
-}
-template <typename T, int N, int STAGES>
-__device__ __forceinline__ void gather_get_stage_chunks(const u32x4* mem, T* P)
-{
-    using TR = TeamRec<T, N>;
-    static_for<0, TR::NCC>([&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-        if constexpr (TR::reads_chunk(STAGES, cc)) {
-            const u32x4 v = mem[FrameXch<T, N>::cell(cc) * 64];
-            const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) P[4 * cc + k] = e[k];
-        }
-    });
-}
-
-template <typename T, int N, int DIALECT>
-__global__ void __launch_bounds__(256)
-frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __restrict__ accel, const T* __restrict__ gyro,
-                   const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
-                   const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
-                   unsigned char* __restrict__ applied, DevConst<T> dc)
-{
-    using L = Lay<N>;
-    using RC = Rec<T, N>;
-    using X = StepXch<T, N>;
-    constexpr int CN = RC::CH_NOM;
-    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned tile = blockIdx.x;
-    const int b0 = (int)(tile * 64u + lane);
-    const bool live = b0 < B;
-    const int b = live ? b0 : (int)(tile * 64u);          // lanes past B run along on the tile's first filter, store nothing
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
-    __shared__ u32x4 xmem[2 * X::PER_SLOT * 64];
-    __shared__ MarkerLDS<T> tbl;
-    const X xch{ xmem + lane };
-    u32x4* const gmem = xmem + lane;
-    T nom[L::NNOM], P[RC::NCOVP];
-    PredictCoef<T> k;
-    auto put4 = [&](int buf, int q, const T* src) {
-        u32x4 v;
-        T* e = reinterpret_cast<T*>(&v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = src[i];
-        *xch.cell(buf, q) = v;
-    };
-    auto get4 = [&](int buf, int q, T* dst) {
-        const u32x4 v = *xch.cell(buf, q);
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = e[i];
-    };
-    auto get_coef = [&](int buf) {
-        T c[28];
-#pragma unroll
-        for (int q = 0; q < X::QC; ++q) get4(buf, q, c + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { k.A[i] = c[i]; k.Bm[i] = c[9 + i]; k.Th[i] = c[18 + i]; }
-        k.dt = c[27];
-    };
-    if (role == 3) {
-        // ---- nominal state + MeasureUpdate ----------------------------------------------------------------------------
-        {
-            // the marker map -> LDS by this wave alone (it is the only reader; LDS operations of one wave are in order)
-            constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(T) * FBUS_MAX_MARKERS * MK_STRIDE / 16;
-            constexpr int PI = (NI + 63) / 64, PM = (NM + 63) / 64;
-            const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
-            const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
-            u32x4 vi[PI], vm[PM];
-#pragma unroll
-            for (int q = 0; q < PI; ++q) { const int i = (int)lane + q * 64; vi[q] = si[i < NI ? i : 0]; }
-#pragma unroll
-            for (int q = 0; q < PM; ++q) { const int i = (int)lane + q * 64; vm[q] = sm[i < NM ? i : 0]; }
-            order_fence();
-            load_chunks<T, N, 0, CN, AUX_NT>(rs, lane, nom);
-            load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, lane, P);
-            order_fence();
-            u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
-            u32x4* dm = reinterpret_cast<u32x4*>(tbl.mk);
-#pragma unroll
-            for (int q = 0; q < PI; ++q) { const int i = (int)lane + q * 64; if (i < NI) di[i] = vi[q]; }
-#pragma unroll
-            for (int q = 0; q < PM; ++q) { const int i = (int)lane + q * 64; if (i < NM) dm[i] = vm[q]; }
-            order_fence();
-        }
-        int k0 = 0, last_used = 0;
-#pragma unroll 1
-        for (int f = 0; f < F; ++f) {
-            const int K = kc.k[f];
-            const T* fa = accel + (size_t)k0 * B * 3;
-            const T* fg = gyro + (size_t)k0 * B * 3;
-            const T* fd = dt + (size_t)k0 * (dt_stride ? B : 1);
-            k0 += K;
-            ImuSample<T> cur;
-            if (K > 0) cur.load(fa, fg, fd, dt_stride, 0, B, b);
-            // the frame's measurements (FBUS_EKF.m:193-204 ; filter.cpp:232-235): chosen and folded in iteration K below
-            const size_t fo = (size_t)f * B + b;
-            int first = 0, last = (M > 0 && live && !(skip && skip[fo])) ? M : 0;
-            int new_prev = -1, used = 0;
-            const int* my_ids = ids + fo * M;
-            const T* my_pos = pos + fo * M * 3;
-            const T* my_quat = quat + fo * M * 4;
-            InfoAcc<T> acc;
-            PoseFold<T, N, DIALECT> fold;
-            fold.clear();
-            MarkerCommon<T, N> mc;
-#pragma unroll 1
-            for (int t = 0; t <= K; ++t) {
-                if (t < K) {
-                    predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, k);
-                    if (t + 1 < K) cur.load(fa, fg, fd, dt_stride, t + 1, B, b);
-                    T c[28];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) { c[i] = k.A[i]; c[9 + i] = k.Bm[i]; c[18 + i] = k.Th[i]; }
-                    c[27] = k.dt;
-#pragma unroll
-                    for (int q = 0; q < X::QC; ++q) put4(t & 1, q, c + 4 * q);
-                } else {
-                    // the nominal state is final: marker choice (MeasureUpdate.m:51-60 ; filter.cpp:639-664) and the fold of
-                    // the rows, while the covariance roles run the frame's last step
-                    if (last > 0 && mode == MODE_NEAREST) {
-                        const int prev_id = (DIALECT == DIALECT_CPP) ? (int)P[L::OFF_PREV - L::OFF_COV] : 0;
-                        int min_i = -1, prev_i = -1;
-                        T min_d = T(10), prev_d = T(0);
-                        for (int i = 0; i < M; ++i) {
-                            const int id = my_ids[i];
-                            if (id < 0) continue;
-                            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
-                            const T dist = fb_sqrt(x * x + y * y + z * z);
-                            if (dist < min_d) { min_d = dist; min_i = i; }
-                            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
-                        }
-                        if (min_i >= 0 && DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0))
-                            min_i = prev_i;
-                        int slot = -1, id = -1;
-                        if (min_i >= 0) {
-                            id = my_ids[min_i];
-                            slot = (id >= 0 && id <= FBUS_MAX_MARKER_ID) ? (int)tbl.id2slot[id] : -1;
-                        }
-                        if (slot < 0) { first = last = 0; }
-                        else {
-                            if (DIALECT == DIALECT_CPP) new_prev = id;
-                            first = min_i; last = min_i + 1;
-                        }
-                    }
-                    mc.build(nom, dc);
-                    for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
-                        MarkerGroup<T, FBUS_MARKER_GROUP> mg;
-                        mg.fetch(my_ids, my_pos, my_quat, i0, last);
-                        mg.resolve(tbl);
-#pragma unroll
-                        for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
-                            if (mg.slot[g] < 0) continue;
-                            fold.add(nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
-                            ++used;
-                        }
-                    }
-                    if (used > 0) fold.finish(acc, nom, dc, mc);
-                }
-                team_barrier();
-            }
-            team_barrier();                                          // the predicted rows are in the gather cells
-            gather_get_predicted<T, N>(gmem, P);
-            const bool last_frame = f + 1 == F;
-            T dx[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) dx[i] = T(0);
-            if (used > 0) {
-                joint_update<T, N, COV_SIMPLE>(P, dx, acc);
-                inject<T, N>(nom, dx);
-                if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
-            }
-            last_used = used;
-            if (!last_frame) {
-                gather_put_all<T, N>(gmem, P);
-                team_barrier();                                      // the posterior is in the gather cells
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (live) {
-            if (M > 0 && F > 0) applied[b0] = last_used > 0 ? 1 : 0;
-            store_chunks<T, N, 0, CN, FBUS_X_FRAME_ST>(rs, lane, nom);
-            store_chunks<T, N, CN, RC::NCH, FBUS_X_FRAME_ST>(rs, lane, P);
-        }
-    } else if (role == 2) {
-        // ---- rows theta (+ Q diagonals) ---------------------------------------------------------------------------------
-        load_stage_chunks<T, N, 4, AUX_NT>(rs, lane, P);
-#pragma unroll 1
-        for (int f = 0; f < F; ++f) {
-            const int K = kc.k[f];
-            team_barrier();                                                  // iteration 0
-#pragma unroll 1
-            for (int t = 1; t <= K; ++t) {
-                get_coef((t - 1) & 1);
-                cov_stage_th<T, N>(P, k, dc.qd);
-                if (t < K) {
-#pragma unroll
-                    for (int q = 0; q < X::QT; ++q) put4(t & 1, X::QC + X::QVX + q, P + X::E_T0 + 4 * q);
-                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(7, 7)], T(0), T(0), T(0) }; put4(t & 1, X::QC + X::QVX + X::QT, d); }
-                }
-                team_barrier();
-            }
-            gather_put_stage<T, N, 2>(gmem, P);
-            team_barrier();
-            if (f + 1 == F) break;
-            team_barrier();
-            gather_get_stage_chunks<T, N, 4>(gmem, P);
-        }
-    } else if (role == 0) {
-        // ---- rows v -----------------------------------------------------------------------------------------------------
-        load_stage_chunks<T, N, 2, AUX_NT>(rs, lane, P);
-#pragma unroll 1
-        for (int f = 0; f < F; ++f) {
-            const int K = kc.k[f];
-            team_barrier();
-#pragma unroll 1
-            for (int t = 1; t <= K; ++t) {
-                get_coef((t - 1) & 1);
-                if (t > 1) {
-#pragma unroll
-                    for (int q = 0; q < X::QT; ++q) {
-                        T v4[4];
-                        get4((t - 1) & 1, X::QC + X::QVX + q, v4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int e = X::E_T0 + 4 * q + i;
-                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
-                        }
-                    }
-                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QVX + X::QT, d); P[pidx<N>(7, 7)] = d[0]; }
-#pragma unroll
-                    for (int i = 9; i < 12; ++i) P[pidx<N>(i, i)] += dc.qd[2];
-                }
-                cov_stage_v<T, N>(P, k, dc.qd);
-                if (t < K) {
-#pragma unroll
-                    for (int q = 0; q < X::QV; ++q) put4(t & 1, X::QC + q, P + X::E_V0 + 4 * q);
-                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(3, 3)], P[pidx<N>(5, 5)], T(0), T(0) }; put4(t & 1, X::QC + X::QV, d); }
-                }
-                team_barrier();
-            }
-            gather_put_stage<T, N, 1>(gmem, P);
-            team_barrier();
-            if (f + 1 == F) break;
-            team_barrier();
-            gather_get_stage_chunks<T, N, 2>(gmem, P);
-        }
-    } else {
-        // ---- rows p -----------------------------------------------------------------------------------------------------
-        load_stage_chunks<T, N, 1, AUX_NT>(rs, lane, P);
-#pragma unroll 1
-        for (int f = 0; f < F; ++f) {
-            const int K = kc.k[f];
-            team_barrier();
-#pragma unroll 1
-            for (int t = 1; t <= K; ++t) {
-                get_coef((t - 1) & 1);
-                if (t > 1) {
-#pragma unroll
-                    for (int q = 0; q < X::QV; ++q) {
-                        T v4[4];
-                        get4((t - 1) & 1, X::QC + q, v4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int e = X::E_V0 + 4 * q + i;
-                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 3 && cov_row<N>(e) < 6) P[e] = v4[i];
-                        }
-                    }
-                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QV, d); P[pidx<N>(3, 3)] = d[0]; P[pidx<N>(5, 5)] = d[1]; }
-                }
-                cov_stage_p<T, N>(P, k);
-                team_barrier();
-            }
-            gather_put_stage<T, N, 0>(gmem, P);
-            team_barrier();
-            if (f + 1 == F) break;
-            team_barrier();
-            gather_get_stage_chunks<T, N, 1>(gmem, P);
-        }
-    }
-}
-
-// =================================================================================
 // correct: one-shot information form, roles share the fold, the rows of W and the elements of P
 // =================================================================================
 // Lam, b -> Z (6 x 6, row-major) and gamma (6):  Lam = Lc Lc' (a pivot that is not clearly positive relative to its
@@ -1188,6 +833,504 @@ correct_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ 
     } else if (role == 1) update_store(std::integral_constant<int, 1>{});
     else if (NR > 2 && role == 2) update_store(std::integral_constant<int, (NR > 2 ? 2 : 0)>{});
     else if (NR > 3) update_store(std::integral_constant<int, (NR > 3 ? 3 : 0)>{});
+}
+
+
+// =================================================================================
+// frame window: F x { K_f ImuUpdates, one MeasureUpdate } per launch -- the predict pipeline of predict_n_team_kernel and the
+// one-shot correct of correct_team_kernel, the covariance handed from phase to phase through LDS
+// =================================================================================
+// The fused frame / frame window kernels of ekf_kernels.hpp keep one filter's whole record in one lane from the first load
+// to the last store; below 1024 tiles most SIMDs idle while each wave walks through ~1150 instructions per ImuUpdate and
+// ~2100 per MeasureUpdate.  Here (FBUS_EKF.m:151-210 ; filter.cpp:229-235):
+//   predict phase   the four-role pipeline of predict_n_team_kernel.  Behind the last step of a frame every covariance role
+//                   writes the rows it owns to the LDS "image" of the covariance (43 cells of 16 bytes per lane); role v adds
+//                   the predict-invariant part (rows ba, bg, g off the diagonal, the previous marker id), of which it holds
+//                   a current copy anyway.
+//   correct phase   the nominal role finished its last predict_nominal one iteration earlier and has chosen the marker(s)
+//                   and folded their rows (PoseFold -> Lam, b: 27 values, left in LDS) while the others were on the last
+//                   step.  Every role reads the image, solves the 6 x 6 problem (info_gain, redundantly), computes its rows
+//                   of W = V Z, exchanges them, applies P -= W W' to its chunks (CorrectPlan<N, 4>) and writes them back
+//                   to the image; the nominal role also forms dx = W gamma and injects it.
+//   next frame      every role reads from the image what its predict stage reads; after the last frame the roles store
+//                   their chunks of the record.
+// K_f + 4 barriers per frame.  The posterior is that of the sequential passes (see correct_team_kernel).  LDS: the image
+// and W are laid over the exchange buffers of the predict pipeline -- 77 cells per lane + the marker map = 80 KiB, and at
+// most 256 registers: two workgroups per CU.
+template <typename T, int N>
+struct FrameImage {
+    using X = StepXch<T, N>;
+    static constexpr int NCC = Rec<T, N>::NCOVP / 4;
+    static constexpr int QW = CorrectXch<N, 4>::QW;
+    static constexpr int C_W = 0;                                 // W (correct phase); the head of exchange buffer 0 otherwise
+    static constexpr int C_IMG = QW;                              // [NCC] the covariance between the phases
+    // Lam (21), b (6), the new previous-marker id: written while the exchange buffers are in use and read while W and the
+    // image are: behind all three
+    static constexpr int C_LAM = (2 * X::PER_SLOT > QW + NCC) ? 2 * X::PER_SLOT : QW + NCC;
+    static constexpr int CELLS = C_LAM + 7;
+    // the first coefficients of the next frame (buffer 0, cells [0, QC)) are written while the image is being read
+    static_assert(X::QC <= QW, "the coefficient cells of buffer 0 must lie inside the W area");
+    static constexpr size_t bytes() { return (size_t)CELLS * 64 * 16 + sizeof(MarkerLDS<T>); }
+    // the elements role v leaves in the image behind a frame's last step: its own (stage 1), the predict-invariant ones
+    // (stage 3) and the padding behind the packed covariance (the previous marker id lives there)
+    // ... which is why role v reads the padding chunk as well (N = 15: a chunk of its own that no stage reads)
+    static constexpr bool pad_chunk(int cc) { return 4 * cc + 3 >= N * (N + 1) / 2; }
+    static constexpr int v_mask(int cc)
+    {
+        int m = TeamRec<T, N>::write_mask(1, cc) | TeamRec<T, N>::write_mask(3, cc);
+        for (int q = 0; q < 4; ++q)
+            if (4 * cc + q >= N * (N + 1) / 2) m |= 1 << q;
+        return m;
+    }
+};
+
+template <typename T, int N, int DIALECT>
+__global__ void __launch_bounds__(256, 2)
+frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __restrict__ accel, const T* __restrict__ gyro,
+                    const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
+                    const T* __restrict__ quat, int mode, const unsigned char* __restrict__ skip,
+                    unsigned char* __restrict__ applied, DevConst<T> dc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    using X = StepXch<T, N>;
+    using FI = FrameImage<T, N>;
+    using PL = CorrectPlan<N, 4>;
+    constexpr int CN = RC::CH_NOM, NN = PL::NN, NP = N * (N + 1) / 2, NCC = FI::NCC;
+    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned tile = blockIdx.x;
+    const int b0 = (int)(tile * 64u + lane);
+    const bool live = b0 < B;
+    const int b = live ? b0 : (int)(tile * 64u);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    extern __shared__ u32x4 dyn_lds[];
+    u32x4* const xmem = dyn_lds;
+    MarkerLDS<T>& tbl = *reinterpret_cast<MarkerLDS<T>*>(dyn_lds + FI::CELLS * 64);
+    const X xch{ xmem + lane };
+    u32x4* const img = xmem + FI::C_IMG * 64 + lane;              // cell cc of this lane: img[cc * 64]
+    float* const lam = reinterpret_cast<float*>(xmem + FI::C_LAM * 64 + lane);   // value i of this lane: cell i / 4, slot i % 4
+    u32x4* const wx = xmem + FI::C_W * 64 + lane;                 // W, a-major, QW cells
+    T nom[L::NNOM], P[RC::NCOVP];
+    PredictCoef<T> k;
+    auto put4 = [&](int buf, int q, const T* src) {
+        u32x4 v;
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = src[i];
+        *xch.cell(buf, q) = v;
+    };
+    auto get4 = [&](int buf, int q, T* dst) {
+        const u32x4 v = *xch.cell(buf, q);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = e[i];
+    };
+    auto get_coef = [&](int buf) {
+        T c[28];
+#pragma unroll
+        for (int q = 0; q < X::QC; ++q) get4(buf, q, c + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { k.A[i] = c[i]; k.Bm[i] = c[9 + i]; k.Th[i] = c[18 + i]; }
+        k.dt = c[27];
+    };
+    auto lam_at = [&](int i) -> float& { return lam[(i / 4) * 256 + (i % 4)]; };
+    // the elements a role owns behind the predict phase -> image (whole chunks as one 16-byte write); S = its stage
+    auto img_put_stage = [&](auto s_) {
+        constexpr int S = decltype(s_)::value;
+        using TR = TeamRec<T, N>;
+        static_for<0, TR::NCC>([&](auto cc_) {
+            constexpr int cc = decltype(cc_)::value;
+            constexpr int m = (S == 1) ? FI::v_mask(cc) : TR::write_mask(S, cc);
+            if constexpr (m != 0) {
+                const unsigned* w = reinterpret_cast<const unsigned*>(P + 4 * cc);
+                if constexpr (m == 0xF) img[cc * 64] = u32x4{ w[0], w[1], w[2], w[3] };
+                else {
+                    unsigned* e = reinterpret_cast<unsigned*>(img + cc * 64);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((m >> q) & 1) e[q] = w[q];
+                }
+            }
+        });
+    };
+    auto img_get_stage_chunks = [&](auto st_) {
+        constexpr int STAGES = decltype(st_)::value;
+        using TR = TeamRec<T, N>;
+        static_for<0, TR::NCC>([&](auto cc_) {
+            constexpr int cc = decltype(cc_)::value;
+            if constexpr (TR::reads_chunk(STAGES, cc) || (STAGES == 2 && FI::pad_chunk(cc))) {
+                const u32x4 v = img[cc * 64];
+                const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[4 * cc + q] = e[q];
+            }
+        });
+    };
+    auto img_get_all = [&]() {
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+            const u32x4 v = img[cc * 64];
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P[4 * cc + q] = e[q];
+        }
+    };
+    // ---- the correct phase of one role (CR = its part in CorrectPlan<N, 4>; part 0 is the nominal role) --------------------
+    // returns with this role's chunks [ch0(CR), ch0(CR + 1)) of P updated in registers; dx for part 0
+    auto correct_part = [&](auto cr_, T* dx) {
+        constexpr int CR = decltype(cr_)::value;
+        img_get_all();
+        InfoAcc<T> acc;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) acc.Lam[i] = lam_at(i);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc.b[i] = lam_at(21 + i);
+        const T np = lam_at(27);
+        T PJ[21];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int c = i; c < 6; ++c) PJ[lidx(i, c)] = P[pidx<N>(jcol(i), jcol(c))];
+        T Z[36], gam[6];
+        info_gain<T>(acc, PJ, Z, gam);
+        constexpr int I0 = PL::row0(CR), I1 = PL::row0(CR + 1);
+        static_for<0, 6>([&](auto a_) {
+            constexpr int a = decltype(a_)::value;
+            T wa[NN];
+            if constexpr (PackedMath<T, N>::on) {
+#pragma unroll
+                for (int i = I0; i < I1; i += 2) {
+                    PairAcc<N> pa;
+#pragma unroll
+                    for (int k2 = 0; k2 < 6; ++k2) pa.add(P, Z[6 * k2 + a], jcol(k2), i);
+                    const f32x2 v = pa.get();
+                    wa[i] = v.x; wa[i + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = I0; i < I1; ++i) {
+                    T s2 = T(0);
+#pragma unroll
+                    for (int k2 = 0; k2 < 6; ++k2) s2 += P[pidx<N>(i, jcol(k2))] * Z[6 * k2 + a];
+                    wa[i] = s2;
+                }
+                if constexpr ((I1 & 1) != 0) wa[I1] = T(0);
+            }
+            float* wl = reinterpret_cast<float*>(wx);
+            constexpr int I1P = (I1 + 1) / 2 * 2;
+#pragma unroll
+            for (int i = I0; i < I1P; i += 2) {
+                const int e = a * NN + i;
+                *reinterpret_cast<f32x2*>(wl + (e / 4) * 256 + (e % 4)) = f32x2{ wa[i], wa[i + 1] };
+            }
+        });
+        team_barrier();                                             // all of W is in LDS
+        T Wt[FI::QW * 4];
+#pragma unroll
+        for (int q = 0; q < FI::QW; ++q) {
+            const u32x4 v = wx[q * 64];
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Wt[4 * q + i] = e[i];
+        }
+        constexpr int C0 = PL::ch0(CR), C1 = PL::ch0(CR + 1);
+        static_for<C0, C1>([&](auto cc_) {
+            constexpr int cc = decltype(cc_)::value;
+            static_for<0, 2>([&](auto h_) {
+                constexpr int e = 4 * cc + 2 * decltype(h_)::value;
+                if constexpr (e + 1 < NP && PackedMath<T, N>::on && cov_row<N>(e) == cov_row<N>(e + 1) && cov_col<N>(e + 1) == cov_col<N>(e) + 1 &&
+                              cov_col<N>(e) % 2 == 0) {
+                    constexpr int i = cov_row<N>(e), c = cov_col<N>(e);
+                    f32x2 v = f32x2{ P[e], P[e + 1] };
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) v -= Wt[a * NN + i] * f32x2{ Wt[a * NN + c], Wt[a * NN + c + 1] };
+                    P[e] = v.x; P[e + 1] = v.y;
+                } else {
+                    static_for<0, 2>([&](auto s_) {
+                        constexpr int e1 = e + decltype(s_)::value;
+                        if constexpr (e1 < NP) {
+                            constexpr int i = cov_row<N>(e1), c = cov_col<N>(e1);
+                            T v = P[e1];
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) v -= Wt[a * NN + i] * Wt[a * NN + c];
+                            P[e1] = v;
+                        }
+                    });
+                }
+            });
+        });
+        if constexpr (C1 == NCC) {
+            if (np >= T(0)) P[L::OFF_PREV - L::OFF_COV] = np;       // filter.cpp:675
+        }
+        if constexpr (CR == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                T s2 = Wt[i] * gam[0];
+#pragma unroll
+                for (int a = 1; a < 6; ++a) s2 += Wt[a * NN + i] * gam[a];
+                dx[i] = s2;
+            }
+        }
+    };
+    auto img_put_part = [&](auto cr_) {
+        constexpr int CR = decltype(cr_)::value;
+        constexpr int C0 = PL::ch0(CR), C1 = PL::ch0(CR + 1);
+#pragma unroll
+        for (int cc = C0; cc < C1; ++cc) {
+            const unsigned* w = reinterpret_cast<const unsigned*>(P + 4 * cc);
+            img[cc * 64] = u32x4{ w[0], w[1], w[2], w[3] };
+        }
+    };
+    auto store_part = [&](auto cr_, bool from_image) {
+        constexpr int CR = decltype(cr_)::value;
+        constexpr int C0 = PL::ch0(CR), C1 = PL::ch0(CR + 1);
+        if (from_image) {
+#pragma unroll
+            for (int cc = C0; cc < C1; ++cc) {
+                const u32x4 v = img[cc * 64];
+                const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[4 * cc + q] = e[q];
+            }
+        }
+        if (live) store_chunks<T, N, CN + C0, CN + C1, FBUS_X_FRAME_ST>(rs, lane, P + 4 * C0);
+    };
+    // what a covariance role does behind the last predict step of a frame (CR: its part of the correct); true = leave the kernel
+    auto frame_tail = [&](auto cr_, auto stage_, auto reads_, int f) -> bool {
+        img_put_stage(stage_);
+        team_barrier();                                             // the predicted covariance is in the image
+        const bool last_frame = f + 1 == F;
+        if (M > 0) {
+            T dx_unused[1];
+            correct_part(cr_, dx_unused);
+            if (last_frame) { store_part(cr_, false); return true; }
+            img_put_part(cr_);
+            team_barrier();                                         // the posterior is in the image
+        } else if (last_frame) {
+            store_part(cr_, true);
+            return true;
+        }
+        img_get_stage_chunks(reads_);
+        return false;
+    };
+    using I0_ = std::integral_constant<int, 0>; using I1_ = std::integral_constant<int, 1>; using I2_ = std::integral_constant<int, 2>;
+    using I3_ = std::integral_constant<int, 3>; using I4_ = std::integral_constant<int, 4>;
+    if (role == 3) {
+        // ---- nominal state, the fold of the measurements, part 0 of the correct ------------------------------------------
+        {
+            constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(T) * FBUS_MAX_MARKERS * MK_STRIDE / 16;
+            constexpr int PI = (NI + 63) / 64, PM = (NM + 63) / 64;
+            const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
+            const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
+            u32x4 vi[PI], vm[PM];
+#pragma unroll
+            for (int q = 0; q < PI; ++q) { const int i = (int)lane + q * 64; vi[q] = si[i < NI ? i : 0]; }
+#pragma unroll
+            for (int q = 0; q < PM; ++q) { const int i = (int)lane + q * 64; vm[q] = sm[i < NM ? i : 0]; }
+            order_fence();
+            load_chunks<T, N, 0, CN, AUX_NT>(rs, lane, nom);
+            constexpr int C_PREV = CN + (L::OFF_PREV - L::OFF_COV) / 4;          // the chunk of the previous marker id
+            load_chunks<T, N, C_PREV, C_PREV + 1, AUX_NT>(rs, lane, P + 4 * (C_PREV - CN));
+            order_fence();
+            u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
+            u32x4* dm = reinterpret_cast<u32x4*>(tbl.mk);
+#pragma unroll
+            for (int q = 0; q < PI; ++q) { const int i = (int)lane + q * 64; if (i < NI) di[i] = vi[q]; }
+#pragma unroll
+            for (int q = 0; q < PM; ++q) { const int i = (int)lane + q * 64; if (i < NM) dm[i] = vm[q]; }
+            order_fence();
+        }
+        T prev_val = P[L::OFF_PREV - L::OFF_COV];                    // the C++ dialect's previous marker id, carried here
+        int k0 = 0, last_used = 0;
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            const T* fa = accel + (size_t)k0 * B * 3;
+            const T* fg = gyro + (size_t)k0 * B * 3;
+            const T* fd = dt + (size_t)k0 * (dt_stride ? B : 1);
+            k0 += K;
+            ImuSample<T> cur;
+            if (K > 0) cur.load(fa, fg, fd, dt_stride, 0, B, b);
+            const size_t fo = (size_t)f * B + b;
+            int first = 0, last = (M > 0 && live && !(skip && skip[fo])) ? M : 0;
+            int new_prev = -1, used = 0;
+            const int* my_ids = ids + fo * M;
+            const T* my_pos = pos + fo * M * 3;
+            const T* my_quat = quat + fo * M * 4;
+#pragma unroll 1
+            for (int t = 0; t <= K; ++t) {
+                if (t < K) {
+                    predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, k);
+                    if (t + 1 < K) cur.load(fa, fg, fd, dt_stride, t + 1, B, b);
+                    T c[28];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { c[i] = k.A[i]; c[9 + i] = k.Bm[i]; c[18 + i] = k.Th[i]; }
+                    c[27] = k.dt;
+#pragma unroll
+                    for (int q = 0; q < X::QC; ++q) put4(t & 1, q, c + 4 * q);
+                } else if (M > 0) {
+                    // the nominal state is final: marker choice (MeasureUpdate.m:51-60 ; filter.cpp:639-664) and the fold of the
+                    // rows -> Lam, b in LDS, while the covariance roles run the frame's last step
+                    if (last > 0 && mode == MODE_NEAREST) {
+                        const int prev_id = (DIALECT == DIALECT_CPP) ? (int)prev_val : 0;
+                        int min_i = -1, prev_i = -1;
+                        T min_d = T(10), prev_d = T(0);
+                        for (int i = 0; i < M; ++i) {
+                            const int id = my_ids[i];
+                            if (id < 0) continue;
+                            const T x = my_pos[3 * i], y = my_pos[3 * i + 1], z = my_pos[3 * i + 2];
+                            const T dist = fb_sqrt(x * x + y * y + z * z);
+                            if (dist < min_d) { min_d = dist; min_i = i; }
+                            if (DIALECT == DIALECT_CPP && id == prev_id) { prev_d = dist; prev_i = i; }
+                        }
+                        if (min_i >= 0 && DIALECT == DIALECT_CPP && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0))
+                            min_i = prev_i;
+                        int slot = -1, id = -1;
+                        if (min_i >= 0) {
+                            id = my_ids[min_i];
+                            slot = (id >= 0 && id <= FBUS_MAX_MARKER_ID) ? (int)tbl.id2slot[id] : -1;
+                        }
+                        if (slot < 0) { first = last = 0; }
+                        else {
+                            if (DIALECT == DIALECT_CPP) new_prev = id;
+                            first = min_i; last = min_i + 1;
+                        }
+                    }
+                    InfoAcc<T> acc;
+                    PoseFold<T, N, DIALECT> fold;
+                    fold.clear();
+                    MarkerCommon<T, N> mc;
+                    mc.build(nom, dc);
+                    for (int i0 = first; i0 < last; i0 += FBUS_MARKER_GROUP) {
+                        MarkerGroup<T, FBUS_MARKER_GROUP> mg;
+                        mg.fetch(my_ids, my_pos, my_quat, i0, last);
+                        mg.resolve(tbl);
+#pragma unroll
+                        for (int g = 0; g < FBUS_MARKER_GROUP; ++g) {
+                            if (mg.slot[g] < 0) continue;
+                            fold.add(nom, dc, mc, mg.mk[g], mg.yp[g], mg.yq[g]);
+                            ++used;
+                        }
+                    }
+                    fold.finish(acc, nom, dc, mc);
+                    if (used == 0) { acc.clear(); new_prev = -1; }
+#pragma unroll
+                    for (int i = 0; i < 21; ++i) lam_at(i) = acc.Lam[i];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) lam_at(21 + i) = acc.b[i];
+                    lam_at(27) = (T)new_prev;
+                    if (new_prev >= 0) prev_val = (T)new_prev;
+                }
+                team_barrier();
+            }
+            team_barrier();                                          // the predicted covariance is in the image
+            const bool last_frame = f + 1 == F;
+            last_used = used;
+            if (M > 0) {
+                T dx[N];
+                correct_part(I0_{}, dx);
+                if (used > 0) inject<T, N>(nom, dx);
+                if (last_frame) { store_part(I0_{}, false); break; }
+                img_put_part(I0_{});
+                team_barrier();                                      // the posterior is in the image
+            } else if (last_frame) {
+                store_part(I0_{}, true);
+                break;
+            }
+        }
+        if (live) {
+            if (M > 0 && F > 0) applied[b0] = last_used > 0 ? 1 : 0;
+            store_chunks<T, N, 0, CN, FBUS_X_FRAME_ST>(rs, lane, nom);
+        }
+    } else if (role == 2) {
+        // ---- rows theta (+ Q diagonals); part 3 of the correct -----------------------------------------------------------------
+        load_stage_chunks<T, N, 4, AUX_NT>(rs, lane, P);
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            team_barrier();                                                  // iteration 0
+#pragma unroll 1
+            for (int t = 1; t <= K; ++t) {
+                get_coef((t - 1) & 1);
+                cov_stage_th<T, N>(P, k, dc.qd);
+                if (t < K) {
+#pragma unroll
+                    for (int q = 0; q < X::QT; ++q) put4(t & 1, X::QC + X::QVX + q, P + X::E_T0 + 4 * q);
+                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(7, 7)], T(0), T(0), T(0) }; put4(t & 1, X::QC + X::QVX + X::QT, d); }
+                }
+                team_barrier();
+            }
+            if (frame_tail(I3_{}, I2_{}, I4_{}, f)) break;
+        }
+    } else if (role == 0) {
+        // ---- rows v; part 1 of the correct -----------------------------------------------------------------------------------------
+        load_stage_chunks<T, N, 2, AUX_NT>(rs, lane, P);
+        static_for<0, NCC>([&](auto cc_) {
+            constexpr int cc = decltype(cc_)::value;
+            if constexpr (FI::pad_chunk(cc) && !TeamRec<T, N>::reads_chunk(2, cc)) load_chunks<T, N, CN + cc, CN + cc + 1, AUX_NT>(rs, lane, P + 4 * cc);
+        });
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            team_barrier();
+#pragma unroll 1
+            for (int t = 1; t <= K; ++t) {
+                get_coef((t - 1) & 1);
+                if (t > 1) {
+#pragma unroll
+                    for (int q = 0; q < X::QT; ++q) {
+                        T v4[4];
+                        get4((t - 1) & 1, X::QC + X::QVX + q, v4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int e = X::E_T0 + 4 * q + i;
+                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
+                        }
+                    }
+                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QVX + X::QT, d); P[pidx<N>(7, 7)] = d[0]; }
+#pragma unroll
+                    for (int i = 9; i < 12; ++i) P[pidx<N>(i, i)] += dc.qd[2];
+                }
+                cov_stage_v<T, N>(P, k, dc.qd);
+                if (t < K) {
+#pragma unroll
+                    for (int q = 0; q < X::QV; ++q) put4(t & 1, X::QC + q, P + X::E_V0 + 4 * q);
+                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(3, 3)], P[pidx<N>(5, 5)], T(0), T(0) }; put4(t & 1, X::QC + X::QV, d); }
+                }
+                team_barrier();
+            }
+            if (frame_tail(I1_{}, I1_{}, I2_{}, f)) break;
+        }
+    } else {
+        // ---- rows p; part 2 of the correct -----------------------------------------------------------------------------------------
+        load_stage_chunks<T, N, 1, AUX_NT>(rs, lane, P);
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            const int K = kc.k[f];
+            team_barrier();
+#pragma unroll 1
+            for (int t = 1; t <= K; ++t) {
+                get_coef((t - 1) & 1);
+                if (t > 1) {
+#pragma unroll
+                    for (int q = 0; q < X::QV; ++q) {
+                        T v4[4];
+                        get4((t - 1) & 1, X::QC + q, v4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int e = X::E_V0 + 4 * q + i;
+                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 3 && cov_row<N>(e) < 6) P[e] = v4[i];
+                        }
+                    }
+                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QV, d); P[pidx<N>(3, 3)] = d[0]; P[pidx<N>(5, 5)] = d[1]; }
+                }
+                cov_stage_p<T, N>(P, k);
+                team_barrier();
+            }
+            if (frame_tail(I2_{}, I0_{}, I1_{}, f)) break;
+        }
+    }
 }
 
 }  // namespace

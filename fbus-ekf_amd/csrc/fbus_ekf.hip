@@ -257,15 +257,16 @@ int team_roles_predict(const fbus_ekf* h, int K)
     return tiles <= 256 ? 3 : 1;
 }
 // fused frame / frame window (frames_team_kernel: the predict_n pipeline + the correct on the nominal role).  Follows the predict
-// setting (fbus_ekf_set_team: 1 = never, 2..4 = always); FBUS_TEAM_FRAME=1|2 overrides.  One workgroup of four waves holds a
-// whole CU's registers, so the automatic choice ends where the tiles outnumber the CUs.
+// setting (fbus_ekf_set_team: 1 = never, 2..4 = always); FBUS_TEAM_FRAME=1|2 overrides.  Two workgroups of four waves fit a CU
+// (80 KiB of LDS, 250 registers), so the automatic choice ends at 512 tiles (profiles/logs/r03_team_frame.txt: +8 % / +12 % at
+// 32 768 filters, 0.8x at 40 960).
 bool team_frames(const fbus_ekf* h, int mode)
 {
     if (h->dtype != 32 || h->prm.cov_form == FBUS_COV_JOSEPH) return false;
     if (mode != MODE_NEAREST && mode != MODE_STACKED) return false;
     if (h->team_frame == 1 || (h->team_frame == 0 && h->team_predict == 1)) return false;
     if (h->team_frame == 2 || h->team_predict >= 2) return true;
-    return (h->B + 63) / 64 <= 256;
+    return (h->B + 63) / 64 <= 512;
 }
 int team_roles_correct(const fbus_ekf* h, int mode)
 {

@@ -236,7 +236,12 @@ void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned c
     const int tiles = (B + 63) / 64;
     FrameCounts kc;
     for (int f = 0; f < FBUS_MAX_WINDOW_FRAMES; ++f) kc.k[f] = f < F ? kcount[f] : 0;
-    hipLaunchKernelGGL((frames_team_kernel<T, N, D>), dim3(tiles), dim3(256), 0, s, recs, B, F, kc, accel, gyro, dt, dt_stride, M,
+    // the image of the covariance, W and the exchange buffers: 80 KiB of LDS per workgroup, above the 64 KiB a kernel gets without asking
+    constexpr size_t lds = FrameImage<T, N>::bytes();
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&frames_team_kernel<T, N, D>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL((frames_team_kernel<T, N, D>), dim3(tiles), dim3(256), lds, s, recs, B, F, kc, accel, gyro, dt, dt_stride, M,
                        ids, pos, quat, mode, skip, applied, dc);
 }
 #define FBUS_INST(D)                                                                                                   \

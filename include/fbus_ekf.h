@@ -136,7 +136,7 @@ int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream);
 /* Waves per 64-filter tile of predict / correct (fp32; no reference counterpart -- the reference runs one filter on one
  * thread, filter.cpp:190-250).  0 (default): chosen per launch from what was measured faster (predict: 3 waves per tile up to
  * 16 384 filters, predict_n: 4 up to 32 768, correct: always one; the fused frame / frame window entry points follow the
- * predict setting: four waves per tile up to 16 384 filters -- DESIGN.md section 4.5); 1: always one wave per tile;
+ * predict setting: four waves per tile up to 32 768 filters -- DESIGN.md section 4.5); 1: always one wave per tile;
  * 2..4: always that many ("team" kernels).  Results agree to fp32 rounding whatever the choice (predict: the same arithmetic, 1 ulp on a few
  * covariance elements where the compiler fuses a different product; correct: the team kernel applies the stacked update in
  * one step, the one-wave kernel as six sequential rank-1 passes), so a caller that compares runs BIT FOR BIT across batch

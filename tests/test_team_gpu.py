@@ -306,7 +306,7 @@ def test_team_frame_window_equals_one_wave_window(dialect, mode, n):
 
 
 def test_team_frame_is_the_default_for_small_batches_and_long_windows():
-    """the launcher's choice: up to 256 tiles the fused frame / frame window entry points run the team kernel (bit-equal to the
+    """the launcher's choice: up to 512 tiles the fused frame / frame window entry points run the team kernel (bit-equal to the
     forced team run); a full 64-frame window with per-filter dt, K up to 9, against the oracle on a strided subset"""
     import torch
     B, M, n, dialect = 16384, 4, 18, 0
