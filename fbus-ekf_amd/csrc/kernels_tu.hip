@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include "ekf_kernels.hpp"
 #include "ekf_team.hpp"
+#include <atomic>
 #include "ekf_launch.hpp"
 
 #ifndef FBUS_TU_T
@@ -238,9 +239,16 @@ void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned c
     for (int f = 0; f < FBUS_MAX_WINDOW_FRAMES; ++f) kc.k[f] = f < F ? kcount[f] : 0;
     // the image of the covariance, W and the exchange buffers: 80 KiB of LDS per workgroup, above the 64 KiB a kernel gets without asking
     constexpr size_t lds = FrameImage<T, N>::bytes();
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&frames_team_kernel<T, N, D>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
+    // (a per-device attribute: asked for once on every device this process launches the kernel on)
+    static std::atomic<unsigned long long> asked{ 0 };
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(asked.load(std::memory_order_relaxed) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&frames_team_kernel<T, N, D>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            asked.fetch_or(bit, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL((frames_team_kernel<T, N, D>), dim3(tiles), dim3(256), lds, s, recs, B, F, kc, accel, gyro, dt, dt_stride, M,
                        ids, pos, quat, mode, skip, applied, dc);
 }

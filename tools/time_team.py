@@ -45,5 +45,20 @@ for B in Bs:
                 rows["predict_n K=8"].append(float("nan"))
             rows["correct stacked M=4"].append(timed(flt, capi.KERNEL_CORRECT, lambda: flt.correct(d_ids, d_pos, d_quat, 1), 200))
             rows["correct nearest M=4"].append(timed(flt, capi.KERNEL_CORRECT, lambda: flt.correct(d_ids, d_pos, d_quat, 0), 200))
+        # fused frame (K = 7 + stacked correct) and a window of 8 such frames: one-wave kernels (set_team 1) and the team kernel (4)
+        kc = [7] * 8
+        acc8, gyr8 = synth.imu_samples(0, B, 0, 56, nom)
+        w_acc, w_gyr, w_dt = up(acc8), up(gyr8), up(np.full(56, 0.005))
+        fr = [synth.marker_frame(0, B, f, 4, nom, prm) for f in range(8)]
+        w_ids = torch.from_numpy(np.stack([x[0] for x in fr])).to(dev)
+        w_pos, w_quat = up(np.stack([x[1] for x in fr])), up(np.stack([x[2] for x in fr]))
+        rows["fused frame K=7 M=4"], rows["frame window 8x(7+1)"] = [], []
+        for r in (1, 2, 3, 4):
+            if r in (1, 4):
+                flt.set_team(r, 1)
+                rows["fused frame K=7 M=4"].append(timed(flt, capi.KERNEL_FRAME, lambda: flt.frame(d_acc[:7], d_gyr[:7], d_dt[:7], d_ids, d_pos, d_quat, 1, fused=True), 60))
+                rows["frame window 8x(7+1)"].append(timed(flt, capi.KERNEL_FRAME, lambda: flt.frames(kc, w_acc, w_gyr, w_dt, w_ids, w_pos, w_quat, 1), 20))
+            else:
+                rows["fused frame K=7 M=4"].append(float("nan")); rows["frame window 8x(7+1)"].append(float("nan"))
     for name, v in rows.items():
         print(f"{B:<8d} {name:<22s} " + "".join(f"{x:<14.2f}" for x in v))
