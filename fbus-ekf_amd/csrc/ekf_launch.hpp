@@ -52,6 +52,13 @@ void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned c
                           const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode,
                           const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
 template <typename T, int N, int D>
+void launch_corners_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int geometry,
+                           int roles, T size, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc,
+                           const VisConst<T>& vc);
+template <typename T, int N, int D>
+void launch_pixels_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, T size,
+                          T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc);
+template <typename T, int N, int D>
 void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode, int roles,
                            const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
 

@@ -1333,4 +1333,164 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
     }
 }
 
+
+// =================================================================================
+// correct from stereo corners / from corner pixels (stacked mode): the markers of a filter divided among the roles
+// =================================================================================
+// correct_corners_kernel is bound by the triangulation (two refracted rays per camera and corner, vision.cpp:472-618) and the
+// 12 row folds of every marker: ~2600 VALU instructions per marker on ONE wave per tile, the 4 markers of BASELINE config 3 one
+// after the other on a quarter of the chip's SIMDs; correct_pixels_kernel likewise by the flat-port projections of its
+// reprojection rows (~550 instructions each, 4 or 8 per marker).  The markers are independent until their rows meet in the
+// 6 x 6 information matrix: role r folds markers r, r + NR, ...; roles 1.. leave their partial sums in LDS (PoseFold's 26
+// values, or the 27 of the information matrix and vector for the pixel rows) and are done; role 0 adds them in role order and
+// applies the update as the one-wave kernels do (joint_factor / joint_apply, the covariance requested behind the fold).
+// Same device functions; the sums of the fold are taken in a different order (fp32 rounding).  Stacked mode, simple
+// covariance form, fp32.
+template <typename T, int N, int NR, bool PIXELS>
+__global__ void __launch_bounds__(64 * NR)
+correct_meas_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
+                         const T* __restrict__ right, int geometry, T size, T r_pix, const unsigned char* __restrict__ skip,
+                         unsigned char* __restrict__ applied, DevConst<T> dc, VisConst<T> vc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    using Fold = PoseFold<T, N, DIALECT_MATLAB>;         // position-type rows only, as in correct_corners_kernel
+    constexpr int NT = 64 * NR, NPART = PIXELS ? 28 : Fold::NVAL;
+    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned tile = blockIdx.x;
+    const int b = (int)(tile * 64u + lane);
+    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
+    const int bc = b < B ? b : (int)(tile * 64u);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    __shared__ MarkerLDS<T> tbl;
+    __shared__ float part_mem[(NR - 1) * NPART * 64];
+    struct Meas { int id; T l[12], r[8]; };
+    const bool c3d = !PIXELS && geometry == VIS_CORNERS3D;
+    const int lw = c3d ? 12 : 8;
+    const bool has_right = PIXELS ? right != nullptr : !c3d;
+    auto fetch = [&](int i, Meas& m) __attribute__((always_inline)) {
+        const size_t o = (size_t)bc * M + i;
+        m.id = ids[o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m.l[j] = ld_meas(left + o * lw + j);
+#pragma unroll
+        for (int j = 8; j < 12; ++j) m.l[j] = c3d ? ld_meas(left + o * lw + j) : T(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m.r[j] = has_right ? ld_meas(right + o * 8 + j) : T(0);
+    };
+    auto corner = [&](const Meas& m, int c, T* out) __attribute__((always_inline)) {
+        if (geometry == VIS_CORNERS3D) { out[0] = m.l[3 * c]; out[1] = m.l[3 * c + 1]; out[2] = m.l[3 * c + 2]; return; }
+        if (geometry == VIS_REFRACTIVE) refraction_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
+        else pinhole_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
+    };
+    Meas cur, nxt;
+    T pqr[L::NPQR];
+    {
+        // the marker map -> LDS (all threads), this role's first marker, the pose part of the nominal state
+        constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(T) * FBUS_MAX_MARKERS * MK_STRIDE / 16;
+        constexpr int PI = (NI + NT - 1) / NT, PM = (NM + NT - 1) / NT;
+        const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
+        const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
+        u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
+        u32x4* dm = reinterpret_cast<u32x4*>(tbl.mk);
+        u32x4 vi[PI], vm[PM];
+#pragma unroll
+        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; vi[q] = si[i < NI ? i : 0]; }
+#pragma unroll
+        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; vm[q] = sm[i < NM ? i : 0]; }
+        order_fence();
+        if (M > 0) fetch((int)role < M ? (int)role : M - 1, cur);
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, lane, pqr);
+        order_fence();
+#pragma unroll
+        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; if (i < NI) di[i] = vi[q]; }
+#pragma unroll
+        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; if (i < NM) dm[i] = vm[q]; }
+        order_fence();
+    }
+    team_barrier();                                              // the marker map is in LDS
+    Fold fold;
+    fold.clear();
+    InfoAcc<T> acc;
+    acc.clear();
+    T npix = T(0);                                               // markers folded into acc (pixel rows)
+    MarkerCommon<T, N> mc;
+    if constexpr (!PIXELS) mc.build(pqr, dc);
+    const T w_pix = PIXELS ? T(1) / r_pix : T(0);
+    const int last = live ? M : 0;
+#pragma unroll 1
+    for (int i = (int)role; i < last; i += NR) {
+        fetch(i + NR < M ? i + NR : M - 1, nxt);                // always a fresh load (no conditional merge of the two records)
+        const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
+        const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
+        if (slot >= 0) {
+            T mk[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) mk[q] = tbl.mk[slot * MK_STRIDE + q];
+            if constexpr (PIXELS) {
+                pixel_info<T, N>(acc, pqr, dc, vc, mk, cur.l, right ? cur.r : nullptr, size, w_pix);
+                npix += T(1);
+            } else {
+                T C[12];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) corner(cur, c, C + 3 * c);
+                fold.add_corners(pqr, dc, mc, mk, C, size);
+            }
+        }
+        cur = nxt;
+    }
+    // partial sums through LDS: value i of role r at part_mem[((r - 1) * NPART + i) * 64 + lane]
+    if (role != 0) {
+        float* part = part_mem + ((role - 1) * NPART) * 64 + lane;
+        if constexpr (PIXELS) {
+#pragma unroll
+            for (int i = 0; i < 21; ++i) part[i * 64] = acc.Lam[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) part[(21 + i) * 64] = acc.b[i];
+            part[27 * 64] = npix;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPART; ++i) part[i * 64] = fold.at(i);
+        }
+        team_barrier();
+        return;
+    }
+    team_barrier();                                              // the other roles' partial sums are in LDS
+#pragma unroll
+    for (int r = 1; r < NR; ++r) {
+        const float* part = part_mem + ((r - 1) * NPART) * 64 + lane;
+        if constexpr (PIXELS) {
+#pragma unroll
+            for (int i = 0; i < 21; ++i) acc.Lam[i] += part[i * 64];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc.b[i] += part[(21 + i) * 64];
+            npix += part[27 * 64];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPART; ++i) fold.at(i) += part[i * 64];
+        }
+    }
+    const int used = PIXELS ? (int)npix : (int)fold.cnt;         // (add_corners counts 4 points per marker)
+    if (!live || used == 0) { if (b < B) applied[b] = 0; return; }
+    InfoFactors<T> fac;
+    if constexpr (!PIXELS) fold.finish(acc, pqr, dc, mc);
+    joint_factor<T>(acc, fac);
+    order_fence();
+    T P[RC::NCOVP];
+    T dx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dx[i] = T(0);
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
+    joint_apply<T, N, COV_SIMPLE>(P, dx, fac);
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
+    inject<T, N>(nom, dx);
+    store_chunks<T, N, 0, RC::CH_PQ>(rs, lane, nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, lane, nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, lane, P);
+    applied[b] = 1;
+}
+
 }  // namespace

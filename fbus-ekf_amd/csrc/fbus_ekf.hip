@@ -256,6 +256,17 @@ int team_roles_predict(const fbus_ekf* h, int K)
     if (K > 1) return tiles <= 512 ? 4 : 1;
     return tiles <= 256 ? 3 : 1;
 }
+// correct from stereo corners (stacked mode) / from corner pixels (correct_meas_team_kernel: the markers of a filter divided among the
+// roles; these kernels are bound by the VALU work per marker -- ~2600 instructions of triangulation and row folds, 4 or 8 flat-port
+// projections).  fbus_ekf_set_team's correct_roles: 1 = never,
+// 2 = two roles, 3..4 = four; 0 = four up to 256 tiles, two up to 512 (measured: profiles/logs/r03_team_corners.txt).
+int team_roles_corners(const fbus_ekf* h, int mode, int M)
+{
+    if (h->dtype != 32 || h->prm.cov_form == FBUS_COV_JOSEPH || mode != MODE_STACKED || M < 2 || h->team_correct == 1) return 1;
+    if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
+    const int tiles = (h->B + 63) / 64;
+    return tiles <= 256 ? 4 : (tiles <= 512 ? 2 : 1);
+}
 // fused frame / frame window (frames_team_kernel: the predict_n pipeline + the correct on the nominal role).  Follows the predict
 // setting (fbus_ekf_set_team: 1 = never, 2..4 = always); FBUS_TEAM_FRAME=1|2 overrides.  Two workgroups of four waves fit a CU
 // (80 KiB of LDS, 250 registers), so the automatic choice ends at 512 tiles (profiles/logs/r03_team_frame.txt: +8 % / +12 % at
@@ -557,6 +568,14 @@ int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
     h->records_warm = true;
+    const int roles = team_roles_corners(h, mode, M);
+    if constexpr (sizeof(T) == 4) {
+        if (roles > 1)
+            launch_corners_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry,
+                                           roles, (T)h->prm.marker_size, (const unsigned char*)skip, h->d_applied, make_dc<T>(h),
+                                           make_vc<T>(h));
+    }
+    if (roles <= 1 || sizeof(T) != 4)
     launch_corners_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry,
                               mode, h->prm.cov_form == FBUS_COV_JOSEPH, (T)h->prm.marker_size, (const unsigned char*)skip,
                               h->d_applied, make_dc<T>(h), make_vc<T>(h));
@@ -570,6 +589,14 @@ int launch_correct_pixels_t(fbus_ekf_t h, int M, const int32_t* ids, const void*
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
     h->records_warm = true;
+    const int roles = team_roles_corners(h, MODE_STACKED, M);          // the pixel form is always stacked
+    if constexpr (sizeof(T) == 4) {
+        if (roles > 1)
+            launch_pixels_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, roles,
+                                          (T)h->prm.marker_size, (T)h->prm.r_pix, (const unsigned char*)skip, h->d_applied,
+                                          make_dc<T>(h), make_vc<T>(h));
+    }
+    if (roles <= 1 || sizeof(T) != 4)
     launch_pixels_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right,
                              h->prm.cov_form == FBUS_COV_JOSEPH, (T)h->prm.marker_size, (T)h->prm.r_pix,
                              (const unsigned char*)skip, h->d_applied, make_dc<T>(h), make_vc<T>(h));

@@ -252,7 +252,40 @@ void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned c
     hipLaunchKernelGGL((frames_team_kernel<T, N, D>), dim3(tiles), dim3(256), lds, s, recs, B, F, kc, accel, gyro, dt, dt_stride, M,
                        ids, pos, quat, mode, skip, applied, dc);
 }
+template <typename T, int N, int D>
+void launch_corners_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int geometry,
+                           int roles, T size, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc,
+                           const VisConst<T>& vc)
+{
+    const int tiles = (B + 63) / 64;
+    if (roles >= 3)
+        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 4, false>), dim3(tiles), dim3(256), 0, s, recs, B, M, ids, left, right,
+                           geometry, size, T(0), skip, applied, dc, vc);
+    else
+        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 2, false>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right,
+                           geometry, size, T(0), skip, applied, dc, vc);
+}
+template <typename T, int N, int D>
+void launch_pixels_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, T size,
+                          T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc)
+{
+    const int tiles = (B + 63) / 64;
+    if (roles >= 3)
+        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 4, true>), dim3(tiles), dim3(256), 0, s, recs, B, M, ids, left, right, 0,
+                           size, r_pix, skip, applied, dc, vc);
+    else
+        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 2, true>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right, 0,
+                           size, r_pix, skip, applied, dc, vc);
+}
 #define FBUS_INST(D)                                                                                                   \
+    template void launch_corners_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,        \
+                                                                 const FBUS_TU_T*, const FBUS_TU_T*, int, int, FBUS_TU_T, \
+                                                                 const unsigned char*, unsigned char*,                 \
+                                                                 const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&); \
+    template void launch_pixels_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,         \
+                                                                const FBUS_TU_T*, const FBUS_TU_T*, int, FBUS_TU_T, FBUS_TU_T, \
+                                                                const unsigned char*, unsigned char*,                  \
+                                                                const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&); \
     template void launch_frames_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const unsigned char*, \
                                                                 const FBUS_TU_T*, const FBUS_TU_T*, const FBUS_TU_T*, int, \
                                                                 int, const int*, const FBUS_TU_T*, const FBUS_TU_T*, int, \

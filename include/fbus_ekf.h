@@ -137,7 +137,8 @@ int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream);
  * thread, filter.cpp:190-250).  0 (default): chosen per launch from what was measured faster (predict: 3 waves per tile up to
  * 16 384 filters, predict_n: 4 up to 32 768, correct: always one; the fused frame / frame window entry points follow the
  * predict setting: four waves per tile up to 32 768 filters -- DESIGN.md section 4.5); 1: always one wave per tile;
- * 2..4: always that many ("team" kernels).  Results agree to fp32 rounding whatever the choice (predict: the same arithmetic, 1 ulp on a few
+ * 2..4: always that many ("team" kernels).  correct_roles also governs fbus_ekf_correct_corners (stacked mode) and fbus_ekf_correct_pixels,
+ * whose markers are divided among the waves of a tile: 0 = four waves up to 16 384 filters, two up to 32 768; 1 = never; 2 = two; 3..4 = four.  Results agree to fp32 rounding whatever the choice (predict: the same arithmetic, 1 ulp on a few
  * covariance elements where the compiler fuses a different product; correct: the team kernel applies the stacked update in
  * one step, the one-wave kernel as six sequential rank-1 passes), so a caller that compares runs BIT FOR BIT across batch
  * sizes or shard layouts pins the value. */

@@ -52,8 +52,11 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo):
     eng.set_state(*now)
     ok[skip == 1] = 0
     assert ok[0] == 0 and ok[1] == 0 and ok[2:][skip[2:] == 0].all()
-    for dtype in (64, 32):
+    # fp32 at this batch size runs correct_meas_team_kernel by default (the markers divided among four waves per tile);
+    # the one-wave kernel (set_team correct_roles = 1) and the two-role form go through the same gate
+    for dtype, roles in ((64, 0), (32, 0), (32, 1), (32, 2)):
         with BatchedFilter(B, prm, dtype=dtype) as flt:
+            flt.set_team(0, roles)
             flt.set_state(nom, rot, P, prev)
             flt.correct_pixels(ids, left, rgt, skip)
             got = flt.get_state()
@@ -61,7 +64,7 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo):
         untouched = ok == 0
         assert np.array_equal(got[0][untouched], nom[untouched].astype(got[0].dtype))
         e = parity_errors(got, eng.get_state())
-        print(f"[parity] correct_pixels dialect {dialect} {'stereo' if stereo else 'left'} fp{dtype}: literal {e['literal']:.2e} "
+        print(f"[parity] correct_pixels dialect {dialect} {'stereo' if stereo else 'left'} fp{dtype} correct_roles {roles}: literal {e['literal']:.2e} "
               f"sigma-aware {e['sigma']:.2e} ({e['sigma_block']}) plain {e['plain']:.2e} ({e['plain_block']}) cov {e['cov']:.2e} "
               f"cov block-wise {e['cov_block']:.2e}")
         if dtype == 64:

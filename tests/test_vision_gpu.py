@@ -183,20 +183,24 @@ def test_correct_from_stereo_corners_matches_oracle(dialect, mode, dtype, mult):
         pp, qq, RR = replay.pose_from_marker(np.concatenate([[ids[b, m]], pos, quat]), prm)
         nom[b, 0:3], nom[b, 6:10], rot[b] = pp + rng.normal(0, 0.005, 3), qq, RR.ravel()
     nom, rot = r32(nom), r32(rot)
-    with BatchedFilter(B, prm, dtype=dtype) as flt:
-        flt.set_state(nom, rot, P, prev)
-        flt.correct_corners(ids, left, right, capi.VIS_REFRACTIVE, mode)
-        g = flt.get_state()
-        ap = flt.applied()
     eng = OracleEngine(B, dialect, 18)
     eng.set_state(nom, rot, P, prev)
     ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids, corners, size, mode)
-    assert (ap == ok).all() and ok[0] == 0 and ok[2:].all()
-    assert (g[3] == eng.prev).all()
-    assert state_rel_err(g[0], eng.nominal, eng.P)[0] <= STATE_TOL * mult
-    assert cov_rel_err(g[2], eng.P) <= COV_TOL * min(mult, 1.0)
-    assert cov_rel_err_blockwise(g[2], eng.P) <= (COV_BLOCK_TOL_F64 if dtype == 64 else COV_BLOCK_TOL * mult)
-    assert not np.array_equal(g[0][2:], nom[2:].astype(g[0].dtype))           # it did update
+    # fp32 stacked mode at this batch size runs correct_corners_team_kernel (the markers divided among four waves per tile): the
+    # default, the one-wave kernel (set_team 1) and the two-role form all go through the same gate
+    for roles in ((0, 1, 2) if (dtype == 32 and mode == 1) else (0,)):
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            flt.set_team(0, roles)
+            flt.set_state(nom, rot, P, prev)
+            flt.correct_corners(ids, left, right, capi.VIS_REFRACTIVE, mode)
+            g = flt.get_state()
+            ap = flt.applied()
+        assert (ap == ok).all() and ok[0] == 0 and ok[2:].all(), roles
+        assert (g[3] == eng.prev).all()
+        assert state_rel_err(g[0], eng.nominal, eng.P)[0] <= STATE_TOL * mult, roles
+        assert cov_rel_err(g[2], eng.P) <= COV_TOL * min(mult, 1.0), roles
+        assert cov_rel_err_blockwise(g[2], eng.P) <= (COV_BLOCK_TOL_F64 if dtype == 64 else COV_BLOCK_TOL * mult), roles
+        assert not np.array_equal(g[0][2:], nom[2:].astype(g[0].dtype))           # it did update
 
 
 @pytest.mark.gpu
