@@ -45,12 +45,27 @@ template <typename T> __device__ __forceinline__ T det3cols(const T* c0, const T
          + c2[0] * (c0[1] * c1[2] - c0[2] * c1[1]);
 }
 
+// fp32: square root, reciprocal square root and reciprocal from the 1-ulp hardware estimates (v_rsq_f32 / v_rcp_f32) + one Newton
+// step, 3-4 instructions instead of the 10-20 of the IEEE sequences; the triangulation of one corner has 6 square roots and 8
+// divisions among its ~300 other instructions (r3: correct_corners at 65 536 filters x 16 slots 68.9 -> see DESIGN.md 4.2c).
+// Arguments are sums of squares of unit-ish vectors, cosines of refracted rays and a Cramer determinant: positive, far from 0.
+__device__ __forceinline__ float vs_rsq(float x) { const float r = __builtin_amdgcn_rsqf(x); return r * (1.5f - 0.5f * x * r * r); }
+__device__ __forceinline__ double vs_rsq(double x) { return 1.0 / sqrt(x); }                // fp64: as before
+__device__ __forceinline__ float vs_sqrt(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x), s_ = x * r;
+    return x > 0.0f ? s_ + 0.5f * r * (x - s_ * s_) : 0.0f;
+}
+__device__ __forceinline__ double vs_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float vs_div(float a, float x) { const float r = __builtin_amdgcn_rcpf(x); return a * (r * (2.0f - x * r)); }
+__device__ __forceinline__ double vs_div(double a, double x) { return a / x; }          // fp64: the reference's own operation
+
 // One Snell refraction at the flat port (unit ray r, interface normal nv).
 template <typename T>
 __device__ __forceinline__ void refract(const T* r, const T* nv, T alpha, int sqrt_minus, T* out, T& v)
 {
     v = dot3(r, nv);
-    const T root = fb_sqrt(T(1) - alpha * alpha * (T(1) - v * v));
+    const T root = vs_sqrt(T(1) - alpha * alpha * (T(1) - v * v));
     const T beta = sqrt_minus ? (root - alpha * v) : (alpha * v - root);
 #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = alpha * r[i] + beta * nv[i];
@@ -61,7 +76,7 @@ template <typename T>
 __device__ __forceinline__ void refraction_corner(const VisConst<T>& vc, T xl, T yl, T xr, T yr, T* out)
 {
     const T pl[3] = { xl, yl, T(1) }, pr[3] = { xr, yr, T(1) };
-    const T il = T(1) / fb_sqrt(dot3(pl, pl)), ir = T(1) / fb_sqrt(dot3(pr, pr));
+    const T il = vs_rsq(dot3(pl, pl)), ir = vs_rsq(dot3(pr, pr));
     const T r0L[3] = { pl[0] * il, pl[1] * il, pl[2] * il }, r0R[3] = { pr[0] * ir, pr[1] * ir, pr[2] * ir };
     T r1L[3], r1R[3], r2L[3], r2R[3], v0L, v0R, v1L, v1R;
     refract(r0L, vc.nrm, vc.alpha0, vc.sqrt_minus0, r1L, v0L);
@@ -69,10 +84,11 @@ __device__ __forceinline__ void refraction_corner(const VisConst<T>& vc, T xl, T
     refract(r1L, vc.nrm, vc.alpha1, vc.sqrt_minus1, r2L, v1L);
     refract(r1R, vc.nrm, vc.alpha1, vc.sqrt_minus1, r2R, v1R);
     T P1L[3], P1R[3];
+    const T aL = vs_div(vc.d_air, v0L), gL = vs_div(vc.d_glass, v1L), aR = vs_div(vc.d_air, v0R), gR = vs_div(vc.d_glass, v1R);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {                        // :546-552 exit points on the outer glass face
-        P1L[i] = (vc.d_air / v0L) * r0L[i] + (vc.d_glass / v1L) * r1L[i];
-        P1R[i] = (vc.d_air / v0R) * r0R[i] + (vc.d_glass / v1R) * r1R[i];
+        P1L[i] = aL * r0L[i] + gL * r1L[i];
+        P1R[i] = aR * r0R[i] + gR * r1R[i];
     }
     T r2RL[3], P1RL[3];                                  // :555-556 right ray in the left frame
     m3v(vc.R_RL, r2R, r2RL);
@@ -81,8 +97,8 @@ __device__ __forceinline__ void refraction_corner(const VisConst<T>& vc, T xl, T
     cross3(r2L, r2RL, cr);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { P1RL[i] += vc.P_LR[i]; dP[i] = P1RL[i] - P1L[i]; }
-    const T d3 = det3cols(cr, r2L, r2RL);                // :559-595 Cramer
-    const T t1 = det3cols(cr, dP, r2RL) / d3, t2 = -det3cols(cr, r2L, dP) / d3;
+    const T d3 = det3cols(cr, r2L, r2RL);                // :559-595 Cramer (the determinant is |r2L x r2R|^2 > 0)
+    const T t1 = vs_div(det3cols(cr, dP, r2RL), d3), t2 = -vs_div(det3cols(cr, r2L, dP), d3);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T P = T(0.5) * (P1L[i] + t1 * r2L[i] + P1RL[i] + t2 * r2RL[i]);

@@ -69,7 +69,10 @@ def test_refractive_matches_oracle_on_perturbed_corners(dtype, tol):
     assert np.abs(c3 - o_c3).max() / scale < tol
     assert np.abs(pos - o_pos).max() / scale < tol
     assert _qerr(quat.astype(np.float64), o_quat) < 50 * tol        # noisy corners: the plane fit amplifies
-    assert np.abs(np.linalg.norm(quat, axis=1) - 1).max() < (1e-6 if dtype == 32 else 1e-14)
+    # Eigen's Quaterniond(Matrix3d) does not renormalise (vision.cpp:758): the norm carries the orthogonality error of the fitted
+    # frame, which in fp32 depends on the last bits of the corners (r3: 1 ulp differences of the triangulation moved the
+    # maximum over these 2000 markers from < 1e-6 to 3.9e-6; test_large_batch_properties allows 1e-4 on noisier corners)
+    assert np.abs(np.linalg.norm(quat, axis=1) - 1).max() < (1e-5 if dtype == 32 else 1e-14)
 
 
 @pytest.mark.parametrize("dtype,tol", [(64, 1e-9), (32, 5e-4)])
