@@ -191,6 +191,10 @@ __device__ __forceinline__ void fb_sincos_x_halfx(double x, double& s, double& c
 __device__ __forceinline__ void fb_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
 __device__ __forceinline__ float fb_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double fb_sqrt(double x) { return sqrt(x); }
+// 1 / sqrt(x), x > 0.  fp32: the 1-ulp hardware estimate + one Newton step (4 instructions; sqrtf followed by an IEEE division is ~25),
+// fp64: the reference's own two operations.
+__device__ __forceinline__ float fb_rsqrt(float x) { const float r = __builtin_amdgcn_rsqf(x); return r * (1.5f - 0.5f * x * r * r); }
+__device__ __forceinline__ double fb_rsqrt(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ float fb_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double fb_abs(double x) { return fabs(x); }
 
@@ -228,7 +232,7 @@ __device__ __forceinline__ void quat_to_rotmat_e(const T* q, T* R)
 template <typename T>
 __device__ __forceinline__ void quat_normalize(T* q)
 {
-    const T inv = T(1) / fb_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const T inv = fb_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 
@@ -486,7 +490,11 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
 
     const T a[3] = { accel[0] - ba[0], accel[1] - ba[1], accel[2] - ba[2] };   // ImuUpdate.m:37-38
     const T w[3] = { gyro[0] - bg[0], gyro[1] - bg[1], gyro[2] - bg[2] };
-    const T wn = fb_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    // fp32: |w| and 1 / |w| from one reciprocal square root (|w| = |w|^2 / |w|); a rate of exactly zero gives 0, 0
+    const T wn2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    T wn, iwn;
+    if constexpr (sizeof(T) == 4) { iwn = (wn2 > T(0)) ? fb_rsqrt(wn2) : T(0); wn = wn2 * iwn; }
+    else { wn = fb_sqrt(wn2); iwn = (wn > T(0)) ? T(1) / wn : T(0); }          // fp64: the reference's operations
 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -503,7 +511,7 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
     if (DIALECT == DIALECT_MATLAB) {
         // ImuUpdate.m:41-43,68.  axis/|axis| is NaN at w == 0 in the reference; guarded here
         // (identity rotation), bit-identical away from zero.
-        const T inv = (wn > T(0)) ? T(1) / wn : T(0);
+        const T inv = iwn;
         n[0] = w[0] * inv; n[1] = w[1] * inv; n[2] = w[2] * inv;
         const T dth = wn * fb_abs(dt);
         fb_sincos_x_halfx(dth * T(0.5), s2, c2, s4, c4);
@@ -516,7 +524,7 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
     } else {
         // filter.cpp:544-561,603
         small_rate = !(wn > T(10e-5));
-        const T inv = small_rate ? T(0) : T(1) / wn;
+        const T inv = small_rate ? T(0) : iwn;
         n[0] = w[0] * inv; n[1] = w[1] * inv; n[2] = w[2] * inv;
         fb_sincos_x_halfx(wn * dt * T(0.5), s2, c2, s4, c4);
         Th[0] = T(1);        Th[1] = w[2] * dt;   Th[2] = -w[1] * dt;
@@ -552,7 +560,8 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
         quat_to_rotmat_e(qH, RH);
         quat_to_rotmat_e(qT, RT);
     }
-    // RK4-style   ImuUpdate.m:49-60 ; filter.cpp:567-581
+    // RK4-style   ImuUpdate.m:49-60 ; filter.cpp:567-581  (dt / 6: fp32 multiplies by the rounded 1/6 -- 1 ulp, no division sequence)
+    const T dt6 = (sizeof(T) == 4) ? dt * T(1.0 / 6.0) : dt / 6;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T kv1 = R0[3 * i] * a[0] + R0[3 * i + 1] * a[1] + R0[3 * i + 2] * a[2] + g[i];
@@ -560,9 +569,9 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
         const T kv4 = RT[3 * i] * a[0] + RT[3 * i + 1] * a[1] + RT[3 * i + 2] * a[2] + g[i];
         const T kv3 = kv2;
         const T v0 = v[i];
-        v[i] = v0 + dt / 6 * (kv1 + 2 * kv2 + 2 * kv3 + kv4);
+        v[i] = v0 + dt6 * (kv1 + 2 * kv2 + 2 * kv3 + kv4);
         const T kp2 = v0 + kv1 * dt / 2, kp3 = v0 + kv2 * dt / 2, kp4 = v0 + kv3 * dt / 2;   // dt/2 sic
-        p[i] = p[i] + dt / 6 * (v0 + 2 * kp2 + 2 * kp3 + kp4);
+        p[i] = p[i] + dt6 * (v0 + 2 * kp2 + 2 * kp3 + kp4);
     }
     if (DIALECT == DIALECT_MATLAB) quat_normalize(qT);               // ImuUpdate.m:76
 #pragma unroll
