@@ -195,6 +195,9 @@ __device__ __forceinline__ double fb_sqrt(double x) { return sqrt(x); }
 // fp64: the reference's own two operations.
 __device__ __forceinline__ float fb_rsqrt(float x) { const float r = __builtin_amdgcn_rsqf(x); return r * (1.5f - 0.5f * x * r * r); }
 __device__ __forceinline__ double fb_rsqrt(double x) { return 1.0 / sqrt(x); }
+// 1 / x.  fp32: hardware estimate + one Newton step (3 instructions instead of the ~10 of the IEEE sequence); fp64: a division.
+__device__ __forceinline__ float fb_rcp1(float x) { const float r = __builtin_amdgcn_rcpf(x); return r * (2.0f - x * r); }
+__device__ __forceinline__ double fb_rcp1(double x) { return 1.0 / x; }
 __device__ __forceinline__ float fb_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double fb_abs(double x) { return fabs(x); }
 
@@ -1000,7 +1003,7 @@ struct PoseFold {
     {
         using L = Lay<N>;
         const T* q = pqr + L::OFF_Q;
-        const T wp = T(1) / dc.r_pos, wq = T(1) / dc.r_quat;
+        const T wp = fb_rcp1(dc.r_pos), wq = fb_rcp1(dc.r_quat);
         const T (&H)[9] = mc.Hpp;
         const T wn = wp * cnt;
         // Lam_pp = w n Hpp' Hpp
@@ -1173,7 +1176,7 @@ __device__ __forceinline__ void joint_factor(InfoAcc<T>& acc, InfoFactors<T>& f,
     for (int a = 0; a < 6; ++a) {
         const T piv = A[lidx(a, a)];
         const bool ok = piv > tiny * dg0[a];
-        const T inv = ok ? T(1) / piv : T(0);
+        const T inv = ok ? fb_rcp1(piv) : T(0);
         f.d[a] = ok ? piv : T(0);
         if (!ok) bt[a] = T(0);
 #pragma unroll
@@ -1343,10 +1346,12 @@ __device__ __forceinline__ void inject(T* rec /* the 28 nominal + rotation eleme
         if (N == 18) rec[L::OFF_G + i] += dx[15 + i];
     }
     const T n2 = dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8];
-    const T nn = fb_sqrt(n2);
+    T nn, inn;                                                     // |dtheta| and its reciprocal (fp32: one refined rsq, see predict_nominal)
+    if constexpr (sizeof(T) == 4) { inn = (n2 > T(0)) ? fb_rsqrt(n2) : T(0); nn = n2 * inn; }
+    else { nn = fb_sqrt(n2); inn = (nn > T(0)) ? T(1) / nn : T(0); }
     T s, c;
     fb_sincos(nn * T(0.5), s, c);
-    const T k = (nn > T(0)) ? s / nn : T(0);                      // guard for the reference's 0/0
+    const T k = (sizeof(T) == 4) ? s * inn : ((nn > T(0)) ? s / nn : T(0));   // guard for the reference's 0/0
     const T dq[4] = { c, dx[6] * k, dx[7] * k, dx[8] * k };
     T qn[4];
     quat_mul(rec + L::OFF_Q, dq, qn);
