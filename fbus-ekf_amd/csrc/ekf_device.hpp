@@ -353,77 +353,144 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
     constexpr bool G = (N == 18);
     constexpr int NC = N - 6;                       // columns theta .. end
     const T dt = k.dt;
-    // U(i, c) = A_i . P(theta, c) + Bm_i . P(ba, c) + dt P(g_i, c), c = 6 .. N-1, accumulated source by source in
-    // the order the rows arrive (theta rows, ba rows, then the g/bg bits)
-    T U[3 * NC];
-    if constexpr (PackedMath<T, N>::on) {
-        // the same sums on aligned column pairs (6+c, 7+c): 26 of the 42 pair-terms per row are one v_pk_fma_f32
+    if constexpr (sizeof(T) == 4) {
+        // U(i, c) = A_i . P(theta, c) + Bm_i . P(ba, c) + dt P(g_i, c), c = 6 .. N-1; row by row (r3): U(i, :), then row i of
+        // D = (P(v,theta) + U_theta/2) A' + (P(v,ba) + U_ba/2) Bm' + dt (P(v,g) + U_g/2) from the PRE-update row i, then
+        // P(v_i, theta..) += U(i, :) -- 12 products live at a time instead of 36 (the same operations in the same order per element)
+        T D[9];
+        static_for<0, 3>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            T U[NC];
+            if constexpr (PackedMath<T, N>::on) {
+                // the sums on aligned column pairs (6+c, 7+c): 26 of the 42 pair-terms per row are one v_pk_fma_f32
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < NC; c += 2) {
+                    PairAcc<N> acc;
+                    acc.add(P, k.A[3 * i], 6, 6 + c); acc.add(P, k.A[3 * i + 1], 7, 6 + c); acc.add(P, k.A[3 * i + 2], 8, 6 + c);
+                    acc.add(P, k.Bm[3 * i], 9, 6 + c); acc.add(P, k.Bm[3 * i + 1], 10, 6 + c); acc.add(P, k.Bm[3 * i + 2], 11, 6 + c);
+                    if (G) acc.add(P, dt, 15 + i, 6 + c);
+                    const f32x2 r = acc.get();
+                    U[c] = r.x; U[c + 1] = r.y;
+                }
+            } else {
 #pragma unroll
-            for (int c = 0; c < NC; c += 2) {
-                PairAcc<N> acc;
-                acc.add(P, k.A[3 * i], 6, 6 + c); acc.add(P, k.A[3 * i + 1], 7, 6 + c); acc.add(P, k.A[3 * i + 2], 8, 6 + c);
-                acc.add(P, k.Bm[3 * i], 9, 6 + c); acc.add(P, k.Bm[3 * i + 1], 10, 6 + c); acc.add(P, k.Bm[3 * i + 2], 11, 6 + c);
-                if (G) acc.add(P, dt, 15 + i, 6 + c);
-                const f32x2 r = acc.get();
-                U[NC * i + c] = r.x; U[NC * i + c + 1] = r.y;
+                for (int c = 0; c < NC; ++c)
+                    U[c] = k.A[3 * i] * PS(6, 6 + c) + k.A[3 * i + 1] * PS(7, 6 + c) + k.A[3 * i + 2] * PS(8, 6 + c);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    U[c] += k.Bm[3 * i] * PS(9, 6 + c) + k.Bm[3 * i + 1] * PS(10, 6 + c) + k.Bm[3 * i + 2] * PS(11, 6 + c);
+                if (G) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) U[c] += dt * PS(15 + i, 6 + c);
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                T acc = T(0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    acc += (PS(3 + i, 6 + m) + T(0.5) * U[m]) * k.A[3 * j + m];
+                    acc += (PS(3 + i, 9 + m) + T(0.5) * U[3 + m]) * k.Bm[3 * j + m];
+                }
+                if (G) acc += dt * (PS(3 + i, 15 + j) + T(0.5) * U[9 + j]);
+                D[3 * i + j] = acc;
+            }
+            if constexpr (PackedMath<T, N>::on) {
+#pragma unroll
+                for (int c = 0; c < NC; c += 2) {
+                    if (is_pair<N>(3 + i, 6 + c)) {
+                        const int o = pidx<N>(3 + i, 6 + c);
+                        const f32x2 r = f32x2{ P[o], P[o + 1] } + f32x2{ U[c], U[c + 1] };
+                        P[o] = r.x; P[o + 1] = r.y;
+                    } else {
+                        PS(3 + i, 6 + c) += U[c]; PS(3 + i, 7 + c) += U[c + 1];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) PS(3 + i, 6 + c) += U[c];
+            }
+        });
+        // v,v block: P(v,v) += D + D'
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) PS(3 + i, 3 + j) += D[3 * i + j] + D[3 * j + i];
     } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                U[NC * i + c] = k.A[3 * i] * PS(6, 6 + c) + k.A[3 * i + 1] * PS(7, 6 + c) + k.A[3 * i + 2] * PS(8, 6 + c);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                U[NC * i + c] += k.Bm[3 * i] * PS(9, 6 + c) + k.Bm[3 * i + 1] * PS(10, 6 + c) + k.Bm[3 * i + 2] * PS(11, 6 + c);
-        if (G) {
+        // fp64 (at the 512-register limit): the block form -- all of U, then D, then the row updates; the row-by-row order above
+        // costs this instantiation 20-52 bytes of scratch
+        // U(i, c) = A_i . P(theta, c) + Bm_i . P(ba, c) + dt P(g_i, c), c = 6 .. N-1, accumulated source by source in
+        // the order the rows arrive (theta rows, ba rows, then the g/bg bits)
+        T U[3 * NC];
+        if constexpr (PackedMath<T, N>::on) {
+            // the same sums on aligned column pairs (6+c, 7+c): 26 of the 42 pair-terms per row are one v_pk_fma_f32
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) U[NC * i + c] += dt * PS(15 + i, 6 + c);
-        }
-    }
-    // v,v block: P(v,v) += D + D',  D = (P(v,theta) + U_theta/2) A' + (P(v,ba) + U_ba/2) Bm' + dt (P(v,g) + U_g/2)
-    T D[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            T acc = T(0);
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                acc += (PS(3 + i, 6 + m) + T(0.5) * U[NC * i + m]) * k.A[3 * j + m];
-                acc += (PS(3 + i, 9 + m) + T(0.5) * U[NC * i + 3 + m]) * k.Bm[3 * j + m];
-            }
-            if (G) acc += dt * (PS(3 + i, 15 + j) + T(0.5) * U[NC * i + 9 + j]);
-            D[3 * i + j] = acc;
-        }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = i; j < 3; ++j) PS(3 + i, 3 + j) += D[3 * i + j] + D[3 * j + i];
-    if constexpr (PackedMath<T, N>::on) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int c = 0; c < NC; c += 2) {
-                if (is_pair<N>(3 + i, 6 + c)) {
-                    const int o = pidx<N>(3 + i, 6 + c);
-                    const f32x2 r = f32x2{ P[o], P[o + 1] } + f32x2{ U[NC * i + c], U[NC * i + c + 1] };
-                    P[o] = r.x; P[o + 1] = r.y;
-                } else {
-                    PS(3 + i, 6 + c) += U[NC * i + c]; PS(3 + i, 7 + c) += U[NC * i + c + 1];
+                for (int c = 0; c < NC; c += 2) {
+                    PairAcc<N> acc;
+                    acc.add(P, k.A[3 * i], 6, 6 + c); acc.add(P, k.A[3 * i + 1], 7, 6 + c); acc.add(P, k.A[3 * i + 2], 8, 6 + c);
+                    acc.add(P, k.Bm[3 * i], 9, 6 + c); acc.add(P, k.Bm[3 * i + 1], 10, 6 + c); acc.add(P, k.Bm[3 * i + 2], 11, 6 + c);
+                    if (G) acc.add(P, dt, 15 + i, 6 + c);
+                    const f32x2 r = acc.get();
+                    U[NC * i + c] = r.x; U[NC * i + c + 1] = r.y;
                 }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    U[NC * i + c] = k.A[3 * i] * PS(6, 6 + c) + k.A[3 * i + 1] * PS(7, 6 + c) + k.A[3 * i + 2] * PS(8, 6 + c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    U[NC * i + c] += k.Bm[3 * i] * PS(9, 6 + c) + k.Bm[3 * i + 1] * PS(10, 6 + c) + k.Bm[3 * i + 2] * PS(11, 6 + c);
+            if (G) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) U[NC * i + c] += dt * PS(15 + i, 6 + c);
             }
-    } else {
+        }
+        // v,v block: P(v,v) += D + D',  D = (P(v,theta) + U_theta/2) A' + (P(v,ba) + U_ba/2) Bm' + dt (P(v,g) + U_g/2)
+        T D[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) PS(3 + i, 6 + c) += U[NC * i + c];
+            for (int j = 0; j < 3; ++j) {
+                T acc = T(0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    acc += (PS(3 + i, 6 + m) + T(0.5) * U[NC * i + m]) * k.A[3 * j + m];
+                    acc += (PS(3 + i, 9 + m) + T(0.5) * U[NC * i + 3 + m]) * k.Bm[3 * j + m];
+                }
+                if (G) acc += dt * (PS(3 + i, 15 + j) + T(0.5) * U[NC * i + 9 + j]);
+                D[3 * i + j] = acc;
+            }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) PS(3 + i, 3 + j) += D[3 * i + j] + D[3 * j + i];
+        if constexpr (PackedMath<T, N>::on) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < NC; c += 2) {
+                    if (is_pair<N>(3 + i, 6 + c)) {
+                        const int o = pidx<N>(3 + i, 6 + c);
+                        const f32x2 r = f32x2{ P[o], P[o + 1] } + f32x2{ U[NC * i + c], U[NC * i + c + 1] };
+                        P[o] = r.x; P[o + 1] = r.y;
+                    } else {
+                        PS(3 + i, 6 + c) += U[NC * i + c]; PS(3 + i, 7 + c) += U[NC * i + c + 1];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) PS(3 + i, 6 + c) += U[NC * i + c];
+        }
     }
     // E_theta, column theta of rows v: P(v,theta) = P(v,theta) Th' - dt P(v,bg)
 #pragma unroll
