@@ -512,11 +512,6 @@ __device__ __forceinline__ void cov_stage_th(T* P, const PredictCoef<T>& k, cons
     const T (&Th)[9] = k.Th;
     T Xn[9], Gm[9];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            Gm[3 * i + j] = Th[3 * i] * PS(6, 6 + j) + Th[3 * i + 1] * PS(7, 6 + j) + Th[3 * i + 2] * PS(8, 6 + j);
-#pragma unroll
     for (int c = 9; c < N; ++c) {
         if (c >= 12 && c < 15) continue;
         const T o0 = PS(6, c), o1 = PS(7, c), o2 = PS(8, c);
@@ -524,6 +519,12 @@ __device__ __forceinline__ void cov_stage_th(T* P, const PredictCoef<T>& k, cons
         for (int i = 0; i < 3; ++i)
             PS(6 + i, c) = Th[3 * i] * o0 + Th[3 * i + 1] * o1 + Th[3 * i + 2] * o2 - dt * PS(12 + i, c);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Gm[3 * i + j] = Th[3 * i] * PS(6, 6 + j) + Th[3 * i + 1] * PS(7, 6 + j) + Th[3 * i + 2] * PS(8, 6 + j);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
