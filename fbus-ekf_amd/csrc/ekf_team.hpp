@@ -250,6 +250,98 @@ struct StepXch {
     static constexpr int PER_SLOT = QC + QVX + QTX;          // 16-byte cells per buffer and lane
     u32x4* mem;                                              // [2][PER_SLOT][64], this lane's column
     __device__ __forceinline__ u32x4* cell(int buf, int q) const { return mem + (buf * PER_SLOT + q) * 64; }
+    __device__ __forceinline__ void put4(int buf, int q, const T* src) const
+    {
+        u32x4 v;
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = src[i];
+        *cell(buf, q) = v;
+    }
+    __device__ __forceinline__ void get4(int buf, int q, T* dst) const
+    {
+        const u32x4 v = *cell(buf, q);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = e[i];
+    }
+    // the 28 coefficients of a step: nominal role -> everybody
+    __device__ __forceinline__ void put_coef(int buf, const PredictCoef<T>& k) const
+    {
+        T c[28];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { c[i] = k.A[i]; c[9 + i] = k.Bm[i]; c[18 + i] = k.Th[i]; }
+        c[27] = k.dt;
+#pragma unroll
+        for (int q = 0; q < QC; ++q) put4(buf, q, c + 4 * q);
+    }
+    __device__ __forceinline__ void get_coef(int buf, PredictCoef<T>& k) const
+    {
+        T c[28];
+#pragma unroll
+        for (int q = 0; q < QC; ++q) get4(buf, q, c + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { k.A[i] = c[i]; k.Bm[i] = c[9 + i]; k.Th[i] = c[18 + i]; }
+        k.dt = c[27];
+    }
+    // iteration t (1 .. K) of the three covariance roles: step t - 1 on this role's rows; what the next role reads of them goes to
+    // buffer t & 1 (not behind the last step).  The caller puts the barrier behind it.
+    __device__ __forceinline__ void step_theta(T* P, PredictCoef<T>& k, const T* qd, int t, int K) const
+    {
+        get_coef((t - 1) & 1, k);
+        cov_stage_th<T, N>(P, k, qd);
+        if (t < K) {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) put4(t & 1, QC + QVX + q, P + E_T0 + 4 * q);
+            if constexpr (DIAG_APART) { const T d[4] = { P[pidx<N>(7, 7)], T(0), T(0), T(0) }; put4(t & 1, QC + QVX + QT, d); }
+        }
+    }
+    __device__ __forceinline__ void step_v(T* P, PredictCoef<T>& k, const T* qd, int t, int K) const
+    {
+        get_coef((t - 1) & 1, k);
+        if (t > 1) {
+            // rows theta as role theta left them after step t - 2 (the cover [E_T0, E_T1) starts with the last elements of rows v
+            // and may end with non-theta elements of the same chunk: only theta elements are taken)
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                T v4[4];
+                get4((t - 1) & 1, QC + QVX + q, v4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = E_T0 + 4 * q + i;
+                    if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
+                }
+            }
+            if constexpr (DIAG_APART) { T d[4]; get4((t - 1) & 1, QC + QVX + QT, d); P[pidx<N>(7, 7)] = d[0]; }
+            // the ba diagonal's + Q of step t - 2 (role theta owns and stores it; this is the private copy stage v reads)
+#pragma unroll
+            for (int i = 9; i < 12; ++i) P[pidx<N>(i, i)] += qd[2];
+        }
+        cov_stage_v<T, N>(P, k, qd);
+        if (t < K) {
+#pragma unroll
+            for (int q = 0; q < QV; ++q) put4(t & 1, QC + q, P + E_V0 + 4 * q);
+            if constexpr (DIAG_APART) { const T d[4] = { P[pidx<N>(3, 3)], P[pidx<N>(5, 5)], T(0), T(0) }; put4(t & 1, QC + QV, d); }
+        }
+    }
+    __device__ __forceinline__ void step_p(T* P, PredictCoef<T>& k, int t) const
+    {
+        get_coef((t - 1) & 1, k);
+        if (t > 1) {
+#pragma unroll
+            for (int q = 0; q < QV; ++q) {
+                T v4[4];
+                get4((t - 1) & 1, QC + q, v4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = E_V0 + 4 * q + i;
+                    if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 3 && cov_row<N>(e) < 6) P[e] = v4[i];
+                }
+            }
+            if constexpr (DIAG_APART) { T d[4]; get4((t - 1) & 1, QC + QV, d); P[pidx<N>(3, 3)] = d[0]; P[pidx<N>(5, 5)] = d[1]; }
+        }
+        cov_stage_p<T, N>(P, k);
+    }
 };
 
 template <typename T, int N, int DIALECT>
@@ -271,27 +363,6 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
     const X xch{ xmem + lane };
     T nom[Lay<N>::NNOM], P[RC::NCOVP];
     PredictCoef<T> k;
-    auto put4 = [&](int buf, int q, const T* src) {
-        u32x4 v;
-        T* e = reinterpret_cast<T*>(&v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = src[i];
-        *xch.cell(buf, q) = v;
-    };
-    auto get4 = [&](int buf, int q, T* dst) {
-        const u32x4 v = *xch.cell(buf, q);
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = e[i];
-    };
-    auto get_coef = [&](int buf) {
-        T c[28];
-#pragma unroll
-        for (int q = 0; q < X::QC; ++q) get4(buf, q, c + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { k.A[i] = c[i]; k.Bm[i] = c[9 + i]; k.Th[i] = c[18 + i]; }
-        k.dt = c[27];
-    };
     if (role == 3) {
         // ---- nominal role: one step ahead of the covariance roles -------------------------------------------------
         load_chunks<T, N, 0, CN, AUX_NT>(rs, lane, nom);
@@ -302,12 +373,7 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
             if (t < K) {
                 predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, k);
                 if (t + 1 < K) cur.load(accel, gyro, dt, dt_stride, t + 1, B, b);
-                T c[28];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) { c[i] = k.A[i]; c[9 + i] = k.Bm[i]; c[18 + i] = k.Th[i]; }
-                c[27] = k.dt;
-#pragma unroll
-                for (int q = 0; q < X::QC; ++q) put4(t & 1, q, c + 4 * q);
+                xch.put_coef(t & 1, k);
             }
             team_barrier();
         }
@@ -318,13 +384,7 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
         team_barrier();                                                  // iteration 0
 #pragma unroll 1
         for (int t = 1; t <= K; ++t) {
-            get_coef((t - 1) & 1);
-            cov_stage_th<T, N>(P, k, dc.qd);
-            if (t < K) {
-#pragma unroll
-                for (int q = 0; q < X::QT; ++q) put4(t & 1, X::QC + X::QVX + q, P + X::E_T0 + 4 * q);
-                if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(7, 7)], T(0), T(0), T(0) }; put4(t & 1, X::QC + X::QVX + X::QT, d); }
-            }
+            xch.step_theta(P, k, dc.qd, t, K);
             team_barrier();
         }
         if (live && K > 0) store_stage<T, N, 2, AUX_DEFAULT>(rs, lane, P);
@@ -334,31 +394,7 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
         team_barrier();
 #pragma unroll 1
         for (int t = 1; t <= K; ++t) {
-            get_coef((t - 1) & 1);
-            if (t > 1) {
-                // rows theta as role theta left them after step t - 2 (the cover [E_T0, E_T1) starts with the last
-                // elements of rows v and may end with non-theta elements of the same chunk: only theta elements are taken)
-#pragma unroll
-                for (int q = 0; q < X::QT; ++q) {
-                    T v4[4];
-                    get4((t - 1) & 1, X::QC + X::QVX + q, v4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int e = X::E_T0 + 4 * q + i;
-                        if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
-                    }
-                }
-                if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QVX + X::QT, d); P[pidx<N>(7, 7)] = d[0]; }
-                // the ba diagonal's + Q of step t - 2 (role theta owns and stores it; this is the private copy stage v reads)
-#pragma unroll
-                for (int i = 9; i < 12; ++i) P[pidx<N>(i, i)] += dc.qd[2];
-            }
-            cov_stage_v<T, N>(P, k, dc.qd);
-            if (t < K) {
-#pragma unroll
-                for (int q = 0; q < X::QV; ++q) put4(t & 1, X::QC + q, P + X::E_V0 + 4 * q);
-                if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(3, 3)], P[pidx<N>(5, 5)], T(0), T(0) }; put4(t & 1, X::QC + X::QV, d); }
-            }
+            xch.step_v(P, k, dc.qd, t, K);
             team_barrier();
         }
         if (live && K > 0) store_stage<T, N, 1, AUX_DEFAULT>(rs, lane, P);
@@ -368,21 +404,7 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
         team_barrier();
 #pragma unroll 1
         for (int t = 1; t <= K; ++t) {
-            get_coef((t - 1) & 1);
-            if (t > 1) {
-#pragma unroll
-                for (int q = 0; q < X::QV; ++q) {
-                    T v4[4];
-                    get4((t - 1) & 1, X::QC + q, v4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int e = X::E_V0 + 4 * q + i;
-                        if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 3 && cov_row<N>(e) < 6) P[e] = v4[i];
-                    }
-                }
-                if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QV, d); P[pidx<N>(3, 3)] = d[0]; P[pidx<N>(5, 5)] = d[1]; }
-            }
-            cov_stage_p<T, N>(P, k);
+            xch.step_p(P, k, t);
             team_barrier();
         }
         if (live && K > 0) store_stage<T, N, 0, AUX_DEFAULT>(rs, lane, P);
@@ -913,27 +935,6 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
     u32x4* const wx = xmem + FI::C_W * 64 + lane;                 // W, a-major, QW cells
     T nom[L::NNOM], P[RC::NCOVP];
     PredictCoef<T> k;
-    auto put4 = [&](int buf, int q, const T* src) {
-        u32x4 v;
-        T* e = reinterpret_cast<T*>(&v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = src[i];
-        *xch.cell(buf, q) = v;
-    };
-    auto get4 = [&](int buf, int q, T* dst) {
-        const u32x4 v = *xch.cell(buf, q);
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = e[i];
-    };
-    auto get_coef = [&](int buf) {
-        T c[28];
-#pragma unroll
-        for (int q = 0; q < X::QC; ++q) get4(buf, q, c + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { k.A[i] = c[i]; k.Bm[i] = c[9 + i]; k.Th[i] = c[18 + i]; }
-        k.dt = c[27];
-    };
     auto lam_at = [&](int i) -> float& { return lam[(i / 4) * 256 + (i % 4)]; };
     // the elements a role owns behind the predict phase -> image (whole chunks as one 16-byte write); S = its stage
     auto img_put_stage = [&](auto s_) {
@@ -1163,12 +1164,7 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
                 if (t < K) {
                     predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, k);
                     if (t + 1 < K) cur.load(fa, fg, fd, dt_stride, t + 1, B, b);
-                    T c[28];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) { c[i] = k.A[i]; c[9 + i] = k.Bm[i]; c[18 + i] = k.Th[i]; }
-                    c[27] = k.dt;
-#pragma unroll
-                    for (int q = 0; q < X::QC; ++q) put4(t & 1, q, c + 4 * q);
+                    xch.put_coef(t & 1, k);
                 } else if (M > 0) {
                     // the nominal state is final: marker choice (MeasureUpdate.m:51-60 ; filter.cpp:639-664) and the fold of the
                     // rows -> Lam, b in LDS, while the covariance roles run the frame's last step
@@ -1252,13 +1248,7 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
             team_barrier();                                                  // iteration 0
 #pragma unroll 1
             for (int t = 1; t <= K; ++t) {
-                get_coef((t - 1) & 1);
-                cov_stage_th<T, N>(P, k, dc.qd);
-                if (t < K) {
-#pragma unroll
-                    for (int q = 0; q < X::QT; ++q) put4(t & 1, X::QC + X::QVX + q, P + X::E_T0 + 4 * q);
-                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(7, 7)], T(0), T(0), T(0) }; put4(t & 1, X::QC + X::QVX + X::QT, d); }
-                }
+                xch.step_theta(P, k, dc.qd, t, K);
                 team_barrier();
             }
             if (frame_tail(I3_{}, I2_{}, I4_{}, f)) break;
@@ -1276,28 +1266,7 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
             team_barrier();
 #pragma unroll 1
             for (int t = 1; t <= K; ++t) {
-                get_coef((t - 1) & 1);
-                if (t > 1) {
-#pragma unroll
-                    for (int q = 0; q < X::QT; ++q) {
-                        T v4[4];
-                        get4((t - 1) & 1, X::QC + X::QVX + q, v4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int e = X::E_T0 + 4 * q + i;
-                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 6 && cov_row<N>(e) < 9) P[e] = v4[i];
-                        }
-                    }
-                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QVX + X::QT, d); P[pidx<N>(7, 7)] = d[0]; }
-#pragma unroll
-                    for (int i = 9; i < 12; ++i) P[pidx<N>(i, i)] += dc.qd[2];
-                }
-                cov_stage_v<T, N>(P, k, dc.qd);
-                if (t < K) {
-#pragma unroll
-                    for (int q = 0; q < X::QV; ++q) put4(t & 1, X::QC + q, P + X::E_V0 + 4 * q);
-                    if constexpr (X::DIAG_APART) { const T d[4] = { P[pidx<N>(3, 3)], P[pidx<N>(5, 5)], T(0), T(0) }; put4(t & 1, X::QC + X::QV, d); }
-                }
+                xch.step_v(P, k, dc.qd, t, K);
                 team_barrier();
             }
             if (frame_tail(I1_{}, I1_{}, I2_{}, f)) break;
@@ -1311,21 +1280,7 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
             team_barrier();
 #pragma unroll 1
             for (int t = 1; t <= K; ++t) {
-                get_coef((t - 1) & 1);
-                if (t > 1) {
-#pragma unroll
-                    for (int q = 0; q < X::QV; ++q) {
-                        T v4[4];
-                        get4((t - 1) & 1, X::QC + q, v4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int e = X::E_V0 + 4 * q + i;
-                            if (e < N * (N + 1) / 2 && cov_row<N>(e) >= 3 && cov_row<N>(e) < 6) P[e] = v4[i];
-                        }
-                    }
-                    if constexpr (X::DIAG_APART) { T d[4]; get4((t - 1) & 1, X::QC + X::QV, d); P[pidx<N>(3, 3)] = d[0]; P[pidx<N>(5, 5)] = d[1]; }
-                }
-                cov_stage_p<T, N>(P, k);
+                xch.step_p(P, k, t);
                 team_barrier();
             }
             if (frame_tail(I2_{}, I0_{}, I1_{}, f)) break;
