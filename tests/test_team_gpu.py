@@ -328,6 +328,11 @@ def test_team_frame_is_the_default_for_small_batches_and_long_windows():
             flt.frames(kcount, d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, capi.MODE_STACKED)
             flt.sync()
             out[what] = flt.get_state()
+            if what == "team":
+                for _ in range(3):                                   # three more windows: 256 frames, ~1300 ImuUpdates in all
+                    flt.frames(kcount, d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, capi.MODE_STACKED)
+                flt.sync()
+                long_run = flt.get_state()
     for k in range(4):
         assert np.array_equal(out["default"][k], out["team"][k]), "default policy at 16 384 filters is not the team frame kernel"
     sub = np.arange(0, B, B // 61)
@@ -343,3 +348,20 @@ def test_team_frame_is_the_default_for_small_batches_and_long_windows():
     print(f"[parity] team frame window, 64 frames / {Kt} steps: literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} "
           f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
     assert e["literal"] <= 2e-4 and e["sigma"] <= 2e-4 and e["cov"] <= 5e-5 and e["asym"] == 0 and e["prev_equal"], e
+    # the long run: the one-shot form P - W W' of the divided MeasureUpdate, 256 times in a row between ~1300 fp32 predicts, must
+    # stay with the oracle and keep every covariance symmetric positive definite
+    for _ in range(3):
+        k0 = 0
+        for f, K in enumerate(kcount):
+            for k in range(K):
+                eng.predict(acc[k0 + k][sub], gyr[k0 + k][sub], dtb[k0 + k][sub])
+            k0 += K
+            eng.correct(ids[f][sub], pos[f][sub], quat[f][sub], capi.MODE_STACKED)
+    e = parity_errors(tuple(x[sub] for x in long_run), eng.get_state())
+    Pl = np.asarray(long_run[2], np.float64)
+    min_eig = np.linalg.eigvalsh(Pl[::16]).min(axis=1)
+    dmin = np.einsum("bii->bi", Pl[::16]).min(axis=1)
+    print(f"[parity] team frame window, 256 frames / {4 * Kt} steps: literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} "
+          f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}; min eigenvalue / min diagonal over 1024 filters {np.min(min_eig / dmin):.2e}")
+    assert np.isfinite(Pl).all() and (min_eig > 0).all() and e["asym"] == 0
+    assert e["literal"] <= 5e-4 and e["sigma"] <= 5e-4 and e["cov"] <= 2e-4, e
