@@ -100,6 +100,15 @@ public:
     void correct_pixels(int M, const int32_t* ids, const Real* left, const Real* right = nullptr, const uint8_t* skip = nullptr)
     { check(fbus_ekf_correct_pixels(h_, M, ids, left, right, skip), "correct_pixels"); }
 
+    // correct() from stereo corners (north-star extension): left / right (B, M, 8) normalised image points, or left = (B, M, 12)
+    // triangulated corners with geometry = FBUS_VIS_CORNERS3D; the triangulation of vision.cpp:472-618 runs on the device
+    void correct_corners(int M, const int32_t* ids, const Real* left, const Real* right, int geometry, Mode mode = Mode::Nearest,
+                         const uint8_t* skip = nullptr)
+    { check(fbus_ekf_correct_corners(h_, M, ids, left, right, geometry, int(mode), skip), "correct_corners"); }
+
+    // waves per 64-filter tile (fbus_ekf_set_team): 0 = chosen per launch, 1 = always one, 2..4 = always that many
+    void set_team(int predict_roles, int correct_roles) { check(fbus_ekf_set_team(h_, predict_roles, correct_roles), "set_team"); }
+
     std::vector<uint8_t> applied() const
     {
         std::vector<uint8_t> a(batch_);
