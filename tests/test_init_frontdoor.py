@@ -261,6 +261,7 @@ int main(int argc, char** argv) {
     const int B = 64, M = 3, NI = 23;
     using F = fbus::BatchedFilter<float>;
     F flt(B, FBUS_DIALECT_CPP);
+    flt.set_team(1, 1); flt.set_team(0, 0);          // the launch policy through the C++ class (back to the automatic choice)
     auto nom = rd<float>(d + "/nom.bin", B * 19), rot = rd<float>(d + "/rot.bin", B * 9), P = rd<float>(d + "/P.bin", B * 324);
     auto prev = rd<int32_t>(d + "/prev.bin", B);
     auto ia = rd<float>(d + "/imu_a.bin", NI * 3), iw = rd<float>(d + "/imu_w.bin", NI * 3);
