@@ -365,3 +365,42 @@ def test_team_frame_is_the_default_for_small_batches_and_long_windows():
           f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}; min eigenvalue / min diagonal over 1024 filters {np.min(min_eig / dmin):.2e}")
     assert np.isfinite(Pl).all() and (min_eig > 0).all() and e["asym"] == 0
     assert e["literal"] <= 5e-4 and e["sigma"] <= 5e-4 and e["cov"] <= 2e-4, e
+
+
+def test_team_frame_window_at_512_tiles_two_workgroups_per_cu():
+    """32 768 filters = 512 tiles: the largest launch the automatic choice gives to frames_team_kernel, two workgroups per CU (80 KiB of
+    LDS and 250 registers each).  Two runs bit-equal (a race between the roles' LDS phases would show as a difference), both modes,
+    C++ dialect (the previous marker id travels through the image), and parity with the oracle on a strided subset"""
+    import torch
+    B, M, n, dialect = 32768, 4, 18, 1
+    kcount = [7, 7, 6, 0, 5]
+    F, Kt = len(kcount), sum(kcount)
+    prm, nom, rot, P, prev, acc, gyr, ids, pos, quat = _window_inputs(B, dialect, n, M, kcount, seed_off=17)
+    dev = torch.device("cuda:0")
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_acc, d_gyr, d_dt = dd(acc), dd(gyr), dd(np.full(Kt, DT[0]))
+    d_ids, d_pos, d_quat = torch.from_numpy(ids).to(dev), dd(pos), dd(quat)
+    runs = []
+    for _ in range(2):
+        with BatchedFilter(B, prm, nstate=n) as flt:
+            flt.set_state(nom, rot, P, prev)
+            flt.frames(kcount, d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, capi.MODE_NEAREST)
+            flt.frames(kcount, d_acc, d_gyr, d_dt, d_ids, d_pos, d_quat, capi.MODE_STACKED)
+            flt.sync()
+            runs.append(flt.get_state())
+    for k in range(4):
+        assert np.array_equal(runs[0][k], runs[1][k]), f"two runs of the team frame window differ (element {k})"
+    sub = np.arange(0, B, B // 53)
+    eng = OracleEngine(len(sub), dialect, n)
+    eng.set_state(nom[sub], rot[sub], P[sub], prev[sub])
+    for mode in (capi.MODE_NEAREST, capi.MODE_STACKED):
+        k0 = 0
+        for f, K in enumerate(kcount):
+            for k in range(K):
+                eng.predict(acc[k0 + k][sub], gyr[k0 + k][sub], DT)
+            k0 += K
+            eng.correct(ids[f][sub], pos[f][sub], quat[f][sub], mode)
+    e = parity_errors(tuple(x[sub] for x in runs[0]), eng.get_state())
+    print(f"[parity] team frame windows at 32 768 filters: literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} "
+          f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
+    assert e["literal"] <= 1e-4 and e["sigma"] <= 1e-4 and e["cov"] <= 2e-5 and e["asym"] == 0 and e["prev_equal"], e
