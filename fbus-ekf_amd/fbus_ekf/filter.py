@@ -85,7 +85,9 @@ class BatchedFilter:
         self._own_stream = stream is None
 
     def set_team(self, predict_roles=0, correct_roles=0):
-        """waves per 64-filter tile of predict / correct: 0 = chosen per launch (default), 1 = one wave per tile, 2..4 fixed"""
+        """waves per 64-filter tile of predict / correct: 0 = chosen per launch (default), 1 = one wave per tile, 2..4 fixed.
+        predict_roles also governs predict_n and the fused frame / frame window entry points (the four-role pipeline), correct_roles also
+        correct_corners (stacked mode) and correct_pixels (2 = two waves per tile, 3..4 = four) -- include/fbus_ekf.h, DESIGN.md 4.5"""
         self._check(self._lib.fbus_ekf_set_team(self._h, int(predict_roles), int(correct_roles)), "set_team")
 
     def wait_stream(self, stream):
