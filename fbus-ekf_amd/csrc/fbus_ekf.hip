@@ -267,7 +267,7 @@ int team_roles_corners(const fbus_ekf* h, int mode, int M)
     const int tiles = (h->B + 63) / 64;
     return tiles <= 256 ? 4 : (tiles <= 512 ? 2 : 1);
 }
-// fused frame / frame window (frames_team_kernel: the predict_n pipeline + the correct on the nominal role).  Follows the predict
+// fused frame / frame window (frames_team_kernel: the predict_n pipeline + the one-shot correct divided over the four roles).  Follows the predict
 // setting (fbus_ekf_set_team: 1 = never, 2..4 = always); FBUS_TEAM_FRAME=1|2 overrides.  Two workgroups of four waves fit a CU
 // (80 KiB of LDS, 250 registers), so the automatic choice ends at 512 tiles (profiles/logs/r03_team_frame.txt: +8 % / +12 % at
 // 32 768 filters, 0.8x at 40 960).
