@@ -62,4 +62,26 @@ template <typename T, int N, int D>
 void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode, int roles,
                            const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
 
+
+// ---- correct() from corner pixels, round-4 kernel (ekf_meas.hpp) ---------------------------------------------------------
+constexpr int MKC_STRIDE = 10;      // doubles per map slot: corner 0 in the world (3), marker x axis (3), y axis (3), pad
+
+// constants of the pixel fold (double; kernel argument)
+struct MeasConst {
+    double P_IL[3];
+    double McL[9], McR[9], tR[3];   // a corner at t_I (IMU frame, t_I = R'(c_w - p) - P_IL) in the refraction frame of the left / right
+                                    // camera:  XL = McL t_I,  XR = McR t_I + tR   (McL = F R_IL: vision.cpp:597-599 undone;
+                                    // McR = R_RL^-1 McL, tR = -R_RL^-1 P_LR: vision.cpp:555-556 inverted)
+    double nML[3], nMR[3];          // n' McL, n' McR
+    double n[3];                    // port normal
+    double a0, a1, d_air, d_glass;  // n_air / n_glass, n_air / n_water
+    const double* mkc;              // [FBUS_MAX_MARKERS][MKC_STRIDE]
+};
+
+// roles: waves per 64-filter tile (1, 2 or 4: the markers of a filter divided among them); right == nullptr: left camera only.
+// The kernel does not depend on the dialect (the pixel rows have no quaternion part); D only keeps the instantiation macro uniform.
+template <typename T, int N, int D>
+void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, double size,
+                      double r_pix, const unsigned char* skip, unsigned char* applied, const short* id2slot, const MeasConst& mc);
+
 }  // namespace fbus

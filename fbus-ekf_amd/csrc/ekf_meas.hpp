@@ -1,0 +1,751 @@
+// ekf_meas.hpp -- correct() from corner PIXELS (round 4): the north star's own MeasureUpdate -- flat-port refractive stereo
+// reprojection of the ArUco corners, per-corner 2 x N Jacobians -- as a first-class kernel.
+//
+// Reference geometry and algebra (paths relative to the upstream repository):
+//   the port model            C++/src/vision.cpp:496-599   (air -> glass -> water, Snell twice; here run FORWARD)
+//   the rows                  matlab/MeasureUpdate.m:67,72-73 ; C++/src/filter.cpp:684-685,691-692 with a marker corner in place of
+//                             the marker origin:  X_k = R_IL R'(P_m + R_m c_k - p - R P_IL),  H = (d pi/d X)[ -R_IL R' | R_IL [R'(c_w - p)]x ]
+//   the update                matlab/MeasureUpdate.m:84-102 ; filter.cpp:709-739   K = P H'(H P H' + R)^-1, dx = K r, P = (I - K H) P
+//
+// What round 3 had (ekf_kernels.hpp::correct_pixels_kernel, kept for the fp64 / Joseph verification paths) and why it is replaced:
+//   * fp32 throughout.  128-256 rows at sigma_pix = 1e-3 shrink the pose variances by 4-5 decades in ONE update; P - k (P h')(P h')'
+//     then cancels to 1e-5 of its terms, the 6 x 6 information matrix accumulated in fp32 is perturbed by eps * cond(Lam), and a
+//     predicted image point known to 6e-8 moves a weakly observed block (gravity, sigma 10) by 5e-5 of itself:
+//     block-wise covariance error 2e-4 .. 3e-3, literal state error 2e-5 .. 4e-5 (tools/emul_pixels_precision.py decomposes it).
+//   * ~550 VALU instructions per projection on one dependent chain: Newton from the paraxial start with a wave vote per step,
+//     IEEE divisions and a square root (52 / 85 cycles each, tools/exp_issue_rates.hip) in the epilogue, 87 instructions per row to
+//     fold it.  0.53 VALU issue.
+// Round 4:
+//   * fp64 costs what fp32 costs on this part except for rsq / rcp (v_fma_f64 4.7 cycles against 4.6, v_rsq_f64 16.5 against 8.5:
+//     profiles/r04_issue_rates.txt), so everything that decides the posterior runs in double: the corner geometry, ONE final
+//     evaluation of the port equation with its Newton correction (the iteration itself stays in fp32 and only has to come within
+//     1e-3: the correction squares that twice), the residual, the Jacobian, the fold, the 6 x 6 algebra.  fp32 is left where it
+//     is harmless: the Newton iterations and the N x N covariance arithmetic.
+//   * the rows regrouped per corner (exact algebra, as PoseFold did for the pose rows): with a = (J_q Mc)' in the IMU frame,
+//     h_p = -R a and h_theta = a x ru (ru = R'(c_w - p)), so  Lam_pp = R S_aa R', Lam_pt = -R S_ac, Lam_tt = S_cc and per corner only
+//     N' = sum a a', n' = sum a r are accumulated row by row (9 FMA per row); S_ac += N'[ru]x, S_cc += [ru]x' N' [ru]x per corner.
+//   * J_q = alpha_q e' + beta_q n' + k g_q': no 3 x 3 dD/dX, no divisions.
+//   * the Newton iteration starts from the MEASURED image point (the innovation is a few 1e-3: one or two steps) and runs the
+//     four corners x one or two cameras of a marker in lock step: 4-8 independent chains per vote instead of one.
+//   * the update in the non-cancelling form: with Lam = Lc Lc', Mt = I + Lc' P_JJ Lc = Cm Cm', Z = Lc Cm^-T,
+//         Sinv = (Lam^-1 + P_JJ)^-1 = Z Z',   G = (I + P_JJ Lam)^-1 = I - P_JJ Sinv  (the difference taken in double),
+//     the p / theta rows of the posterior are the PRODUCT  G P(J, :)  -- no subtraction of nearly equal numbers -- and only the
+//     block of the states the rows do not touch takes  P_rr - W W',  W = P_rJ Z, where the cancellation is the physical one.
+//     dx = P(:, J) G' b.
+#pragma once
+#include "ekf_kernels.hpp"
+#include "ekf_launch.hpp"          // MeasConst
+
+
+namespace {
+
+// workgroup barrier that does not drain the global loads in flight (ekf_team.hpp::team_barrier)
+__device__ __forceinline__ void meas_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- double-precision reciprocal square root / reciprocal from the hardware estimates (v_rsq_f64 / v_rcp_f64: ~2^-23 relative)
+// + NS Newton steps: one gives 2^-45 (what an fp32 posterior needs many times over), two the full double
+template <int NS = 2>
+__device__ __forceinline__ double md_rsq(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double h = 0.5 * x * y;
+        y = __builtin_fma(y, __builtin_fma(-h, y, 0.5), y);
+    }
+    return y;
+}
+template <int NS = 2>
+__device__ __forceinline__ double md_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+    return y;
+}
+
+// Batched forms: the same operation on NQ independent values, written OPERATION BY OPERATION across the batch.  One wave per SIMD
+// has nothing but its own independent instructions to fill the latency of a dependent chain (v_fma_f64 issues every 4.7 cycles
+// but a dependent one every 5.6, v_rsq_f64 16.5, profiles/r04_issue_rates.txt), and the machine scheduler keeps the source order
+// of long unrolled bodies: written projection by projection the four corners of a marker ran one after the other
+// (round 4, first version: 6.0 cycles per instruction).
+template <int NS, int NQ>
+__device__ __forceinline__ void md_rsq_n(const double (&x)[NQ], double (&y)[NQ])
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = __builtin_amdgcn_rsq(x[q]);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double h[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) h[q] = 0.5 * x[q] * y[q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) h[q] = __builtin_fma(-h[q], y[q], 0.5);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] = __builtin_fma(y[q], h[q], y[q]);
+    }
+}
+template <int NS, int NQ>
+__device__ __forceinline__ void md_rcp_n(const double (&x)[NQ], double (&y)[NQ])
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = __builtin_amdgcn_rcp(x[q]);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double h[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) h[q] = __builtin_fma(-x[q], y[q], 1.0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) y[q] = __builtin_fma(y[q], h[q], y[q]);
+    }
+}
+template <int NS, int NQ> __device__ __forceinline__ void pe_rsq_n(const double (&x)[NQ], double (&y)[NQ]) { md_rsq_n<NS, NQ>(x, y); }
+template <int NS, int NQ> __device__ __forceinline__ void pe_rcp_n(const double (&x)[NQ], double (&y)[NQ]) { md_rcp_n<NS, NQ>(x, y); }
+template <int NS, int NQ> __device__ __forceinline__ void pe_rsq_n(const float (&x)[NQ], float (&y)[NQ])
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = __builtin_amdgcn_rsqf(x[q]);
+}
+template <int NS, int NQ> __device__ __forceinline__ void pe_rcp_n(const float (&x)[NQ], float (&y)[NQ])
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = __builtin_amdgcn_rcpf(x[q]);
+}
+
+// the port equation  rho = L(t) = d_air t + d_glass tan(theta_glass) + zw tan(theta_water),  t = tan(theta_air)   (vision_device.hpp)
+// with s = sin(theta_air) = t r, r = (1 + t^2)^-1/2, icg = 1 / cos(theta_glass) = (1 - a0^2 s^2)^-1/2, icw likewise, G = d_glass a0,
+// W = zw a1:   L = d_air t + s (G icg + W icw),   L' = d_air + r^3 (G icg^3 + W icw^3),
+//              L'' = 3 r^5 ( -t (G icg^3 + W icw^3) + s r (G a0^2 icg^5 + W a1^2 icw^5) )   (< 0: L is concave)
+// dt: HALLEY's step  -2 f L' / (2 L'^2 - f L''),  f = L - rho  (cubic convergence: from the measured ray, a few 1e-3 .. 1e-2 off,
+// one step in fp32 leaves ~1e-6 and one more in double the rounding error; tools/emul_meas_fold.py halley).  The denominator is
+// kept >= L'^2 (far below the root f L'' > 0 could eat it: the step then is at most twice Newton's).
+// Lzt, Ltt: d L_z / dt, d L_t / dt (to carry L_z, L_t along the step to first order).
+template <typename S, int NQ> struct PortEvalN { S Lt[NQ], Lz[NQ], dt[NQ], Ltt[NQ], Lzt[NQ]; };
+template <int NS, typename S, int NQ>
+__device__ __forceinline__ void port_eval_n(S a0, S a1, S d_air, S G, const S (&W)[NQ], const S (&rho)[NQ], const S (&t)[NQ],
+                                            PortEvalN<S, NQ>& o)
+{
+    const S a02 = a0 * a0, a12 = a1 * a1;
+    S x[NQ], r[NQ], s_[NQ], s2[NQ], icg[NQ], icw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x[q] = S(1) + t[q] * t[q];
+    pe_rsq_n<NS, NQ>(x, r);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s_[q] = t[q] * r[q];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s2[q] = s_[q] * s_[q];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x[q] = S(1) - a02 * s2[q];
+    pe_rsq_n<NS, NQ>(x, icg);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x[q] = S(1) - a12 * s2[q];
+    pe_rsq_n<NS, NQ>(x, icw);
+    S icg2[NQ], icw2[NQ], g1[NQ], w1[NQ], g3[NQ], w3[NQ], q3[NQ], r2[NQ], r3[NQ], L[NQ], f[NQ], Lt2[NQ], den[NQ], h[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { icg2[q] = icg[q] * icg[q]; icw2[q] = icw[q] * icw[q]; g1[q] = G * icg[q]; w1[q] = W[q] * icw[q]; r2[q] = r[q] * r[q]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { g3[q] = g1[q] * icg2[q]; w3[q] = w1[q] * icw2[q]; r3[q] = r2[q] * r[q]; L[q] = g1[q] + w1[q]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { q3[q] = g3[q] + w3[q]; L[q] = d_air * t[q] + s_[q] * L[q]; o.Lz[q] = a1 * s_[q] * icw[q]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { o.Lt[q] = d_air + r3[q] * q3[q]; h[q] = a02 * g3[q] * icg2[q] + a12 * w3[q] * icw2[q]; f[q] = L[q] - rho[q]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { h[q] = s_[q] * r[q] * h[q] - t[q] * q3[q]; o.Lzt[q] = a1 * r3[q] * icw[q] * icw2[q]; Lt2[q] = o.Lt[q] * o.Lt[q]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) o.Ltt[q] = S(3) * r3[q] * r2[q] * h[q];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) den[q] = fmax(S(2) * Lt2[q] - f[q] * o.Ltt[q], Lt2[q]);
+    pe_rcp_n<NS, NQ>(den, h);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) o.dt[q] = -S(2) * f[q] * o.Lt[q] * h[q];
+}
+
+// ---- the sums of the fold (double) --------------------------------------------------------------------------------------
+struct PixAcc {
+    double Saa[6], Sac[9], Scc[6], sa[3], sc[3];          // symmetric ones in the order 00 01 02 11 12 22
+    static constexpr int NVAL = 27;
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { Saa[i] = 0.0; Scc[i] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Sac[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { sa[i] = 0.0; sc[i] = 0.0; }
+    }
+    __device__ __forceinline__ double& at(int k)
+    {
+        return k < 6 ? Saa[k] : (k < 15 ? Sac[k - 6] : (k < 21 ? Scc[k - 15] : (k < 24 ? sa[k - 21] : sc[k - 24])));
+    }
+    // one corner: N' = sum a a' (sym, 00 01 02 11 12 22), n' = sum a r over its rows, r = ru = R'(c_w - p)
+    __device__ __forceinline__ void add_corner(const double* Np, const double* np, const double* r)
+    {
+        // full symmetric N'
+        const double N00 = Np[0], N01 = Np[1], N02 = Np[2], N11 = Np[3], N12 = Np[4], N22 = Np[5];
+        const double Nf[9] = { N00, N01, N02, N01, N11, N12, N02, N12, N22 };
+        // Q = N' [r]x :  column 0 = N'(:,1) r2 - N'(:,2) r1, column 1 = N'(:,2) r0 - N'(:,0) r2, column 2 = N'(:,0) r1 - N'(:,1) r0
+        double Q[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            Q[3 * i + 0] = Nf[3 * i + 1] * r[2] - Nf[3 * i + 2] * r[1];
+            Q[3 * i + 1] = Nf[3 * i + 2] * r[0] - Nf[3 * i + 0] * r[2];
+            Q[3 * i + 2] = Nf[3 * i + 0] * r[1] - Nf[3 * i + 1] * r[0];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Saa[i] += Np[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Sac[i] += Q[i];
+        // [r]x' Q :  row 0 = r2 Q(1,:) - r1 Q(2,:), row 1 = r0 Q(2,:) - r2 Q(0,:), row 2 = r1 Q(0,:) - r0 Q(1,:)
+        Scc[0] += r[2] * Q[3] - r[1] * Q[6];
+        Scc[1] += r[2] * Q[4] - r[1] * Q[7];
+        Scc[2] += r[2] * Q[5] - r[1] * Q[8];
+        Scc[3] += r[0] * Q[7] - r[2] * Q[1];
+        Scc[4] += r[0] * Q[8] - r[2] * Q[2];
+        Scc[5] += r[1] * Q[2] - r[0] * Q[5];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sa[i] += np[i];
+        sc[0] += np[1] * r[2] - np[2] * r[1];           // n' x r
+        sc[1] += np[2] * r[0] - np[0] * r[2];
+        sc[2] += np[0] * r[1] - np[1] * r[0];
+    }
+    // -> the 6 x 6 information matrix (upper triangle, lidx order) and vector of the stacked rows
+    //    Lam_pp = w R S_aa R',  Lam_pt = -w R S_ac,  Lam_tt = w S_cc,  b_p = -w R s_a,  b_t = w s_c
+    __device__ __forceinline__ void finish(const double* R, double w, double* Lam, double* b) const
+    {
+        const double Sf[9] = { Saa[0], Saa[1], Saa[2], Saa[1], Saa[3], Saa[4], Saa[2], Saa[4], Saa[5] };
+        double T1[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) T1[3 * i + k] = R[3 * i] * Sf[k] + R[3 * i + 1] * Sf[3 + k] + R[3 * i + 2] * Sf[6 + k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = i; j < 3; ++j)
+                Lam[lidx(i, j)] = w * (T1[3 * i] * R[3 * j] + T1[3 * i + 1] * R[3 * j + 1] + T1[3 * i + 2] * R[3 * j + 2]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                Lam[lidx(i, 3 + j)] = -w * (R[3 * i] * Sac[j] + R[3 * i + 1] * Sac[3 + j] + R[3 * i + 2] * Sac[6 + j]);
+            b[i] = -w * (R[3 * i] * sa[0] + R[3 * i + 1] * sa[1] + R[3 * i + 2] * sa[2]);
+            b[3 + i] = w * sc[i];
+        }
+        Lam[lidx(3, 3)] = w * Scc[0]; Lam[lidx(3, 4)] = w * Scc[1]; Lam[lidx(3, 5)] = w * Scc[2];
+        Lam[lidx(4, 4)] = w * Scc[3]; Lam[lidx(4, 5)] = w * Scc[4]; Lam[lidx(5, 5)] = w * Scc[5];
+    }
+};
+
+// ---- one marker: 4 corners x NCAM cameras in lock step --------------------------------------------------------------------
+// p, R: the filter's position and carried rotation (double copies of the record's values); mkc: the map slot (corner 0, x axis,
+// y axis); yl / yr: the 8 + 8 measured image coordinates.  Every stage is written across the NP = 4 NCAM projections (see md_rsq_n).
+// One evaluation of the port equation per projection in the common case (see below).
+template <int NCAM, typename T>
+__device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, const double* R, const MeasConst& mc,
+                                                  const double* mkc, const T* yl, const T* yr, double size)
+{
+    constexpr int NS = sizeof(T) == 8 ? 2 : 1;           // Newton steps behind v_rsq_f64 / v_rcp_f64
+    constexpr int NP = 4 * NCAM;
+    double ru[4][3];
+    {
+        double u0[3], ru0[3], rAx[3], rAy[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u0[i] = mkc[i] - p[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ru0[i] = R[i] * u0[0] + R[3 + i] * u0[1] + R[6 + i] * u0[2];                                   // R'(C0 - p)
+            rAx[i] = size * (R[i] * mkc[3] + R[3 + i] * mkc[4] + R[6 + i] * mkc[5]);
+            rAy[i] = size * (R[i] * mkc[6] + R[3 + i] * mkc[7] + R[6 + i] * mkc[8]);
+        }
+        // corners c_k = (0,0,0), (0,s,0), (s,s,0), (s,0,0) of the marker frame (vision.cpp:736-759)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ru[0][i] = ru0[i];
+            ru[1][i] = ru0[i] + rAy[i];
+            ru[2][i] = ru0[i] + rAx[i] + rAy[i];
+            ru[3][i] = ru0[i] + rAx[i];
+        }
+    }
+    const double* n = mc.n;
+    // per projection q = (corner k, camera c): lateral offset, depth, visibility, and the start of the port equation's solution
+    double lat[NP][3], rho[NP], irho[NP], Wd[NP], vis[NP], t[NP];
+    {
+        double X[NP][3], z[NP], r2[NP], zwq[NP], r2s[NP], xs[NP], ir0[NP], ze[NP];
+        bool ok[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int k = q / NCAM, c = q % NCAM;
+            const double* M = c ? mc.McR : mc.McL;
+            const double tI[3] = { ru[k][0] - mc.P_IL[0], ru[k][1] - mc.P_IL[1], ru[k][2] - mc.P_IL[2] };
+#pragma unroll
+            for (int i = 0; i < 3; ++i) X[q][i] = M[3 * i] * tI[0] + M[3 * i + 1] * tI[1] + M[3 * i + 2] * tI[2] + (c ? mc.tR[i] : 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) z[q] = X[q][0] * n[0] + X[q][1] * n[1] + X[q][2] * n[2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) lat[q][i] = X[q][i] - z[q] * n[i];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { r2[q] = lat[q][0] * lat[q][0] + lat[q][1] * lat[q][1] + lat[q][2] * lat[q][2]; zwq[q] = z[q] - mc.d_air - mc.d_glass; }
+        // in front of the port and inside its field of view (in water no ray leans further than asin(n_air / n_water); 0.9 of that
+        // limit, as the oracle): otherwise the corner contributes no rows to this camera.  A point out of view is replaced by a
+        // harmless one on the axis (rho = 0, 1 / rho = 0, one metre of water): everything below stays finite, its rows get weight 0
+        const double c0 = (mc.d_air + mc.d_glass * mc.a0) / mc.a1;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double lim = 0.9 * zwq[q] * mc.a1;
+            ok[q] = (zwq[q] > 0.0) && (r2[q] * (1.0 - mc.a1 * mc.a1) < lim * lim);
+            vis[q] = ok[q] ? 1.0 : 0.0;
+            r2s[q] = ok[q] ? r2[q] : 0.0;
+            const double zs = ok[q] ? zwq[q] : 1.0;
+            Wd[q] = zs * mc.a1;
+            ze[q] = zs + c0;
+            xs[q] = r2s[q] > 0.0 ? r2s[q] : 1.0;
+        }
+        md_rsq_n<NS, NP>(xs, ir0);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { irho[q] = (r2s[q] > 0.0) ? ir0[q] : 0.0; rho[q] = r2s[q] * irho[q]; }
+        // Start: the THIN-port solution in closed form, twice.  With the port's own offsets folded into an effective water depth
+        // z_e = z_w + (d_air + d_glass a0) / a1 (exact in the paraxial limit) the equation is rho = z_e tan(theta_water) with
+        // sin(theta_water) = a1 sin(theta_air):  t0 = u / sqrt(a1^2 - (1 - a1^2) u^2),  u = rho / z_e  -- within 1.4e-3 of the root for
+        // 0.25 .. 2 m of water and tangents up to 1.4, but 1.9e-2 at the rim of the admitted field of view (tangent 3).  Then the
+        // port's offsets AT t0 are taken off rho and the thin-port equation is solved once more for the water alone:
+        //     u1 = (rho - d_air t0 - d_glass tan(theta_glass(t0))) / z_w,   t1 = u1 / sqrt(a1^2 - (1 - a1^2) u1^2)
+        // -- within 1.7e-3 everywhere, 1e-4 inside tangent 1.4 (tools/emul_meas_fold.py).  The hardware estimates (2^-23) are good
+        // enough for a start.  Measured in one run (65 536 filters x 16 slots, left / stereo): second pass always 79.4 / 120.0 us,
+        // only for the waves that hold a tangent > 1.3 (voted, applied per lane) 78.3 / 124.0 -- the branch costs more than the
+        // pass --, never 76.0 / 113.2 (and 1.6e-4 off at the rim).
+        const double q1 = 1.0 - mc.a1 * mc.a1, a12 = mc.a1 * mc.a1, Gd0 = mc.d_glass * mc.a0;
+        double u[NP], w_[NP], r_[NP], s_[NP], izw[NP];
+        md_rcp_n<0, NP>(ze, u);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { u[q] *= rho[q]; w_[q] = fmax(a12 - q1 * u[q] * u[q], 1e-6); }
+        md_rsq_n<0, NP>(w_, w_);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { t[q] = u[q] * w_[q]; r_[q] = 1.0 + t[q] * t[q]; izw[q] = Wd[q]; }
+        md_rsq_n<0, NP>(r_, r_);
+        md_rcp_n<0, NP>(izw, izw);                                      // 1 / (z_w a1)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { s_[q] = t[q] * r_[q]; w_[q] = 1.0 - mc.a0 * mc.a0 * s_[q] * s_[q]; }
+        md_rsq_n<0, NP>(w_, w_);                                        // 1 / cos(theta_glass)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            u[q] = fmax((rho[q] - mc.d_air * t[q] - Gd0 * s_[q] * w_[q]) * izw[q] * mc.a1, 0.0);
+            w_[q] = fmax(a12 - q1 * u[q] * u[q], 1e-6);
+        }
+        md_rsq_n<0, NP>(w_, w_);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) t[q] = u[q] * w_[q];
+    }
+    // ONE Halley step in double from there (cubic: a step of size dt leaves ~0.06 |dt|^3, measured -- <= 1.6e-10 from the start
+    // above, below what an fp32 posterior can see); fp64 records take a second one, which reaches double precision.  No
+    // iteration, no wave vote, and nothing depends on the measured image point.
+    // (Round-4 history: Newton in fp32 from the paraxial start, 3-4 voted steps; from the measured ray 2-3; Halley from the
+    // measured ray 1-2, then one in double; this form: one evaluation of the port equation.)
+    double iLt[NP], c2[NP];
+    {
+        constexpr int NFIN = sizeof(T) == 8 ? 2 : 1;
+        PortEvalN<double, NP> f;
+        const double Gd = mc.d_glass * mc.a0;
+#pragma unroll
+        for (int rep = 0; rep < NFIN; ++rep) {
+            port_eval_n<NS, double, NP>(mc.a0, mc.a1, mc.d_air, Gd, Wd, rho, t, f);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) t[q] = fmax(t[q] + f.dt[q], 0.0);
+        }
+        // L_t and L_z for the Jacobian, carried along the last step to first order (they were evaluated in front of it)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { f.Lt[q] += f.Ltt[q] * f.dt[q]; f.Lz[q] += f.Lzt[q] * f.dt[q]; }
+        md_rcp_n<NS, NP>(f.Lt, iLt);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) c2[q] = f.Lz[q] * iLt[q];
+    }
+    double kk[NP], Dz[NP], iDz[NP], uv[NP][2], e[NP][3], eM[NP][3];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) kk[q] = (irho[q] > 0.0) ? t[q] * irho[q] : iLt[q];          // t / rho; on the axis its limit 1 / L_t
+#pragma unroll
+    for (int q = 0; q < NP; ++q) Dz[q] = n[2] + kk[q] * lat[q][2];
+    md_rcp_n<NS, NP>(Dz, iDz);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        uv[q][0] = (n[0] + kk[q] * lat[q][0]) * iDz[q];
+        uv[q][1] = (n[1] + kk[q] * lat[q][1]) * iDz[q];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[q][i] = lat[q][i] * irho[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const double* M = (q % NCAM) ? mc.McR : mc.McL;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) eM[q][j] = e[q][0] * M[j] + e[q][1] * M[3 + j] + e[q][2] * M[6 + j];
+    }
+    // rows: J_r = alpha e' + beta n' + k g',  g = (unit_r - uv_r unit_z) / D_z;  a = (J_r Mc)' masked by visibility
+    double a[NP][2][3], res[NP][2];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int k = q / NCAM, c = q % NCAM;
+        const double* M = c ? mc.McR : mc.McL;
+        const double* nM = c ? mc.nMR : mc.nML;
+        const T* y = c ? yr : yl;
+        const double c1 = iLt[q] - kk[q];
+        const double kz = kk[q] * iDz[q] * vis[q];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double ge = (e[q][r] - uv[q][r] * e[q][2]) * iDz[q], gn = (n[r] - uv[q][r] * n[2]) * iDz[q];
+            const double am = ge * c1 * vis[q], bm = -(c2[q] * ge + kk[q] * gn) * vis[q];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[q][r][j] = am * eM[q][j] + bm * nM[j] + kz * (M[3 * r + j] - uv[q][r] * M[6 + j]);
+            res[q][r] = (double)y[2 * k + r] - uv[q][r];
+        }
+    }
+    double Np[4][6], np[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Np[k][i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) np[k][i] = 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < NCAM; ++c)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double* ar = a[k * NCAM + c][r];
+                Np[k][0] += ar[0] * ar[0]; Np[k][1] += ar[0] * ar[1]; Np[k][2] += ar[0] * ar[2];
+                Np[k][3] += ar[1] * ar[1]; Np[k][4] += ar[1] * ar[2]; Np[k][5] += ar[2] * ar[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) np[k][j] += ar[j] * res[k * NCAM + c][r];
+            }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc.add_corner(Np[k], np[k], ru[k]);
+}
+
+// ---- the 6 x 6 stage in double ----------------------------------------------------------------------------------------------
+// in: Lam (21, lidx order), b (6), PJJ (36, full symmetric);  out: G = (I + P_JJ Lam)^-1 (36), Sinv = (Lam^-1 + P_JJ)^-1 (21,
+// lidx order), m = G' b (6)
+__host__ __device__ constexpr int ltx(int i, int j) { return i * (i + 1) / 2 + j; }      // lower triangle, j <= i
+template <typename T>
+__device__ __forceinline__ void info_solve(const double* Lam, const double* b, const double* PJJ, T* G, T* Sinv, T* m)
+{
+    // Lam = Lc Lc' (no pivoting: Lam is positive semi-definite; a pivot that is not clearly positive relative to its original
+    // diagonal carries no information and its column is dropped -- joint_factor's rule)
+    double Lc[21];
+    {
+        double A[21];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) A[ltx(i, j)] = Lam[lidx(j, i)];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double piv = A[ltx(a, a)];
+            const bool ok = piv > 4e-15 * Lam[lidx(a, a)];
+            const double s0 = md_rsq(ok ? piv : 1.0);
+            const double s = ok ? s0 : 0.0;
+#pragma unroll
+            for (int i = a; i < 6; ++i) Lc[ltx(i, a)] = A[ltx(i, a)] * s;
+#pragma unroll
+            for (int i = a + 1; i < 6; ++i)
+#pragma unroll
+                for (int j = a + 1; j <= i; ++j) A[ltx(i, j)] -= Lc[ltx(i, a)] * Lc[ltx(j, a)];
+        }
+    }
+    // Y = P_JJ Lc ;  Mt = I + Lc' Y  (symmetric, eigenvalues >= 1) = Cm Cm'
+    double Y[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = j; k < 6; ++k) s += PJJ[6 * i + k] * Lc[ltx(k, j)];
+            Y[6 * i + j] = s;
+        }
+    double Cm[21], iC[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = i; k < 6; ++k) s += Lc[ltx(k, i)] * Y[6 * k + j];
+            Cm[ltx(i, j)] = s;
+        }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double s = md_rsq(Cm[ltx(a, a)]);
+        iC[a] = s;
+#pragma unroll
+        for (int i = a; i < 6; ++i) Cm[ltx(i, a)] *= s;
+#pragma unroll
+        for (int i = a + 1; i < 6; ++i)
+#pragma unroll
+            for (int j = a + 1; j <= i; ++j) Cm[ltx(i, j)] -= Cm[ltx(i, a)] * Cm[ltx(j, a)];
+    }
+    // Z Cm' = Lc, row by row: z_j = (lc_ij - sum_{k<j} z_k Cm(j,k)) / Cm(j,j)
+    double Zd[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double s = (j <= i) ? Lc[ltx(i, j)] : 0.0;
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= Zd[6 * i + k] * Cm[ltx(j, k)];
+            Zd[6 * i + j] = s * iC[j];
+        }
+    // Sinv = Z Z' ;  G = I - P_JJ Sinv ;  m = G' b
+    double Si[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += Zd[6 * i + k] * Zd[6 * j + k];
+            Si[6 * i + j] = s; Si[6 * j + i] = s;
+        }
+    double Gd[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s -= PJJ[6 * i + k] * Si[6 * k + j];
+            Gd[6 * i + j] = s;
+        }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s += Gd[6 * i + j] * b[i];
+        m[j] = (T)s;
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) G[i] = (T)Gd[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) Sinv[lidx(i, j)] = (T)Si[6 * i + j];
+}
+
+// ---- the update of the N x N covariance and the error state, type T, whole covariance resident --------------------------
+// J = the p and theta columns (state indices jcol(0..5)); r = the other N - 6; x_c = P(J, c).
+//   dx       = P(:, J) m
+//   P(a, c) -= x_a' Sinv x_c                  a <= c in r                     (the physical cancellation only)
+//   P(J, c)  = G x_c                          all c: a product, nothing is subtracted
+__host__ __device__ constexpr int rcol(int k) { return k < 3 ? 3 + k : 6 + k; }           // k-th state index outside J
+template <typename T, int N>
+__device__ __forceinline__ void direct_update(T* P, T* dx, const T* G, const T* Sinv, const T* m)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+    constexpr int NR_ = N - 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T s = PS(i, jcol(0)) * m[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) s += PS(i, jcol(k)) * m[k];
+        dx[i] = s;
+    }
+    // the block outside J, column by column: t = Sinv x_c, then P(a, c) -= x_a . t for the columns a <= c (the x are still the old ones)
+#pragma unroll
+    for (int c = 0; c < NR_; ++c) {
+        T t[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            T s = Sinv[lidx(0, i)] * PS(jcol(0), rcol(c));
+#pragma unroll
+            for (int j = 1; j < 6; ++j) s += Sinv[j <= i ? lidx(j, i) : lidx(i, j)] * PS(jcol(j), rcol(c));
+            t[i] = s;
+        }
+#pragma unroll
+        for (int a = 0; a <= c; ++a) {
+            T s = PS(jcol(0), rcol(a)) * t[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) s += PS(jcol(k), rcol(a)) * t[k];
+            PS(rcol(a), rcol(c)) -= s;
+        }
+    }
+    // the J x J block from the old values (upper triangle of G P_JJ), then the J x r columns in place
+    {
+        T nj[21];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                T s = G[6 * i] * PS(jcol(0), jcol(j));
+#pragma unroll
+                for (int k = 1; k < 6; ++k) s += G[6 * i + k] * PS(jcol(k), jcol(j));
+                nj[lidx(i, j)] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) PS(jcol(i), jcol(j)) = nj[lidx(i, j)];
+    }
+#pragma unroll
+    for (int c = 0; c < NR_; ++c) {
+        T x[6], y[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) x[j] = PS(jcol(j), rcol(c));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            T s = G[6 * i] * x[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) s += G[6 * i + j] * x[j];
+            y[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) PS(jcol(i), rcol(c)) = y[i];
+    }
+#undef PS
+}
+
+// Marker map of the pixel fold in LDS: id -> slot (the table of the other kernels) and the double-precision corner frame of
+// every slot.
+struct alignas(16) MeasLDS {
+    short id2slot[FBUS_MAX_MARKER_ID + 1];
+    double mkc[FBUS_MAX_MARKERS * MKC_STRIDE];
+};
+
+// =================================================================================
+// correct() from corner pixels: all visible markers, 2 (left camera) or 4 (stereo) reprojection rows per corner, one
+// linearisation point.  One filter per lane; NR waves ("roles") per 64-filter tile divide the markers among themselves
+// (role r folds markers r, r + NR, ...; their sums meet in LDS, in role order) and role 0 applies the update.
+// =================================================================================
+template <typename T, int N, int NR>
+__global__ void __launch_bounds__(64 * NR)
+correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
+                       const T* __restrict__ right, double size, double r_pix, const unsigned char* __restrict__ skip,
+                       unsigned char* __restrict__ applied, const short* __restrict__ id2slot, MeasConst mc)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    constexpr int NT = 64 * NR;
+    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned tile = blockIdx.x;
+    const int b = (int)(tile * 64u + lane);
+    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
+    const int bc = b < B ? b : (int)(tile * 64u);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    __shared__ MeasLDS tbl;
+    __shared__ double part_mem[(NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1)];
+    struct Meas { int id; T l[8], r[8]; };
+    const bool stereo = right != nullptr;
+    // the id and the 8 (+ 8) image coordinates of marker slot i: 16-byte loads (a slot's 8 coordinates are 32 / 64 contiguous bytes)
+    auto fetch = [&](int i, Meas& mm) __attribute__((always_inline)) {
+        const size_t o = (size_t)bc * M + i;
+        constexpr int EP = 16 / (int)sizeof(T);
+        mm.id = ids[o];
+        const u32x4* pl = reinterpret_cast<const u32x4*>(left + o * 8);
+        const u32x4* pr = reinterpret_cast<const u32x4*>((stereo ? right : left) + o * 8);
+#pragma unroll
+        for (int c = 0; c < 8 / EP; ++c) {
+            const u32x4 vl = pl[c], vr = pr[c];
+            const T* el = reinterpret_cast<const T*>(&vl);
+            const T* er = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+            for (int k = 0; k < EP; ++k) { mm.l[c * EP + k] = el[k]; mm.r[c * EP + k] = er[k]; }
+        }
+    };
+    Meas cur, nxt;
+    T pqr[L::NPQR];
+    {
+        // the marker map -> LDS (all threads), this role's first marker, the pose part of the nominal state
+        constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(double) * FBUS_MAX_MARKERS * MKC_STRIDE / 16;
+        constexpr int PI = (NI + NT - 1) / NT, PM = (NM + NT - 1) / NT;
+        const u32x4* si = reinterpret_cast<const u32x4*>(id2slot);
+        const u32x4* sm = reinterpret_cast<const u32x4*>(mc.mkc);
+        u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
+        u32x4* dm = reinterpret_cast<u32x4*>(tbl.mkc);
+        u32x4 vi[PI], vm[PM];
+#pragma unroll
+        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; vi[q] = si[i < NI ? i : 0]; }
+#pragma unroll
+        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; vm[q] = sm[i < NM ? i : 0]; }
+        order_fence();
+        if (M > 0) fetch((int)role < M ? (int)role : M - 1, cur);
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, lane, pqr);
+        order_fence();
+#pragma unroll
+        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; if (i < NI) di[i] = vi[q]; }
+#pragma unroll
+        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; if (i < NM) dm[i] = vm[q]; }
+        order_fence();
+    }
+    if constexpr (NR > 1) meas_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double pd[3], Rd[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pd[i] = (double)pqr[L::OFF_P3 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rd[i] = (double)pqr[L::OFF_R + i];
+    PixAcc acc;
+    acc.clear();
+    double nfold = 0.0;                                          // markers of the map this role has folded
+    const int last = live ? M : 0;
+#pragma unroll 1
+    for (int i = (int)role; i < last; i += NR) {
+        fetch(i + NR < M ? i + NR : M - 1, nxt);                // always a fresh load (no conditional merge of the two records)
+        const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
+        const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
+        if (slot >= 0) {
+            double mk[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
+            if (stereo) pixel_fold_marker<2, T>(acc, pd, Rd, mc, mk, cur.l, cur.r, size);
+            else pixel_fold_marker<1, T>(acc, pd, Rd, mc, mk, cur.l, cur.l, size);
+            nfold += 1.0;
+        }
+        cur = nxt;
+    }
+    if constexpr (NR > 1) {
+        // partial sums through LDS: value i of role r at part_mem[((r - 1) * (NVAL + 1) + i) * 64 + lane]
+        if (role != 0) {
+            double* part = part_mem + ((role - 1) * (PixAcc::NVAL + 1)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < PixAcc::NVAL; ++i) part[i * 64] = acc.at(i);
+            part[PixAcc::NVAL * 64] = nfold;
+            meas_barrier();
+            return;
+        }
+        meas_barrier();
+#pragma unroll
+        for (int r = 1; r < NR; ++r) {
+            const double* part = part_mem + ((r - 1) * (PixAcc::NVAL + 1)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < PixAcc::NVAL; ++i) acc.at(i) += part[i * 64];
+            nfold += part[PixAcc::NVAL * 64];
+        }
+    }
+    if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
+    // the covariance is requested here: it arrives under the 6 x 6 stage
+    T P[RC::NCOVP];
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
+    double Lam[21], bv[6];
+    acc.finish(Rd, 1.0 / r_pix, Lam, bv);
+    T G[36], Sinv[21], m[6];
+    {
+        double PJJ[36];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
+        info_solve<T>(Lam, bv, PJJ, G, Sinv, m);
+    }
+    T dx[N];
+    direct_update<T, N>(P, dx, G, Sinv, m);
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
+    inject<T, N>(nom, dx);
+    // write-through (sc1) as correct_kernel: the lines reach the Infinity Cache at once instead of being written back from the L2s
+    // under the tail of the launch
+    store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);
+    applied[b] = 1;
+}
+
+}  // namespace

@@ -57,6 +57,7 @@ void rotmat_to_quat(const double R[9], double q[4])
 struct HostConst {
     double R_IL[9], P_IL[3], Q_IL[4], CL[16];
     std::vector<double> mk;             // n_markers x MK_STRIDE
+    std::vector<double> mkc;            // FBUS_MAX_MARKERS x MKC_STRIDE: corner 0, x axis, y axis of every marker (pixel fold, double)
     std::vector<short> id2slot;
 };
 
@@ -77,6 +78,7 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
     if (prm.n_markers < 0 || prm.n_markers > FBUS_MAX_MARKERS) { err = "n_markers out of range"; return false; }
     hc.id2slot.assign(FBUS_MAX_MARKER_ID + 1, (short)-1);
     hc.mk.assign((size_t)FBUS_MAX_MARKERS * MK_STRIDE, 0.0);        // always the full table: kernels copy it to LDS whole
+    hc.mkc.assign((size_t)FBUS_MAX_MARKERS * MKC_STRIDE, 0.0);
     const double w = hc.Q_IL[0], x = hc.Q_IL[1], y = hc.Q_IL[2], z = hc.Q_IL[3];
     // Lq(Q_IL) * L2, L2 = diag(1,-1,-1,-1)   MeasureUpdate.m:39-44
     const double LL2[16] = { w,  x,  y,  z,
@@ -96,6 +98,12 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
         // c_m = 1/4 |Q_IL|^2 |Qm|^2: the isotropic information of the marker's four quaternion rows per unit weight and |q|^2
         // (PoseFold, ekf_device.hpp)
         m[7] = 0.25 * (w * w + x * x + y * y + z * z) * (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        // the marker frame of the corner / pixel rows in double: R_m = rotmat(quat(marker_rot)) as the other kernels (and the
+        // oracle) build it -- quaternion_to_rotmat.m:22-33 -- corner k at P_m + R_m c_k, c_k in the marker's x-y plane
+        double* c = &hc.mkc[(size_t)k * MKC_STRIDE];
+        const double Rm0[3] = { q[0] * q[0] + q[1] * q[1] - q[2] * q[2] - q[3] * q[3], 2 * (q[1] * q[2] + q[0] * q[3]), 2 * (q[1] * q[3] - q[0] * q[2]) };
+        const double Rm1[3] = { 2 * (q[1] * q[2] - q[0] * q[3]), q[0] * q[0] - q[1] * q[1] + q[2] * q[2] - q[3] * q[3], 2 * (q[2] * q[3] + q[0] * q[1]) };
+        for (int i = 0; i < 3; ++i) { c[i] = prm.marker_pos[k][i]; c[3 + i] = Rm0[i]; c[6 + i] = Rm1[i]; }
     }
     return true;
 }
@@ -128,7 +136,9 @@ struct fbus_ekf {
     bool own_recs = false;
     size_t rec_bytes = 0, bytes_per_filter = 0;
     void* d_mk = nullptr;
+    double* d_mkc = nullptr;            // HostConst::mkc on the device
     short* d_id2slot = nullptr;
+    bool pixels_legacy = false;         // FBUS_PIXELS_LEGACY=1 (A/B runs): the round-3 fp32 pixel-row kernels instead of ekf_meas.hpp
     unsigned char* d_applied = nullptr;
     void* d_ema_carry = nullptr;        // B x 6, previous EMA-filtered IMU sample
     bool ema_has_carry = false;
@@ -263,6 +273,14 @@ int team_roles_predict(const fbus_ekf* h, int K)
 int team_roles_corners(const fbus_ekf* h, int mode, int M)
 {
     if (h->dtype != 32 || h->prm.cov_form == FBUS_COV_JOSEPH || mode != MODE_STACKED || M < 2 || h->team_correct == 1) return 1;
+    if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
+    const int tiles = (h->B + 63) / 64;
+    return tiles <= 256 ? 4 : (tiles <= 512 ? 2 : 1);
+}
+// round-4 pixel-row kernel (correct_pixels2_kernel): roles divide the markers; both record types
+int team_roles_pixels(const fbus_ekf* h, int M)
+{
+    if (M < 2 || h->team_correct == 1) return 1;
     if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
     const int tiles = (h->B + 63) / 64;
     return tiles <= 256 ? 4 : (tiles <= 512 ? 2 : 1);
@@ -523,6 +541,39 @@ VisConst<T> make_vc(const fbus_ekf* h)
     return vc;
 }
 
+// constants of the round-4 pixel fold (double whatever the record type)
+MeasConst make_mc(const fbus_ekf* h)
+{
+    const fbus_params& p = h->prm;
+    const VisConst<double> vc = make_vc<double>(h);
+    MeasConst mc;
+    for (int i = 0; i < 3; ++i) mc.P_IL[i] = h->hc.P_IL[i];
+    // XL = F R_IL t_I (the triangulation's axis flip undone, vision.cpp:597-599); XR = R_RL^-1 (XL - P_LR) (vision.cpp:555-556)
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) mc.McL[3 * i + j] = (i < 2 ? -1.0 : 1.0) * h->hc.R_IL[3 * i + j];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            double a = 0;
+            for (int k = 0; k < 3; ++k) a += vc.R_RL_inv[3 * i + k] * mc.McL[3 * k + j];
+            mc.McR[3 * i + j] = a;
+        }
+        double b = 0;
+        for (int k = 0; k < 3; ++k) b += vc.R_RL_inv[3 * i + k] * vc.P_LR[k];
+        mc.tR[i] = -b;
+    }
+    for (int j = 0; j < 3; ++j) {
+        mc.n[j] = p.port_normal[j];
+        mc.nML[j] = mc.nMR[j] = 0;
+    }
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) { mc.nML[j] += mc.n[i] * mc.McL[3 * i + j]; mc.nMR[j] += mc.n[i] * mc.McR[3 * i + j]; }
+    mc.a0 = p.n_air / p.n_glass;
+    mc.a1 = p.n_air / p.n_water;
+    mc.d_air = p.d_air; mc.d_glass = p.d_glass;
+    mc.mkc = h->d_mkc;
+    return mc;
+}
+
 template <typename T>
 int launch_marker_pose_t(fbus_ekf_t h, int n, int geometry, const void* left, const void* right, void* pos,
                          void* quat, void* corners3d)
@@ -589,6 +640,18 @@ int launch_correct_pixels_t(fbus_ekf_t h, int M, const int32_t* ids, const void*
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
     h->records_warm = true;
+    if (!h->pixels_legacy) {
+        h->records_warm = h->warm_after_correct;      // written through (sc1), as correct_kernel's records
+        // round 4: double-precision fold + non-cancelling update (ekf_meas.hpp), both record types, either covariance form
+        // (the form is symmetric by construction and subtracts nothing on the rows the measurement shrinks: what Joseph's
+        // form is chosen for)
+        const int roles = team_roles_pixels(h, M);
+        launch_pixels2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, roles,
+                                  h->prm.marker_size, h->prm.r_pix, (const unsigned char*)skip, h->d_applied, h->d_id2slot, make_mc(h));
+        timing_end(h, ev);
+        HIP_TRY(h, hipGetLastError());
+        return FBUS_OK;
+    }
     const int roles = team_roles_corners(h, MODE_STACKED, M);          // the pixel form is always stacked
     if constexpr (sizeof(T) == 4) {
         if (roles > 1)
@@ -776,6 +839,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
     if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
     if (const char* e = std::getenv("FBUS_TEAM_FRAME")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->team_frame = v; }
+    if (const char* e = std::getenv("FBUS_PIXELS_LEGACY")) h->pixels_legacy = std::atoi(e) != 0;
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
     h->device = device;
@@ -804,6 +868,8 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     } else {
         if (hipMemcpy(h->d_mk, h->hc.mk.data(), nmk * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(FBUS_ERR_HIP);
     }
+    if (hipMalloc((void**)&h->d_mkc, h->hc.mkc.size() * sizeof(double)) != hipSuccess) return bail(FBUS_ERR_NOMEM);
+    if (hipMemcpy(h->d_mkc, h->hc.mkc.data(), h->hc.mkc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return bail(FBUS_ERR_HIP);
     const size_t lut = h->hc.id2slot.size() * sizeof(short);
     if (hipMalloc((void**)&h->d_id2slot, lut) != hipSuccess) return bail(FBUS_ERR_NOMEM);
     if (hipMemcpy(h->d_id2slot, h->hc.id2slot.data(), lut, hipMemcpyHostToDevice) != hipSuccess) return bail(FBUS_ERR_HIP);
@@ -824,6 +890,7 @@ int fbus_ekf_destroy(fbus_ekf_t h)
     if (h->d_applied) (void)hipFree(h->d_applied);
     if (h->d_ema_carry) (void)hipFree(h->d_ema_carry);
     if (h->d_mk) (void)hipFree(h->d_mk);
+    if (h->d_mkc) (void)hipFree(h->d_mkc);
     if (h->d_id2slot) (void)hipFree(h->d_id2slot);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     (void)fbus_ekf_comm_destroy(h);

@@ -6,10 +6,12 @@
 //   4 correct from stereo corners
 //   5 frame window (F frames per launch)
 //   6 team kernels (several waves per tile: predict, predict_n, correct; fp32 only)
+//   7 correct from corner pixels, round-4 kernel (ekf_meas.hpp: double-precision fold, non-cancelling update)
 // gfx950 only.
 #include <cstdlib>
 #include "ekf_kernels.hpp"
 #include "ekf_team.hpp"
+#include "ekf_meas.hpp"
 #include <atomic>
 #include "ekf_launch.hpp"
 
@@ -298,8 +300,26 @@ void launch_pixels_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, 
                                                                  const FBUS_TU_T*, const FBUS_TU_T*, int, int,         \
                                                                  const unsigned char*, unsigned char*,                 \
                                                                  const DevConst<FBUS_TU_T>&);
+#elif FBUS_TU_FAMILY == 7
+template <typename T, int N, int D>
+void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, double size,
+                      double r_pix, const unsigned char* skip, unsigned char* applied, const short* id2slot, const MeasConst& mc)
+{
+    const int tiles = (B + 63) / 64;
+#define FBUS_LAUNCH_PX(NR)                                                                                               \
+    hipLaunchKernelGGL((correct_pixels2_kernel<T, N, NR>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, right, size, \
+                       r_pix, skip, applied, id2slot, mc)
+    if (roles >= 3) FBUS_LAUNCH_PX(4);
+    else if (roles == 2) FBUS_LAUNCH_PX(2);
+    else FBUS_LAUNCH_PX(1);
+#undef FBUS_LAUNCH_PX
+}
+#define FBUS_INST(D)                                                                                                   \
+    template void launch_pixels2_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*, const FBUS_TU_T*, \
+                                                            const FBUS_TU_T*, int, double, double, const unsigned char*, \
+                                                            unsigned char*, const short*, const MeasConst&);
 #else
-#error "FBUS_TU_FAMILY must be 1..6"
+#error "FBUS_TU_FAMILY must be 1..7"
 #endif
 
 FBUS_INST(DIALECT_MATLAB)

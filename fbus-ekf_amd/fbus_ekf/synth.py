@@ -170,14 +170,51 @@ def marker_frame(lo, hi, frame, M, nominal0, params, seed=BASE_SEED, noise=1e-3)
     return mids[slot].astype(np.int32), pos, quat
 
 
-def pixel_wall_scene(B, slots, params, size, seed=9, nbase=256, depth=(1.2, 1.8), noise=5e-4):
+def port_project(params, Xcam, right=False, iters=40):
+    """Forward flat-port projection in numpy (the oracle's fbv_project_camera, vectorised; used to build realistic image
+    measurements for the benches -- parity tests use the oracle itself): points (..., 3) of the LEFT camera frame as the
+    triangulation returns them (vision.cpp:597-599: x and y flipped) -> normalised image points (..., 2) of the left or right
+    camera and the visibility mask (in front of the port, inside 0.9 of its field of view).
+    rho = d_air t + d_glass tan(theta_glass) + z_w tan(theta_water), t = tan(theta_air), Snell twice; Newton from the
+    paraxial start (monotone: L is increasing and concave)."""
+    X = np.asarray(Xcam, float) * np.array([-1.0, -1.0, 1.0])
+    if right:
+        TL = np.array(list(params.T_SC_left), float).reshape(4, 4)
+        TR = np.array(list(params.T_SC_right), float).reshape(4, 4)
+        R_RL = TL[:3, :3] @ TR[:3, :3].T
+        P_LR = TL[:3, 3] - R_RL @ TR[:3, 3]
+        X = np.einsum("ij,...j->...i", np.linalg.inv(R_RL), X - P_LR)
+    n = np.array(list(params.port_normal), float)
+    a0, a1 = params.n_air / params.n_glass, params.n_air / params.n_water
+    z = X @ n
+    lat = X - z[..., None] * n
+    rho = np.sqrt((lat * lat).sum(-1))
+    zw = z - params.d_air - params.d_glass
+    ok = (zw > 0) & (rho < 0.9 * np.where(zw > 0, zw, 0) * a1 / np.sqrt(1 - a1 * a1))
+    zs = np.where(ok, zw, 1.0)
+    rs = np.where(ok, rho, 0.0)
+    t = rs / (params.d_air + a0 * params.d_glass + a1 * zs)
+    for _ in range(iters):
+        r = 1.0 / np.sqrt(1.0 + t * t)
+        s = t * r
+        icg, icw = 1.0 / np.sqrt(1.0 - a0 * a0 * s * s), 1.0 / np.sqrt(1.0 - a1 * a1 * s * s)
+        g, w = params.d_glass * a0 * icg, zs * a1 * icw
+        L = params.d_air * t + s * (g + w)
+        Lt = params.d_air + (g * icg * icg + w * icw * icw) * r ** 3
+        t = np.maximum(t + (rs - L) / Lt, 0.0)
+    k = np.where(rs > 0, t / np.where(rs > 0, rs, 1.0), 0.0)
+    D = n + k[..., None] * np.where(ok[..., None], lat, 0.0)
+    return D[..., :2] / D[..., 2:3], ok
+
+
+def pixel_wall_scene(B, slots, params, size, seed=9, nbase=256, depth=(1.2, 1.8), noise=5e-4, stereo=False):
     """Scene for the reprojection-row update (fbus_ekf_correct_pixels) at batch scale, without the oracle: REPLACES the marker map
     in `params` by a 4 x 4 wall of 16 markers (ids 0..15, 0.3 m pitch, the orientation of the reference's marker 0:
     GetMarkerMap.m) and places `nbase` camera poses 1.2-1.8 m in front of it (repeated to B filters, positions jittered by 3 mm).
-    Returns (nominal (B,19), rot (B,9), ids (B,slots) with -1 padding, left (B,slots,8)): the markers in front of the left camera
-    and PIN-HOLE projections of their corners + noise as the measured image points.  The flat-port model is applied by the kernel
-    to the PREDICTED corners; its cost does not depend on the measured values, which is all a timing leg needs (parity tests use
-    the oracle's refractive projection instead, tests/util.py::pixel_scene)."""
+    Returns (nominal (B,19), rot (B,9), ids (B,slots) with -1 padding, left (B,slots,8)[, right (B,slots,8) with stereo=True]): the
+    markers in front of the port and the FLAT-PORT projections of their corners (port_project) + noise as the measured image points
+    (round 4: the kernel starts its Newton iteration from the measured point, so the timing legs need innovations of realistic
+    size; the nominal positions are then jittered by 3 mm).  Parity tests use the oracle's projection (tests/util.py::pixel_scene)."""
     rng = np.random.default_rng(seed)
     _, mpos, mquat = marker_table(params)
     R0 = np.array(list(params.marker_rot[0])).reshape(3, 3)
@@ -198,6 +235,7 @@ def pixel_wall_scene(B, slots, params, size, seed=9, nbase=256, depth=(1.2, 1.8)
     nom[:, 16] = 9.8
     ids = np.full((nbase, slots), -1, np.int32)
     left = np.zeros((nbase, slots, 8))
+    right = np.zeros((nbase, slots, 8))
     for b in range(nbase):
         while True:
             k0 = int(rng.integers(16))
@@ -210,19 +248,29 @@ def pixel_wall_scene(B, slots, params, size, seed=9, nbase=256, depth=(1.2, 1.8)
             p = -R @ R_IL.T @ yp + wall[k0] - R @ P_IL
             cam = np.einsum("ij,kcj->kci", R_IL @ R.T, world - p - R @ P_IL)        # (16, 4, 3)
             vis = (cam[:, :, 2].min(axis=1) > 0.25) & ((np.linalg.norm(cam[:, :, :2], axis=2) / cam[:, :, 2]).max(axis=1) < 0.8)
+            uvL, okL = port_project(params, cam)
+            vis &= okL.all(axis=1)
+            if stereo:
+                uvR, okR = port_project(params, cam, right=True)
+                vis &= okR.all(axis=1)
             if vis[k0]:
                 break
         nom[b, 0:3], nom[b, 6:10] = p, q
         order = [k0] + [k for k in rng.permutation(16) if k != k0 and vis[k]]
         for m, k in enumerate(order[:slots]):
             ids[b, m] = k
-            left[b, m] = (cam[k, :, :2] / cam[k, :, 2:3]).ravel() + rng.normal(0, noise, 8)
+            left[b, m] = uvL[k].ravel() + rng.normal(0, noise, 8)
+            if stereo:
+                right[b, m] = uvR[k].ravel() + rng.normal(0, noise, 8)
     rep = (B + nbase - 1) // nbase
     nom = np.tile(nom, (rep, 1))[:B]
     ids = np.tile(ids, (rep, 1))[:B]
     left = np.tile(left, (rep, 1, 1))[:B]
+    right = np.tile(right, (rep, 1, 1))[:B]
     nom[:, 0:3] += rng.normal(0, 0.003, (B, 3))
     r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
     nom = r32(nom)
     rot = r32(q2R(nom[:, 6:10]).reshape(B, 9))
+    if stereo:
+        return nom, rot, ids, r32(left), r32(right)
     return nom, rot, ids, r32(left)
