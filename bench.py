@@ -28,7 +28,7 @@ written back) / its average duration measured with HIP events on the launch stre
 `achieved_api` prices SURVEY.md 8(d)'s full record round trip (1620 B) instead.  `roofline_hbm_resident` is the
 same measurement at 1 048 576 filters per GPU (839 MB of records: three times the 256 MiB Infinity Cache);
 `roofline_b262144` the round-2 leg (210 MB: partly cache-resident).  `fp64` is the same workload through the fp64 kernels,
-`compute_bound` the 128-row reprojection update (correct_pixels).  `cpu_baseline` is the fp64 dense oracle port (oracle/),
+`north_star_rows` the same mixed schedule with the reprojection-row update (correct_pixels) in place of the pose update.  `cpu_baseline` is the fp64 dense oracle port (oracle/),
 timed on a bounded sample.
 """
 import argparse
@@ -401,53 +401,102 @@ def fp64_leg(torch, dev, local_rank, args, capi):
     return blk
 
 
-def pixels_leg(torch, dev, local_rank, args, capi, B=65536, SLOTS=16):
-    """BASELINE config 5's literal shape -- 16 marker slots x 4 corners x 2 rows = 128 stacked reprojection rows per filter through
-    the flat port (fbus_ekf_correct_pixels_dev, left camera) -- is the one COMPUTE-bound row of SURVEY.md 8(d): ~550 VALU
-    instructions per projected corner against 2.7 kB of traffic per filter.  Reported: launch time (HIP events), rows/s, and the
-    VALU issue fraction = wave-level VALU instructions of one launch (SQ_INSTS_VALU of the committed rocprofv3 pass,
-    profiles/r03_pixels_sq.json) / (launch time x 1024 SIMDs x clock / 4 cycles per wave64 instruction).
-    Inputs: a wall of 16 markers 1.2-1.8 m in front of the camera; the measured image points are pin-hole projections of the true
-    corners + noise (the kernel's work -- the refractive projection of the PREDICTED corners and its Jacobian -- does not depend
-    on the measured values)."""
+def _pixels_sq_profile():
+    """the committed SQ-counter digest of the pixel-row kernel (tools/r4_pixels_prof.sh -> profiles/r04_pixels_sq.json)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r04_pixels_sq.json")))
+    except Exception:
+        return None
+
+
+def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, warmup=1):
+    """The north star's OWN MeasureUpdate -- flat-port refractive stereo reprojection of the ArUco corners, per-corner 2 x N
+    Jacobians (fbus_ekf_correct_pixels_dev, csrc/ekf_meas.hpp) -- in the headline's mixed workload: the same 200 Hz + 30 Hz
+    schedule (7 / 7 / 6 per-call predicts, then a camera frame; one bench step = 1 s of sensor time = 230 EKF steps per filter)
+    with the correct launch replaced by
+        pixels_m4      4 marker slots, left camera: 32 reprojection rows per filter and frame
+        pixels_m16     16 marker slots (BASELINE config 5's shape): 128 rows, and the stereo form (256 rows) as one launch time
+        corners_m4     fbus_ekf_correct_corners_dev (stereo corners triangulated through the port on the device, 12 rows per marker)
+    Scene: a wall of 16 markers 1.2 - 1.8 m in front of the port, image points = flat-port projections of the true corners +
+    noise (synth.pixel_wall_scene), filters at rest.  Reported per case: EKF steps/s, ms per bench step, launch time of the update
+    (HIP events on the handle's stream), its algorithmic bytes (2 x 796 + 68 M) and their fraction of 8 TB/s, and --
+    these kernels are VALU-bound, that fraction is not what limits them -- the VALU issue fraction = wave-level VALU instructions of
+    one launch (SQ_INSTS_VALU, committed rocprofv3 pass profiles/r04_pixels_sq.json) / (launch time x SIMDs x clock / 4)."""
     from fbus_ekf import BatchedFilter, synth
     torch.cuda.empty_cache()
-    prm = capi.default_params(capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP)
-    size = 0.15
-    prm.marker_size = size
-    nom, rot, ids, left = synth.pixel_wall_scene(B, SLOTS, prm, size, seed=9)
+    out = {}
+    prof = _pixels_sq_profile()
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-    d_ids, d_left = torch.from_numpy(ids).to(dev), f32(left)
-    nvis = float((ids >= 0).sum(axis=1).mean())
-    with BatchedFilter(B, prm, device=local_rank, order_streams=False) as flt:
-        reps = 12
-        torch.cuda.synchronize()
+    for name, slots, kind in (("pixels_m4", 4, "pixels"), ("pixels_m16", 16, "pixels"), ("corners_m4", 4, "corners")):
+        prm = capi.default_params(capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP)
+        size = 0.15
+        prm.marker_size = size
+        nom, rot, ids, left, right = synth.pixel_wall_scene(B, slots, prm, size, seed=9, stereo=True)
+        acc, gyr = synth.imu_samples(0, B, 0, sum(PATTERN), nom)
+        d_acc, d_gyr = f32(acc), f32(gyr)
+        d_dt = torch.full((1,), 0.005, dtype=torch.float32, device=dev)
+        d_ids, d_left, d_right = torch.from_numpy(ids).to(dev), f32(left), f32(right)
+        nvis = float((ids >= 0).sum(axis=1).mean())
         prev0 = np.zeros(B, np.int32)
-        for k in range(reps + 2):
-            if k == 2:
-                flt.sync(); flt.timing_enable(True); flt.timing_reset()
-            flt.set_state(nom, rot, None, prev0)          # every launch from the same prior (state and covariance)
+        with BatchedFilter(B, prm, device=local_rank, order_streams=False) as flt:
+            flt.set_state(nom, rot, None, prev0)
             flt.reset_cov()
-            flt.correct_pixels(d_ids, d_left, None)
-        ms, n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
-        flt.timing_enable(False)
-        applied = float(flt.applied().mean())
-    us = ms / n * 1e3
-    rows = nvis * 8
-    blk = {"kernel": "correct_pixels_kernel<float,18> (left camera)", "bound": "valu", "batch": B, "marker_slots": SLOTS,
-           "markers_in_view_mean": nvis, "rows_per_filter_mean": rows, "avg_launch_us": us, "launches": n,
-           "reprojection_rows_per_s": rows * B / (us * 1e-6), "filters_updated_frac": applied,
-           "valu_insts_per_launch": None, "valu_issue_frac": None, "clock_MHz": None, "source": None}
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r03_pixels_sq.json")))
-        insts, mhz = float(prof["SQ_INSTS_VALU_per_launch"]), float(prof.get("clock_MHz", 2400.0))
-        if int(prof.get("batch", 0)) == B and int(prof.get("marker_slots", 0)) == SLOTS:
-            blk.update({"valu_insts_per_launch": insts, "clock_MHz": mhz, "source": "profiles/r03_pixels_sq.json",
-                        "valu_issue_frac": insts / (us * 1e-6 * 1024 * mhz * 1e6 / 4.0),
-                        "sq_active_inst_valu_over_wave_cycles": prof.get("SQ_ACTIVE_INST_VALU_over_SQ_WAVE_CYCLES")})
-    except Exception:
-        pass
-    return blk
+            torch.cuda.synchronize()
+
+            def update(stereo=False):
+                if kind == "pixels":
+                    flt.correct_pixels(d_ids, d_left, d_right if stereo else None)
+                else:
+                    flt.correct_corners(d_ids, d_left, d_right, capi.VIS_REFRACTIVE, capi.MODE_STACKED)
+
+            def bench_step(i):
+                for r in range(PATTERNS_PER_STEP):
+                    k = 0
+                    for K in PATTERN:
+                        for j in range(K):
+                            flt.predict(d_acc[k + j], d_gyr[k + j], d_dt)
+                        k += K
+                        update()
+            el = timed(torch, bench_step, steps, warmup)          # throughput: no event brackets inside the timed region
+            flt.timing_enable(True, stride=1)                     # launch times: one more step with a bracket around every launch
+            flt.timing_reset()
+            bench_step(0)
+            flt.sync()
+            u_ms, u_n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
+            p_ms, p_n = flt.timing_read(capi.KERNEL_PREDICT)
+            applied = float(flt.applied().mean())
+            finite = bool(np.isfinite(flt.get_state()[0]).all())
+            us = u_ms / max(u_n, 1) * 1e3
+            rows = nvis * (8 if kind == "pixels" else 12)
+            bytes_api = 2 * 796 + 68 * slots
+            blk = {"value": B * STEPS_PER_BENCH_STEP * steps / el, "unit": "EKF steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+                   "batch": B, "marker_slots": slots, "markers_in_view_mean": nvis, "rows_per_filter_and_frame": rows,
+                   "update": "fbus_ekf_correct_pixels_dev (left camera)" if kind == "pixels" else "fbus_ekf_correct_corners_dev (refractive, stacked)",
+                   "update_avg_launch_us": us, "update_launches": u_n, "predict_avg_launch_us": p_ms / max(p_n, 1) * 1e3,
+                   "update_bytes_per_filter_api": bytes_api, "update_algorithmic_GBs": bytes_api * B / (us * 1e-6) / 1e9,
+                   "update_frac_of_hbm_peak": bytes_api * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                   "filters_updated_frac": applied, "state_finite": finite}
+            if kind == "pixels":
+                blk["reprojection_rows_per_s"] = rows * B / (us * 1e-6)
+                if slots == 16:
+                    # the stereo form of the same update (256 rows), launch time only
+                    flt.timing_reset()
+                    for _ in range(6):
+                        update(stereo=True)
+                    s_ms, s_n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
+                    blk["stereo_256_rows_avg_launch_us"] = s_ms / max(s_n, 1) * 1e3
+                if prof and int(prof.get("batch", 0)) == B and int(prof.get("marker_slots", 0)) == slots:
+                    insts, mhz = float(prof["counters_per_launch"]["SQ_INSTS_VALU"]), float(prof.get("clock_MHz") or 2400.0)
+                    simds = int(prof.get("simds", 1024))
+                    blk.update({"valu_insts_per_launch": insts, "clock_MHz": mhz, "source": "profiles/r04_pixels_sq.json",
+                                "valu_issue_frac": insts / (us * 1e-6 * simds * mhz * 1e6 / 4.0),
+                                "valu_issue_frac_profiled_run": prof.get("valu_issue_frac_kernel_trace"),
+                                "sq_active_inst_valu_over_wave_cycles": prof.get("SQ_ACTIVE_INST_VALU_over_SQ_WAVE_CYCLES")})
+            flt.timing_enable(False)
+        out[name] = blk
+    out["note"] = ("same 200 Hz + 30 Hz per-call schedule as `value`, the camera frame applied as reprojection rows (pixels_*) or as "
+                   "triangulated corner rows (corners_m4) instead of marker poses; VALU-bound updates: read valu_issue_frac, not the byte fraction")
+    return out
 
 
 _REAL_STDOUT = None
@@ -517,7 +566,7 @@ def main():
             dist.barrier()
 
     if args.only_pixels:
-        emit(json.dumps({"compute_bound": pixels_leg(torch, dev, local_rank, args, capi)}))
+        emit(json.dumps({"north_star_rows": north_star_rows_leg(torch, dev, local_rank, args, capi)}))
         return
     w = Workload(torch, dev, local_rank, lo, hi, args, POOL if args.tile == 1 else 2, with_cov=(hi - lo) <= 131072 and args.tile == 1,
                  tile=args.tile)
@@ -663,7 +712,22 @@ def main():
         return roof2
 
     if rank == 0:
-        out["roofline_hbm_resident"] = out["roofline_b262144"] = out["fp64"] = out["compute_bound"] = None
+        out["roofline_hbm_resident"] = out["roofline_b262144"] = out["fp64"] = out["north_star_rows"] = None
+        # legs this line does NOT carry, and why (an N > 1 line has none of the single-GPU side legs: say so instead of nulls)
+        skipped = []
+        if world > 1 or strong:
+            why = f"{world} ranks" if world > 1 else "strong-scaling run (--total-batch)"
+            skipped += [f"{leg}: single-GPU side leg, not run with {why}" for leg in
+                        ("roofline_hbm_resident", "roofline_b262144", "fp64", "north_star_rows", "cpu_baseline")]
+        else:
+            if args.no_hbm_leg or args.batch >= MID_LEG_BATCH:
+                skipped += [f"{leg}: " + ("--no-hbm-leg" if args.no_hbm_leg else f"--batch {args.batch} is itself a large-batch run")
+                            for leg in ("roofline_hbm_resident", "roofline_b262144")]
+            if args.no_extra_legs:
+                skipped += ["fp64: --no-extra-legs", "north_star_rows: --no-extra-legs"]
+            if args.no_cpu_baseline:
+                skipped += ["cpu_baseline: --no-cpu-baseline"]
+        out["legs_skipped"] = skipped
         if world == 1 and not args.no_hbm_leg and not strong and args.batch < MID_LEG_BATCH:
             out["roofline_hbm_resident"] = batch_leg(
                 HBM_LEG_BATCH, 2, 16, max(2, min(args.steps, 3)),
@@ -677,7 +741,7 @@ def main():
                 "this leg as the HBM figure): kept for continuity, the HBM claim is roofline_hbm_resident")
         if world == 1 and not args.no_extra_legs and not strong:
             out["fp64"] = fp64_leg(torch, dev, local_rank, args, capi)
-            out["compute_bound"] = pixels_leg(torch, dev, local_rank, args, capi)
+            out["north_star_rows"] = north_star_rows_leg(torch, dev, local_rank, args, capi)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

@@ -8,6 +8,7 @@ mkdir -p $OUT
 python3 tools/run_pixels.py --both > $OUT/times.txt 2>&1
 FBUS_PIXELS_LEGACY=1 python3 tools/run_pixels.py --both >> $OUT/times.txt 2>&1
 python3 tools/run_pixels.py --both --batch 16384 --slots 4 >> $OUT/times.txt 2>&1
+python3 bench.py --only-pixels > $OUT/north_star_rows.json 2> $OUT/north_star_rows.err
 cat $OUT/times.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/run_pixels.py > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p1 -- python3 tools/run_pixels.py > $OUT/p1.log 2>&1
@@ -30,8 +31,11 @@ fs = sorted(glob.glob(f"{out}/trace/**/*kernel_stats.csv", recursive=True), key=
 for r in csv.DictReader(open(fs[-1])) if fs else []:
     if "correct_pixels" in r["Name"]:
         us = float(r["AverageNs"]) / 1e3; name = r["Name"]
+import shutil
+if fs: shutil.copy(fs[-1], f"{out}/kernel_stats.csv")
 mhz = (per.get("GRBM_GUI_ACTIVE", 0) / 8 / us) if us else None      # GRBM_GUI_ACTIVE sums the 8 XCDs
-d = {"kernel": name.split("(")[0], "batch": 65536, "marker_slots": 16, "waves": grid, "avg_launch_us_kernel_trace": us, "clock_MHz": mhz,
+d = {"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "batch": 65536, "marker_slots": 16, "camera": "left", "waves": grid, "simds": 1024,
+     "avg_launch_us_kernel_trace": us, "clock_MHz": mhz,
      "SQ_INSTS_VALU_per_wave": per.get("SQ_INSTS_VALU", 0) / max(grid, 1), "counters_per_launch": per}
 if us and per.get("SQ_INSTS_VALU") and mhz:
     d["valu_issue_frac_kernel_trace"] = per["SQ_INSTS_VALU"] / (us * 1e-6 * 1024 * mhz * 1e6 / 4)
