@@ -73,6 +73,7 @@ struct MeasConst {
                                     // camera:  XL = McL t_I,  XR = McR t_I + tR   (McL = F R_IL: vision.cpp:597-599 undone;
                                     // McR = R_RL^-1 McL, tR = -R_RL^-1 P_LR: vision.cpp:555-556 inverted)
     double nML[3], nMR[3];          // n' McL, n' McR
+    double NI[6];                   // R_IL' R_IL (symmetric: 00 01 02 11 12 22): the N' of a corner's three position rows
     double n[3];                    // port normal
     double a0, a1, d_air, d_glass;  // n_air / n_glass, n_air / n_water
     const double* mkc;              // [FBUS_MAX_MARKERS][MKC_STRIDE]
@@ -83,5 +84,10 @@ struct MeasConst {
 template <typename T, int N, int D>
 void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, double size,
                       double r_pix, const unsigned char* skip, unsigned char* applied, const short* id2slot, const MeasConst& mc);
+// correct() from stereo corners, round-4 kernel: nearest marker (roles forced to 1) or stacked; dialect: hysteresis of the nearest mode
+template <typename T, int N, int D>
+void launch_corners2_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int geometry, int mode,
+                       int roles, double size, double r_pos, double switch_thres, const unsigned char* skip, unsigned char* applied,
+                       const short* id2slot, const MeasConst& mc, const VisConst<double>& vc, const VisConst<T>& vct);
 
 }  // namespace fbus

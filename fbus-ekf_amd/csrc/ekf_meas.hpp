@@ -234,13 +234,26 @@ struct PixAcc {
     }
 };
 
+// The reference's h(x) is R_IL R'(c_w - p - R P_IL) (MeasureUpdate.m:67 ; filter.cpp:684) with the CARRIED rotation matrix, which
+// is a rotation only to its fp32 rounding: R'(R P_IL) is not P_IL but 6e-8 |P_IL| off, i.e. 1e-8 in an image point -- visible in
+// the fp64 kernels (2e-7 against the oracle before this was taken over literally).  Per filter: pil = R'(R P_IL); then
+// R'(c_w - p - R P_IL) = R'(c_w - p) - pil.
+__device__ __forceinline__ void filter_pil(const double* R, const double* P_IL, double* pil)
+{
+    double RP[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) RP[i] = R[3 * i] * P_IL[0] + R[3 * i + 1] * P_IL[1] + R[3 * i + 2] * P_IL[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pil[i] = R[i] * RP[0] + R[3 + i] * RP[1] + R[6 + i] * RP[2];
+}
+
 // ---- one marker: 4 corners x NCAM cameras in lock step --------------------------------------------------------------------
-// p, R: the filter's position and carried rotation (double copies of the record's values); mkc: the map slot (corner 0, x axis,
-// y axis); yl / yr: the 8 + 8 measured image coordinates.  Every stage is written across the NP = 4 NCAM projections (see md_rsq_n).
+// p, R: the filter's position and carried rotation (double copies of the record's values); pil = R'(R P_IL) (see filter_pil);
+// mkc: the map slot (corner 0, x axis, y axis); yl / yr: the 8 + 8 measured image coordinates.  Every stage is written across the NP = 4 NCAM projections (see md_rsq_n).
 // One evaluation of the port equation per projection in the common case (see below).
 template <int NCAM, typename T>
-__device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, const double* R, const MeasConst& mc,
-                                                  const double* mkc, const T* yl, const T* yr, double size)
+__device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, const double* R, const double* pil,
+                                                  const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size)
 {
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;           // Newton steps behind v_rsq_f64 / v_rcp_f64
     constexpr int NP = 4 * NCAM;
@@ -274,7 +287,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         for (int q = 0; q < NP; ++q) {
             const int k = q / NCAM, c = q % NCAM;
             const double* M = c ? mc.McR : mc.McL;
-            const double tI[3] = { ru[k][0] - mc.P_IL[0], ru[k][1] - mc.P_IL[1], ru[k][2] - mc.P_IL[2] };
+            const double tI[3] = { ru[k][0] - pil[0], ru[k][1] - pil[1], ru[k][2] - pil[2] };
 #pragma unroll
             for (int i = 0; i < 3; ++i) X[q][i] = M[3 * i] * tI[0] + M[3 * i + 1] * tI[1] + M[3 * i + 2] * tI[2] + (c ? mc.tR[i] : 0.0);
         }
@@ -419,6 +432,126 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
             }
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc.add_corner(Np[k], np[k], ru[k]);
+}
+
+// ---- correct() from stereo CORNERS: triangulation through the port in double, 3 position-type rows per corner ----------------
+// vision.cpp:496-599 for the four corners of one marker (the arithmetic of vision_device.hpp::refraction_corner, in double and
+// written across the 8 rays / 4 corners -- see md_rsq_n): left / right normalised image points -> points in the left camera frame.
+template <typename T>
+__device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& vc, const T* yl, const T* yr, double (&C)[4][3])
+{
+    constexpr int NS = sizeof(T) == 8 ? 2 : 1;
+    constexpr int NQ = 8;                                 // ray q = 2 k + c: corner k, camera c
+    const double* n = vc.nrm;
+    double r0[NQ][3], r1[NQ][3], r2[NQ][3], v0[NQ], v1[NQ], x[NQ], y[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const T* p = (q & 1) ? yr : yl;
+        r0[q][0] = (double)p[2 * (q >> 1)]; r0[q][1] = (double)p[2 * (q >> 1) + 1]; r0[q][2] = 1.0;
+        x[q] = r0[q][0] * r0[q][0] + r0[q][1] * r0[q][1] + 1.0;
+    }
+    md_rsq_n<NS, NQ>(x, y);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r0[q][i] *= y[q];
+        v0[q] = r0[q][0] * n[0] + r0[q][1] * n[1] + r0[q][2] * n[2];
+        x[q] = 1.0 - vc.alpha0 * vc.alpha0 * (1.0 - v0[q] * v0[q]);
+    }
+    md_rsq_n<NS, NQ>(x, y);                              // air -> glass   (vision.cpp:505-522)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double root = x[q] * y[q];
+        const double beta = vc.sqrt_minus0 ? (root - vc.alpha0 * v0[q]) : (vc.alpha0 * v0[q] - root);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r1[q][i] = vc.alpha0 * r0[q][i] + beta * n[i];
+        v1[q] = r1[q][0] * n[0] + r1[q][1] * n[1] + r1[q][2] * n[2];
+        x[q] = 1.0 - vc.alpha1 * vc.alpha1 * (1.0 - v1[q] * v1[q]);
+    }
+    md_rsq_n<NS, NQ>(x, y);                              // glass -> water (vision.cpp:524-543)
+    double P1[NQ][3], iv0[NQ], iv1[NQ];
+    md_rcp_n<NS, NQ>(v0, iv0);
+    md_rcp_n<NS, NQ>(v1, iv1);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double root = x[q] * y[q];
+        const double beta = vc.sqrt_minus1 ? (root - vc.alpha1 * v1[q]) : (vc.alpha1 * v1[q] - root);
+        const double aq = vc.d_air * iv0[q], gq = vc.d_glass * iv1[q];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            r2[q][i] = vc.alpha1 * r1[q][i] + beta * n[i];
+            P1[q][i] = aq * r0[q][i] + gq * r1[q][i];      // exit point on the outer glass face (vision.cpp:546-552)
+        }
+    }
+    // the right ray in the left frame (vision.cpp:555-556), mid-point of the two rays by Cramer (vision.cpp:559-595)
+    double d3[4], id3[4], t1[4], t2[4], rL[4][3], rR[4][3], PL[4][3], PR[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qL = 2 * k, qR = 2 * k + 1;
+        double dP[3], cr[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            rL[k][i] = r2[qL][i]; PL[k][i] = P1[qL][i];
+            rR[k][i] = vc.R_RL[3 * i] * r2[qR][0] + vc.R_RL[3 * i + 1] * r2[qR][1] + vc.R_RL[3 * i + 2] * r2[qR][2];
+            PR[k][i] = vc.R_RL[3 * i] * P1[qR][0] + vc.R_RL[3 * i + 1] * P1[qR][1] + vc.R_RL[3 * i + 2] * P1[qR][2] + vc.P_LR[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dP[i] = PR[k][i] - PL[k][i];
+        cross3(rL[k], rR[k], cr);
+        d3[k] = det3cols(cr, rL[k], rR[k]);
+        t1[k] = det3cols(cr, dP, rR[k]);
+        t2[k] = -det3cols(cr, rL[k], dP);
+    }
+    md_rcp_n<NS, 4>(d3, id3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t1[k] *= id3[k]; t2[k] *= id3[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double Pm = 0.5 * (PL[k][i] + t1[k] * rL[k][i] + PR[k][i] + t2[k] * rR[k][i]);
+            C[k][i] = (i < 2) ? -Pm : Pm;                 // vision.cpp:597-599
+        }
+    }
+}
+
+// the four corner positions C (left camera frame, as triangulated) of one marker as 12 position-type rows:
+//   h_k = R_IL (ru_k - P_IL),  rows a_i = (R_IL)_i' for every corner:  N' = R_IL' R_IL (constant, mc.NI),  n' = R_IL' (C_k - h_k)
+// (MeasureUpdate.m:67,72-73 with the corner in place of the marker origin; oracle: fbo_correct_corners)
+__device__ __forceinline__ void corner_fold_marker(PixAcc& acc, const double* p, const double* R, const double* pil,
+                                                   const MeasConst& mc, const double* mkc, const double (&C)[4][3], double size)
+{
+    double ru[4][3];
+    {
+        double u0[3], ru0[3], rAx[3], rAy[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u0[i] = mkc[i] - p[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ru0[i] = R[i] * u0[0] + R[3 + i] * u0[1] + R[6 + i] * u0[2];
+            rAx[i] = size * (R[i] * mkc[3] + R[3 + i] * mkc[4] + R[6 + i] * mkc[5]);
+            rAy[i] = size * (R[i] * mkc[6] + R[3 + i] * mkc[7] + R[6 + i] * mkc[8]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ru[0][i] = ru0[i];
+            ru[1][i] = ru0[i] + rAy[i];
+            ru[2][i] = ru0[i] + rAx[i] + rAy[i];
+            ru[3][i] = ru0[i] + rAx[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double tI[3] = { ru[k][0] - pil[0], ru[k][1] - pil[1], ru[k][2] - pil[2] };
+        double fr[3], np[3];                              // F (C - h): McL = F R_IL, so R_IL' res = McL' (F res)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double XL = mc.McL[3 * i] * tI[0] + mc.McL[3 * i + 1] * tI[1] + mc.McL[3 * i + 2] * tI[2];
+            fr[i] = (i < 2 ? -C[k][i] : C[k][i]) - XL;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) np[j] = mc.McL[j] * fr[0] + mc.McL[3 + j] * fr[1] + mc.McL[6 + j] * fr[2];
+        acc.add_corner(mc.NI, np, ru[k]);
+    }
 }
 
 // ---- the 6 x 6 stage in double ----------------------------------------------------------------------------------------------
@@ -682,6 +815,8 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     for (int i = 0; i < 3; ++i) pd[i] = (double)pqr[L::OFF_P3 + i];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Rd[i] = (double)pqr[L::OFF_R + i];
+    double pil[3];
+    filter_pil(Rd, mc.P_IL, pil);
     PixAcc acc;
     acc.clear();
     double nfold = 0.0;                                          // markers of the map this role has folded
@@ -695,8 +830,8 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
             double mk[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-            if (stereo) pixel_fold_marker<2, T>(acc, pd, Rd, mc, mk, cur.l, cur.r, size);
-            else pixel_fold_marker<1, T>(acc, pd, Rd, mc, mk, cur.l, cur.l, size);
+            if (stereo) pixel_fold_marker<2, T>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+            else pixel_fold_marker<1, T>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
             nfold += 1.0;
         }
         cur = nxt;
@@ -742,6 +877,198 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     inject<T, N>(nom, dx);
     // write-through (sc1) as correct_kernel: the lines reach the Infinity Cache at once instead of being written back from the L2s
     // under the tail of the launch
+    store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);
+    applied[b] = 1;
+}
+
+
+// =================================================================================
+// correct() from stereo corners (12 position-type rows per marker; north-star extension B2, oracle: fbo_correct_corners):
+// nearest marker (by its first corner; C++ dialect: hysteresis against the previous one, filter.cpp:639-664) or all of them.
+// Same structure as correct_pixels2_kernel; the triangulation of the refractive geometry runs in double.
+// =================================================================================
+template <typename T, int N, int NR>
+__global__ void __launch_bounds__(64 * NR)
+correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
+                        const T* __restrict__ right, int geometry, int mode, int dialect, double size, double r_pos,
+                        double switch_thres, const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied,
+                        const short* __restrict__ id2slot, MeasConst mc, VisConst<double> vc, VisConst<T> vct)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    constexpr int NT = 64 * NR;
+    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned tile = blockIdx.x;
+    const int b = (int)(tile * 64u + lane);
+    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
+    const int bc = b < B ? b : (int)(tile * 64u);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    __shared__ MeasLDS tbl;
+    __shared__ double part_mem[(NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1)];
+    struct Meas { int id; T l[12], r[8]; };
+    const bool c3d = geometry == VIS_CORNERS3D;
+    const int lw = c3d ? 12 : 8;
+    auto fetch = [&](int i, Meas& mm) __attribute__((always_inline)) {
+        const size_t o = (size_t)bc * M + i;
+        constexpr int EP = 16 / (int)sizeof(T);
+        mm.id = ids[o];
+        const u32x4* pl = reinterpret_cast<const u32x4*>(left + o * lw);
+        const u32x4* pr = reinterpret_cast<const u32x4*>((c3d ? left : right) + o * 8);
+#pragma unroll
+        for (int c = 0; c < 12 / EP; ++c) {
+            const u32x4 vl = pl[(c < 8 / EP || c3d) ? c : 0];
+            const T* el = reinterpret_cast<const T*>(&vl);
+#pragma unroll
+            for (int k = 0; k < EP; ++k) mm.l[c * EP + k] = el[k];
+        }
+#pragma unroll
+        for (int c = 0; c < 8 / EP; ++c) {
+            const u32x4 vr = pr[c];
+            const T* er = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+            for (int k = 0; k < EP; ++k) mm.r[c * EP + k] = er[k];
+        }
+    };
+    // the four corners of a measured marker in the left camera frame
+    auto corners = [&](const Meas& mm, double (&C)[4][3]) __attribute__((always_inline)) {
+        if (geometry == VIS_REFRACTIVE) { tri_corners_refractive<T>(vc, mm.l, mm.r, C); return; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (geometry == VIS_CORNERS3D) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) C[k][i] = (double)mm.l[3 * k + i];
+            } else {
+                T o3[3];                                 // pin-hole DLT (vision.cpp:395-466): the 4 x 4 eigen-solver stays in T
+                pinhole_corner(vct, mm.l[2 * k], mm.l[2 * k + 1], mm.r[2 * k], mm.r[2 * k + 1], o3);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) C[k][i] = (double)o3[i];
+            }
+        }
+    };
+    Meas cur, nxt;
+    T pqr[L::NPQR];
+    T prev_raw = T(0);
+    {
+        constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(double) * FBUS_MAX_MARKERS * MKC_STRIDE / 16;
+        constexpr int PI = (NI + NT - 1) / NT, PM = (NM + NT - 1) / NT;
+        const u32x4* si = reinterpret_cast<const u32x4*>(id2slot);
+        const u32x4* sm = reinterpret_cast<const u32x4*>(mc.mkc);
+        u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
+        u32x4* dm = reinterpret_cast<u32x4*>(tbl.mkc);
+        u32x4 vi[PI], vm[PM];
+#pragma unroll
+        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; vi[q] = si[i < NI ? i : 0]; }
+#pragma unroll
+        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; vm[q] = sm[i < NM ? i : 0]; }
+        order_fence();
+        if (M > 0) fetch((int)role < M ? (int)role : M - 1, cur);
+        if (mode == MODE_NEAREST && dialect == DIALECT_CPP) prev_raw = recs[elem_index<T, N>(bc, L::OFF_PREV)];
+        order_fence();
+        load_chunks<T, N, 0, RC::CH_PQR>(rs, lane, pqr);
+        order_fence();
+#pragma unroll
+        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; if (i < NI) di[i] = vi[q]; }
+#pragma unroll
+        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; if (i < NM) dm[i] = vm[q]; }
+        order_fence();
+    }
+    if constexpr (NR > 1) meas_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double pd[3], Rd[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pd[i] = (double)pqr[L::OFF_P3 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rd[i] = (double)pqr[L::OFF_R + i];
+    double pil[3];
+    filter_pil(Rd, mc.P_IL, pil);
+    PixAcc acc;
+    acc.clear();
+    double nfold = 0.0;
+    int new_prev = -1;
+    auto fold_marker = [&](const Meas& mm) __attribute__((always_inline)) {
+        const bool ok = mm.id >= 0 && mm.id <= FBUS_MAX_MARKER_ID;
+        const int slot = ok ? (int)tbl.id2slot[ok ? mm.id : 0] : -1;
+        if (slot < 0) return false;
+        double mk[9], C[4][3];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
+        corners(mm, C);
+        corner_fold_marker(acc, pd, Rd, pil, mc, mk, C, size);
+        return true;
+    };
+    if (mode == MODE_NEAREST) {
+        // one role only (the launcher): nearest visible marker by its first corner
+        if (live) {
+            const int prev_id = (int)prev_raw;
+            int min_i = -1, prev_i = -1;
+            double min_d = 10.0, prev_d = 0.0;
+#pragma unroll 1
+            for (int i = 0; i < M; ++i) {
+                fetch(i + 1 < M ? i + 1 : M - 1, nxt);
+                if (cur.id >= 0) {
+                    double C[4][3];
+                    corners(cur, C);
+                    const double dist = sqrt(C[0][0] * C[0][0] + C[0][1] * C[0][1] + C[0][2] * C[0][2]);
+                    if (dist < min_d) { min_d = dist; min_i = i; }
+                    if (dialect == DIALECT_CPP && cur.id == prev_id) { prev_d = dist; prev_i = i; }
+                }
+                cur = nxt;
+            }
+            if (min_i >= 0) {
+                if (dialect == DIALECT_CPP && prev_i >= 0 && fabs(prev_d - min_d) < switch_thres && prev_d != 0.0) min_i = prev_i;
+                fetch(min_i, cur);
+                if (fold_marker(cur)) { nfold = 1.0; if (dialect == DIALECT_CPP) new_prev = cur.id; }
+            }
+        }
+    } else {
+        const int last = live ? M : 0;
+#pragma unroll 1
+        for (int i = (int)role; i < last; i += NR) {
+            fetch(i + NR < M ? i + NR : M - 1, nxt);
+            if (fold_marker(cur)) nfold += 1.0;
+            cur = nxt;
+        }
+    }
+    if constexpr (NR > 1) {
+        if (role != 0) {
+            double* part = part_mem + ((role - 1) * (PixAcc::NVAL + 1)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < PixAcc::NVAL; ++i) part[i * 64] = acc.at(i);
+            part[PixAcc::NVAL * 64] = nfold;
+            meas_barrier();
+            return;
+        }
+        meas_barrier();
+#pragma unroll
+        for (int r = 1; r < NR; ++r) {
+            const double* part = part_mem + ((r - 1) * (PixAcc::NVAL + 1)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < PixAcc::NVAL; ++i) acc.at(i) += part[i * 64];
+            nfold += part[PixAcc::NVAL * 64];
+        }
+    }
+    if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
+    T P[RC::NCOVP];
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
+    double Lam[21], bv[6];
+    acc.finish(Rd, 1.0 / r_pos, Lam, bv);
+    T G[36], Sinv[21], m[6];
+    {
+        double PJJ[36];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
+        info_solve<T>(Lam, bv, PJJ, G, Sinv, m);
+    }
+    T dx[N];
+    direct_update<T, N>(P, dx, G, Sinv, m);
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
+    inject<T, N>(nom, dx);
+    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
     store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
     store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);

@@ -567,6 +567,12 @@ MeasConst make_mc(const fbus_ekf* h)
     }
     for (int j = 0; j < 3; ++j)
         for (int i = 0; i < 3; ++i) { mc.nML[j] += mc.n[i] * mc.McL[3 * i + j]; mc.nMR[j] += mc.n[i] * mc.McR[3 * i + j]; }
+    {   // R_IL' R_IL = McL' McL (F is orthogonal)
+        const double* Mm = mc.McL;
+        int o = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i; j < 3; ++j) mc.NI[o++] = Mm[i] * Mm[j] + Mm[3 + i] * Mm[3 + j] + Mm[6 + i] * Mm[6 + j];
+    }
     mc.a0 = p.n_air / p.n_glass;
     mc.a1 = p.n_air / p.n_water;
     mc.d_air = p.d_air; mc.d_glass = p.d_glass;
@@ -619,6 +625,17 @@ int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
     h->records_warm = true;
+    if (!h->pixels_legacy) {
+        // round 4: triangulation and fold in double, non-cancelling update (ekf_meas.hpp), as the pixel rows
+        h->records_warm = h->warm_after_correct;
+        const int roles = mode == MODE_STACKED ? team_roles_pixels(h, M) : 1;
+        launch_corners2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
+                                   roles, h->prm.marker_size, h->prm.r_pos, h->prm.switch_thres, (const unsigned char*)skip,
+                                   h->d_applied, h->d_id2slot, make_mc(h), make_vc<double>(h), make_vc<T>(h));
+        timing_end(h, ev);
+        HIP_TRY(h, hipGetLastError());
+        return FBUS_OK;
+    }
     const int roles = team_roles_corners(h, mode, M);
     if constexpr (sizeof(T) == 4) {
         if (roles > 1)

@@ -314,10 +314,29 @@ void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
     else FBUS_LAUNCH_PX(1);
 #undef FBUS_LAUNCH_PX
 }
+template <typename T, int N, int D>
+void launch_corners2_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int geometry, int mode,
+                       int roles, double size, double r_pos, double switch_thres, const unsigned char* skip, unsigned char* applied,
+                       const short* id2slot, const MeasConst& mc, const VisConst<double>& vc, const VisConst<T>& vct)
+{
+    const int tiles = (B + 63) / 64;
+    if (mode != MODE_STACKED) roles = 1;
+#define FBUS_LAUNCH_CR(NR)                                                                                               \
+    hipLaunchKernelGGL((correct_corners2_kernel<T, N, NR>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, right,  \
+                       geometry, mode, D, size, r_pos, switch_thres, skip, applied, id2slot, mc, vc, vct)
+    if (roles >= 3) FBUS_LAUNCH_CR(4);
+    else if (roles == 2) FBUS_LAUNCH_CR(2);
+    else FBUS_LAUNCH_CR(1);
+#undef FBUS_LAUNCH_CR
+}
 #define FBUS_INST(D)                                                                                                   \
     template void launch_pixels2_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*, const FBUS_TU_T*, \
                                                             const FBUS_TU_T*, int, double, double, const unsigned char*, \
-                                                            unsigned char*, const short*, const MeasConst&);
+                                                            unsigned char*, const short*, const MeasConst&);           \
+    template void launch_corners2_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*, const FBUS_TU_T*, \
+                                                             const FBUS_TU_T*, int, int, int, double, double, double,  \
+                                                             const unsigned char*, unsigned char*, const short*,       \
+                                                             const MeasConst&, const VisConst<double>&, const VisConst<FBUS_TU_T>&);
 #else
 #error "FBUS_TU_FAMILY must be 1..7"
 #endif

@@ -265,8 +265,15 @@ def test_config5_sixteen_slots_fp32_against_fp64():
             # ... and the fp32 kernels against the ORACLE directly on the strided subset (not only against the fp64 kernels)
             assert_parity([x[sub] for x in res[32][0]], eng.get_state(), 32, "config 5 pose rows, fp32 device vs oracle, one frame")
         else:
-            gates = ((0, "one frame", WINDOW_TOL, 10 * PLAIN_TOL, COV_BLOCK_TOL, 5e-5),
-                     (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL, 5e-5))
+            # (round 4) the corner rows go through the double-precision fold and the non-cancelling update of csrc/ekf_meas.hpp:
+            # the update by itself meets the single-step gates with two decades to spare (config 3: literal 1.7e-7, block-wise
+            # covariance 2e-7), and the fp32 kernels against the ORACLE on the strided subset meet them un-multiplied (next
+            # line).  The maximum over all 65 536 filters of fp32 against fp64 after 7 fp32 PREDICTS + the 144-row update is what
+            # the pose form's comment above describes -- the fp32 nominal state the update starts from, times the gain of 144
+            # rows -- and gets the pose form's multipliers (3x / 5x; literal 2e-5: measured 1.1e-5, round 3: 1.4e-5 under a 5e-5 gate).
+            assert_parity([x[sub] for x in res[32][0]], eng.get_state(), 32, "config 5 corner rows, fp32 device vs oracle, one frame")
+            gates = ((0, "one frame", 3 * STATE_TOL, 5 * PLAIN_TOL, COV_BLOCK_TOL, 2e-5),
+                     (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL, STATE_TOL))
         for i, name, st, pl, cb, lit in gates:
             _properties(res[32][i], f"config 5 {form} {name}", psd_stride=97)
             e = parity_errors(res[32][i], res[64][i])

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--reps", type=int, default=12)
     ap.add_argument("--dtype", type=int, default=32)
     ap.add_argument("--roles", type=int, default=0)
+    ap.add_argument("--corners", action="store_true", help="fbus_ekf_correct_corners_dev (refractive, stacked) instead of the pixel rows")
     args = ap.parse_args()
     import torch
     from fbus_ekf import BatchedFilter, capi, synth
@@ -33,20 +34,23 @@ def main():
     prev0 = np.zeros(B, np.int32)
     with BatchedFilter(B, prm, device=0, dtype=args.dtype, order_streams=False) as flt:
         flt.set_team(0, args.roles)
-        for stereo in ((False, True) if args.both else (args.stereo,)):
+        for stereo in ((True,) if args.corners else ((False, True) if args.both else (args.stereo,))):
             torch.cuda.synchronize()
             for k in range(args.reps + 2):
                 if k == 2:
                     flt.sync(); flt.timing_enable(True); flt.timing_reset()
                 flt.set_state(nom, rot, None, prev0)
                 flt.reset_cov()
-                flt.correct_pixels(d_ids, d_left, d_right if stereo else None)
+                if args.corners:
+                    flt.correct_corners(d_ids, d_left, d_right, capi.VIS_REFRACTIVE, capi.MODE_STACKED)
+                else:
+                    flt.correct_pixels(d_ids, d_left, d_right if stereo else None)
             ms, n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
             flt.timing_enable(False)
             g = flt.get_state()
             ok = bool(np.isfinite(g[0]).all() and np.isfinite(g[2]).all())
             rows = nvis * (16 if stereo else 8)
-            print(f"correct_pixels fp{args.dtype} B {B} slots {args.slots} ({nvis:.1f} in view, {rows:.0f} rows) {'stereo' if stereo else 'left'}: "
+            print(f"{'correct_corners' if args.corners else 'correct_pixels'} fp{args.dtype} B {B} slots {args.slots} ({nvis:.1f} in view, {rows:.0f} rows) {'stereo' if stereo else 'left'}: "
                   f"{ms / n * 1e3:.1f} us per launch, applied {float(flt.applied().mean()):.3f}, finite {ok}, "
                   f"posterior sigma_p {float(np.sqrt(g[2][:, 0, 0]).mean()):.2e}", flush=True)
 
