@@ -132,7 +132,8 @@ def pmc_traffic(batch, args, world, kernel="predict"):
     it was taken on THIS configuration (batch, dialect, markers, mode, eager launches, one GPU); otherwise None."""
     if world != 1 or args.graphs:
         return None, None
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_digest_b{batch}.json") for r in (3, 2)) if os.path.exists(q)), "")
+    # this round's digest, else round 3's (same per-call predict / correct kernels: unchanged since); never round 2's kernels
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_digest_b{batch}.json") for r in (4, 3)) if os.path.exists(q)), "")
     try:
         d = json.load(open(path))
         cfg = d.get("_config", {})
@@ -351,6 +352,21 @@ def _timed(torch, fn, steps, warmup, barrier, before_timing):
 
 
 def roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src):
+    roof, corr = _roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src)
+    # which kernels actually ran (fbus_ekf_launch_info): below a quarter of the chip the per-call predict is the 3-role team
+    # kernel, whose roles reload the nominal chunks and overlapping covariance chunks -- the one-wave byte model (1436 B per
+    # filter) does not describe it, so only the API-priced figures are kept there
+    pol = w.flt.launch_policy(M=w.M, K=max(PATTERN))
+    tname = "float" if w.dtype == 32 else "double"
+    if pol["roles_predict"] > 1:
+        roof.update({"kernel": f"predict_team_kernel<{tname},18,{pol['roles_predict']} roles>", "achieved": roof["achieved_api"],
+                     "frac": roof["frac_api"], "bytes_moved_per_launch": None, "frac_of_copy_ceiling": None, "traffic": None,
+                     "traffic_source": None, "traffic_GBs": None, "byte_model": "api (SURVEY 8(d)): the team kernel's roles re-read shared chunks"})
+    roof["launch_policy"] = pol
+    return roof, corr
+
+
+def _roofline_block(w, pred_ms, pred_n, corr_ms, corr_n, traffic, traffic_src):
     B, M = w.B, w.M
     es = 1 if w.dtype == 32 else 2                                # fp64 records and inputs are twice the bytes
     tname = "float" if w.dtype == 32 else "double"
@@ -571,6 +587,8 @@ def main():
     w = Workload(torch, dev, local_rank, lo, hi, args, POOL if args.tile == 1 else 2, with_cov=(hi - lo) <= 131072 and args.tile == 1,
                  tile=args.tile)
     flt = w.flt
+    if strong:
+        flt.set_policy_batch(args.total_batch)      # the same kernels whatever the shard layout (fbus_ekf_set_policy_batch)
     frames_timed = args.steps * len(PATTERN) * PATTERNS_PER_STEP
     # HIP-event brackets on every stride-th camera frame (a pair costs ~8 us of stream time: <= 1.5 % of the timed region)
     stride = max(6, min(16, frames_timed // 10))

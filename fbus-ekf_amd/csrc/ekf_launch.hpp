@@ -12,20 +12,28 @@
 
 namespace fbus {
 
+// What the launchers need to know about the device and the process, decided ONCE per handle (fbus_ekf_create: device properties +
+// environment overrides) -- nothing below reads the environment.
+struct LaunchPolicy {
+    int simds = 1024;               // SIMDs of the device (CUs x 4): one wave per SIMD = `simds` 64-filter tiles
+    int two_wave_min_b = 1024 * 64 + 1;   // from this many filters on a launch has more waves than SIMDs: the <= 256-register forms
+    bool meas_vec = true;           // measurement inputs of correct as 16-byte loads where legal
+};
+
 // K == 1: the streamed per-call kernel (`policy`: 0 = nt loads and stores, 1 = default-policy loads, 2 = default loads
 // and stores); K > 1: predict_n, K samples per launch with the record resident in registers
 template <typename T, int N, int D>
 void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T* accel, const T* gyro, const T* dt,
-                      int dt_stride, const DevConst<T>& dc);
+                      int dt_stride, const DevConst<T>& dc, const LaunchPolicy& lp);
 
 template <typename T, int N, int D>
 void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode,
-                      bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
+                      bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const LaunchPolicy& lp);
 
 template <typename T, int N, int D>
 void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
                     int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
-                    const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
+                    const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const LaunchPolicy& lp);
 
 // a window of F frames in one launch (fp32; not (Joseph, nearest)); kcount: F host bytes
 template <typename T, int N, int D>

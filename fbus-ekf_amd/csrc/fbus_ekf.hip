@@ -17,6 +17,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -114,6 +115,12 @@ bool build_host_const(const fbus_params& prm, HostConst& hc, std::string& err)
 // handle
 // ---------------------------------------------------------------------------------
 struct fbus_ekf {
+    // ---- launch policy, derived from the device at create (fbus_ekf_create), environment overrides read there once ----------
+    LaunchPolicy lp;                  // SIMD count, two-wave threshold, vector measurement loads (handed to the launchers)
+    int cus = 256;                    // hipDeviceProp::multiProcessorCount (FBUS_FAKE_SIMDS / 4 overrides it)
+    size_t l2_bytes = (size_t)4 << 20;        // hipDeviceProp::l2CacheSize (one XCD's L2)
+    size_t mall_bytes = (size_t)256 << 20;    // memory-side Infinity Cache: not exposed by the runtime; 256 MiB per 1024 SIMDs, FBUS_MALL_MB
+    int policy_batch = 0;             // fbus_ekf_set_policy_batch: the batch the kernel-FAMILY choice is keyed on (0 = this handle's)
     bool records_warm = false;        // the last kernel stored the records with the default cache policy (they sit in L2)
     int big_records_mb = 56;          // records larger than this run the predict with default-policy loads and stores (FBUS_BIG_RECORDS_MB)
     bool warm_after_correct = false;  // experiment knob FBUS_WARM_AFTER_CORRECT=1: the first predict behind a correct takes the "warm" load policy
@@ -258,13 +265,20 @@ void timing_end(fbus_ekf_t h, int i)
 //   predict_n  K = 8: 4096 filters 18.8 -> 10.3 us, 16 384: 20.7 -> 17.5, 32 768: 23.2 -> 20.9                 => up to 512 tiles
 //   correct    4096 filters 6.4 -> 7.6 us, 16 384: 7.2 -> 9.2, 32 768: 10.0 -> 18: the one-wave kernel folds its markers under
 //              the load latency and the team pays two exchanges and a redundant 6 x 6 solve per role       => never by default
+// (round 4) The thresholds are fractions of the device's SIMD count (256 / 512 tiles = a quarter / half of MI355X's 1024 SIMDs: what
+// was measured is "how much of the chip a one-wave launch leaves idle"), and the batch they are compared with is the POLICY batch:
+// the handle's own unless fbus_ekf_set_policy_batch names the whole job -- team and one-wave kernels agree to fp32 rounding only,
+// so a job cut into shards (fbus::ShardedFilter) keys the choice on the total and gets the same kernels whatever the shard layout.
+int policy_tiles(const fbus_ekf* h) { return ((h->policy_batch > 0 ? h->policy_batch : h->B) + 63) / 64; }
+int quarter_chip(const fbus_ekf* h) { return h->lp.simds / 4; }
+int half_chip(const fbus_ekf* h) { return h->lp.simds / 2; }
 int team_roles_predict(const fbus_ekf* h, int K)
 {
     if (h->dtype != 32 || h->team_predict == 1) return 1;
     if (h->team_predict >= 2) return K > 1 ? 4 : (h->team_predict > 4 ? 4 : h->team_predict);
-    const int tiles = (h->B + 63) / 64;
-    if (K > 1) return tiles <= 512 ? 4 : 1;
-    return tiles <= 256 ? 3 : 1;
+    const int tiles = policy_tiles(h);
+    if (K > 1) return tiles <= half_chip(h) ? 4 : 1;
+    return tiles <= quarter_chip(h) ? 3 : 1;
 }
 // correct from stereo corners (stacked mode) / from corner pixels (correct_meas_team_kernel: the markers of a filter divided among the
 // roles; these kernels are bound by the VALU work per marker -- ~2600 instructions of triangulation and row folds, 4 or 8 flat-port
@@ -274,16 +288,16 @@ int team_roles_corners(const fbus_ekf* h, int mode, int M)
 {
     if (h->dtype != 32 || h->prm.cov_form == FBUS_COV_JOSEPH || mode != MODE_STACKED || M < 2 || h->team_correct == 1) return 1;
     if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
-    const int tiles = (h->B + 63) / 64;
-    return tiles <= 256 ? 4 : (tiles <= 512 ? 2 : 1);
+    const int tiles = policy_tiles(h);
+    return tiles <= quarter_chip(h) ? 4 : (tiles <= half_chip(h) ? 2 : 1);
 }
 // round-4 pixel-row kernel (correct_pixels2_kernel): roles divide the markers; both record types
 int team_roles_pixels(const fbus_ekf* h, int M)
 {
     if (M < 2 || h->team_correct == 1) return 1;
     if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
-    const int tiles = (h->B + 63) / 64;
-    return tiles <= 256 ? 4 : (tiles <= 512 ? 2 : 1);
+    const int tiles = policy_tiles(h);
+    return tiles <= quarter_chip(h) ? 4 : (tiles <= half_chip(h) ? 2 : 1);
 }
 // fused frame / frame window (frames_team_kernel: the predict_n pipeline + the one-shot correct divided over the four roles).  Follows the predict
 // setting (fbus_ekf_set_team: 1 = never, 2..4 = always); FBUS_TEAM_FRAME=1|2 overrides.  Two workgroups of four waves fit a CU
@@ -295,7 +309,7 @@ bool team_frames(const fbus_ekf* h, int mode)
     if (mode != MODE_NEAREST && mode != MODE_STACKED) return false;
     if (h->team_frame == 1 || (h->team_frame == 0 && h->team_predict == 1)) return false;
     if (h->team_frame == 2 || h->team_predict >= 2) return true;
-    return (h->B + 63) / 64 <= 512;
+    return policy_tiles(h) <= half_chip(h);
 }
 int team_roles_correct(const fbus_ekf* h, int mode)
 {
@@ -303,6 +317,13 @@ int team_roles_correct(const fbus_ekf* h, int mode)
     if (mode != MODE_NEAREST && mode != MODE_STACKED) return 1;
     return h->team_correct > 4 ? 4 : h->team_correct;
 }
+
+// (round 4, measured and NOT kept: a batch of more than one wave per SIMD as launches of one round each.  The per-call kernels run
+// 65 536 filters -- 52 MB of records, exactly one wave per SIMD -- at 7.7 TB/s because the records stay cache-resident from launch
+// to launch; two such launches over the two halves of 131 072 filters do NOT run at twice 12.2 us (29.1 us against 28.0 us for the
+// single launch, 60.7 against 55.8 at 262 144: tools/r4_by_batch.sh, profiles/r04_bench_by_batch.txt) -- what is lost past 65 536
+// filters is the residency (56 MB, section 4.1 of DESIGN.md), not the launch shape, and beyond it the kernels stream at the
+// 6.3-6.7 TB/s this part copies at.)
 
 template <typename T, int N, int D>
 int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
@@ -321,7 +342,7 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
     // of N = 15 records on the nt side): a cache-capacity effect, keyed on bytes, not on the wave count.  Beyond the 256 MiB
     // Infinity Cache the records stream from HBM and non-temporal STORES win again (524 288 filters = 419 MB: 133 -> 116 us
     // with default loads; 1 048 576 = 839 MB: 290 -> 275 us with nt loads as well -- nothing is left to hit).
-    const size_t mall = (size_t)256 << 20;
+    const size_t mall = h->mall_bytes;
     const bool big = h->rec_bytes > ((size_t)h->big_records_mb << 20);
     int policy = (big ? 2 : (h->records_warm ? 1 : 0));
     if (big && h->rec_bytes > mall) policy = (h->rec_bytes > 2 * mall) ? 0 : 1;
@@ -336,8 +357,8 @@ int launch_predict_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, c
                                            (const T*)dt, dt_per_filter ? 1 : 0, make_dc<T>(h));
     }
     if (roles <= 1 || sizeof(T) != 4)
-    launch_predict_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, policy, (const T*)accel, (const T*)gyro, (const T*)dt,
-                              dt_per_filter ? 1 : 0, make_dc<T>(h));
+        launch_predict_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, policy, (const T*)accel, (const T*)gyro, (const T*)dt,
+                                  dt_per_filter ? 1 : 0, make_dc<T>(h), h->lp);
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -356,8 +377,8 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
                                            roles, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
     }
     if (roles <= 1 || sizeof(T) != 4)
-    launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
-                              h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+        launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+                                  h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h), h->lp);
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -414,7 +435,7 @@ int launch_frame_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, con
     } else
     launch_frame_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, (const T*)accel, (const T*)gyro, (const T*)dt,
                             dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
-                            h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
+                            h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h), h->lp);
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     }
@@ -839,7 +860,9 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     *out = nullptr;
     if (!prm || batch <= 0) return FBUS_ERR_INVALID;
     if ((dtype != 32 && dtype != 64) || (nstate != 15 && nstate != 18)) return FBUS_ERR_UNSUPPORTED;
-    if (prm->dialect != FBUS_DIALECT_MATLAB && prm->dialect != FBUS_DIALECT_CPP) return FBUS_ERR_INVALID;
+    // the checks of fbus_params_validate (dialect, cov_form, positive noise -- a zero r_pos would turn the fold's weights into NaN --,
+    // marker table): the header promises them here
+    if (fbus_params_validate(prm, nullptr, 0) != FBUS_OK) return FBUS_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FBUS_ERR_NO_DEVICE;
     DeviceGuard guard_(device);
@@ -850,6 +873,23 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (!h) return FBUS_ERR_NOMEM;
     h->B = batch;
     h->Bs = (batch + 63) / 64 * 64;
+    {   // launch policy from the device: CU count -> SIMDs, L2 size; the memory-side cache is not exposed (256 MiB per 1024 SIMDs)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
+            if (prop.l2CacheSize > 0) h->l2_bytes = (size_t)prop.l2CacheSize;
+        }
+        int simds = h->cus * 4;
+        if (const char* e = std::getenv("FBUS_FAKE_SIMDS")) { const int v = std::atoi(e); if (v >= 4) { simds = v / 4 * 4; h->cus = simds / 4; } }
+        h->lp.simds = simds;
+        h->lp.two_wave_min_b = simds * 64 + 1;
+        if (const char* e = std::getenv("FBUS_TWO_WAVE_MIN_B")) h->lp.two_wave_min_b = std::atoi(e);
+        h->lp.meas_vec = std::getenv("FBUS_NO_MEAS_VEC") == nullptr;
+        h->mall_bytes = ((size_t)256 << 20) / 1024 * (size_t)simds;
+        if (const char* e = std::getenv("FBUS_MALL_MB")) { const long v = std::atol(e); if (v > 0) h->mall_bytes = (size_t)v << 20; }
+        // records larger than this leave the one-round, cache-resident regime (measured crossover 52-60 MB on 1024 SIMDs, 4.1)
+        h->big_records_mb = (int)(56L * simds / 1024);
+    }
     if (const char* e = std::getenv("FBUS_BIG_RECORDS_MB")) h->big_records_mb = std::atoi(e);
     if (const char* e = std::getenv("FBUS_WARM_AFTER_CORRECT")) h->warm_after_correct = std::atoi(e) != 0;
     if (const char* e = std::getenv("FBUS_PREDICT_POLICY")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->predict_policy_force = v; }
@@ -921,6 +961,32 @@ int fbus_ekf_set_team(fbus_ekf_t h, int predict_roles, int correct_roles)
     if (!h || predict_roles < 0 || predict_roles > 4 || correct_roles < 0 || correct_roles > 4) return FBUS_ERR_INVALID;
     h->team_predict = predict_roles;
     h->team_correct = correct_roles;
+    return FBUS_OK;
+}
+
+int fbus_ekf_set_policy_batch(fbus_ekf_t h, int total_filters)
+{
+    if (!h || total_filters < 0) return FBUS_ERR_INVALID;
+    h->policy_batch = total_filters;
+    return FBUS_OK;
+}
+
+int fbus_ekf_launch_info(fbus_ekf_t h, int what, int arg, int* value)
+{
+    if (!h || !value) return FBUS_ERR_INVALID;
+    switch (what) {
+        case FBUS_INFO_SIMDS: *value = h->lp.simds; break;
+        case FBUS_INFO_ONE_ROUND_FILTERS: *value = h->lp.simds * 64; break;
+        case FBUS_INFO_TWO_WAVE_MIN_B: *value = h->lp.two_wave_min_b; break;
+        case FBUS_INFO_BIG_RECORDS_MB: *value = h->big_records_mb; break;
+        case FBUS_INFO_MALL_MB: *value = (int)(h->mall_bytes >> 20); break;
+        case FBUS_INFO_L2_KB: *value = (int)(h->l2_bytes >> 10); break;
+        case FBUS_INFO_POLICY_BATCH: *value = h->policy_batch > 0 ? h->policy_batch : h->B; break;
+        case FBUS_INFO_ROLES_PREDICT: *value = team_roles_predict(h, arg > 1 ? arg : 1); break;
+        case FBUS_INFO_ROLES_MEAS: *value = team_roles_pixels(h, arg > 0 ? arg : 4); break;
+        case FBUS_INFO_TEAM_FRAMES: *value = team_frames(h, MODE_STACKED) ? 1 : 0; break;
+        default: return FBUS_ERR_INVALID;
+    }
     return FBUS_OK;
 }
 

@@ -21,22 +21,18 @@
 
 namespace fbus {
 
-// From this many filters on a launch has more waves than the chip has SIMDs (1024): some SIMDs hold two, and the
-// instantiations written for at most 256 registers (row-split correct, parked predict_n / frame) let them run side by
-// side instead of one after the other; up to 1024 waves every SIMD holds one wave whatever the register count, and the
-// one-wave forms win.  r2 switched at 2048 waves; r3 measured the range in between (tools/r3_tail.sh,
-// profiles/logs/r03_tail_sweep.txt): stacked correct at 73 728 filters 24.9 -> 21.4 us, fused frame +20 % from 69 632 to
-// 114 688 filters.  FBUS_TWO_WAVE_MIN_B moves the threshold (A/B runs, tests).
-static int two_wave_min_b()
-{
-    static const int v = [] { const char* e = getenv("FBUS_TWO_WAVE_MIN_B"); return e ? atoi(e) : 1024 * BLOCK + 1; }();
-    return v;
-}
+// LaunchPolicy::two_wave_min_b (ekf_launch.hpp; default SIMDs x 64 + 1): from this many filters on a launch has more waves than
+// the chip has SIMDs: some SIMDs hold two, and the instantiations written for at most 256 registers (row-split correct, parked
+// predict_n / frame) let them run side by side instead of one after the other; up to one wave per SIMD every SIMD holds one wave
+// whatever the register count, and the one-wave forms win.  r2 switched at 2048 waves; r3 measured the range in between
+// (tools/r3_tail.sh, profiles/logs/r03_tail_sweep.txt): stacked correct at 73 728 filters 24.9 -> 21.4 us, fused frame +20 % from
+// 69 632 to 114 688 filters.  r4: the threshold comes from the device (CU count) through the handle, FBUS_TWO_WAVE_MIN_B is read
+// once at create.
 
 #if FBUS_TU_FAMILY == 1
 template <typename T, int N, int D>
 void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T* accel, const T* gyro, const T* dt,
-                      int dt_stride, const DevConst<T>& dc)
+                      int dt_stride, const DevConst<T>& dc, const LaunchPolicy& lp)
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
     // policy 0: nt loads and stores; 1: default-policy loads (first predict behind a kernel that stored the records with
@@ -56,7 +52,7 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
             hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_NT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, 1,
                                accel + (size_t)k * B * 3, gyro + (size_t)k * B * 3, dt + (size_t)k * (dt_stride ? B : 1),
                                dt_stride, dc);
-    } else if (B >= two_wave_min_b()) {
+    } else if (B >= lp.two_wave_min_b) {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
                            K, accel, gyro, dt, dt_stride, dc);
     } else {
@@ -67,25 +63,25 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
 #define FBUS_INST(D)                                                                                                  \
     template void launch_predict_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, int, const FBUS_TU_T*,  \
                                                             const FBUS_TU_T*, const FBUS_TU_T*, int,                  \
-                                                            const DevConst<FBUS_TU_T>&);
+                                                            const DevConst<FBUS_TU_T>&, const LaunchPolicy&);
 
 #elif FBUS_TU_FAMILY == 2
 template <typename T, int N, int D>
 void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode,
-                      bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
+                      bool joseph, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const LaunchPolicy& lp)
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
     const bool joint = mode == MODE_STACKED;
     // measurement inputs as 16-byte loads where that is legal (groups of four markers, aligned arrays)
     if (M % 4 == 0 && ((reinterpret_cast<uintptr_t>(ids) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(quat)) & 15) == 0 &&
-        !getenv("FBUS_NO_MEAS_VEC"))
+        lp.meas_vec)
         mode |= MODE_MEAS_VEC;
 #define FBUS_LAUNCH_CORRECT(COV, JOINT)                                                                              \
     hipLaunchKernelGGL((correct_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, pos, quat, \
                        mode, skip, applied, dc)
     // fp32, stacked, simple form: from 1025 waves on (two on some SIMDs) the row-split instantiation (194 registers) is the
     // faster one -- see the LEAN comment in correct_kernel
-    if (sizeof(T) == 4 && joint && !joseph && B >= two_wave_min_b()) {
+    if (sizeof(T) == 4 && joint && !joseph && B >= lp.two_wave_min_b) {
         hipLaunchKernelGGL((correct_kernel<T, N, D, COV_SIMPLE, true, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
                            pos, quat, mode, skip, applied, dc);
         return;
@@ -98,13 +94,13 @@ void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
     template void launch_correct_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,             \
                                                             const FBUS_TU_T*, const FBUS_TU_T*, int, bool,             \
                                                             const unsigned char*, unsigned char*,                      \
-                                                            const DevConst<FBUS_TU_T>&);
+                                                            const DevConst<FBUS_TU_T>&, const LaunchPolicy&);
 
 #elif FBUS_TU_FAMILY == 3
 template <typename T, int N, int D>
 void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
                     int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
-                    const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
+                    const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const LaunchPolicy& lp)
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
     const bool joint = mode == MODE_STACKED;
@@ -114,7 +110,7 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
     // (Joseph form, nearest marker) is not built as a fused kernel (7 Joseph rank-2 passes with the record resident
     // spilled 280 bytes per lane): fbus_ekf.hip runs that combination as predict_n + correct
     // stacked mode, simple form, > 1024 waves: the two-waves-per-SIMD kernel (see frame2_kernel)
-    if (joint && !joseph && B >= two_wave_min_b()) {
+    if (joint && !joseph && B >= lp.two_wave_min_b) {
         hipLaunchKernelGGL((frame2_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, dt_stride, M, ids,
                            pos, quat, skip, applied, dc);
         return;
@@ -128,7 +124,7 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
                                                           const FBUS_TU_T*, const FBUS_TU_T*, int, int, const int*,   \
                                                           const FBUS_TU_T*, const FBUS_TU_T*, int, bool,              \
                                                           const unsigned char*, unsigned char*,                       \
-                                                          const DevConst<FBUS_TU_T>&);
+                                                          const DevConst<FBUS_TU_T>&, const LaunchPolicy&);
 
 #elif FBUS_TU_FAMILY == 4
 template <typename T, int N, int D>

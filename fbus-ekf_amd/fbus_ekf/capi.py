@@ -18,7 +18,10 @@ L0_QUAT_MUL, L0_QUAT_TO_ROTMAT_M, L0_QUAT_TO_ROTMAT_E, L0_QUAT_NORMALIZE, L0_EXP
 MAX_MARKERS, MAX_VISIBLE = 32, 16
 MAX_WINDOW_FRAMES = 64           # fbus_ekf_frames_fused_dev
 STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
-ABI_VERSION = 3                    # FBUS_ABI_VERSION of the header this mirror was written against
+# fbus_ekf_launch_info (include/fbus_ekf.h)
+(INFO_SIMDS, INFO_ONE_ROUND_FILTERS, INFO_TWO_WAVE_MIN_B, INFO_BIG_RECORDS_MB, INFO_MALL_MB, INFO_L2_KB, INFO_POLICY_BATCH,
+ INFO_ROLES_PREDICT, INFO_ROLES_MEAS, INFO_TEAM_FRAMES) = range(10)
+ABI_VERSION = 4                    # FBUS_ABI_VERSION of the header this mirror was written against
 ERR_ABI = 6
 
 
@@ -88,6 +91,8 @@ def load_library():
         "fbus_ekf_destroy": ([H], C.c_int),
         "fbus_ekf_set_stream": ([H, vp], C.c_int),
         "fbus_ekf_set_team": ([H, C.c_int, C.c_int], C.c_int),
+        "fbus_ekf_set_policy_batch": ([H, C.c_int], C.c_int),
+        "fbus_ekf_launch_info": ([H, C.c_int, C.c_int, C.POINTER(C.c_int)], C.c_int),
         "fbus_ekf_wait_stream": ([H, vp], C.c_int),
         "fbus_ekf_signal_stream": ([H, vp], C.c_int),
         "fbus_ekf_sync": ([H], C.c_int),

@@ -90,6 +90,26 @@ class BatchedFilter:
         correct_corners (stacked mode) and correct_pixels (2 = two waves per tile, 3..4 = four) -- include/fbus_ekf.h, DESIGN.md 4.5"""
         self._check(self._lib.fbus_ekf_set_team(self._h, int(predict_roles), int(correct_roles)), "set_team")
 
+    def set_policy_batch(self, total_filters):
+        """the batch the automatic kernel-family choice is keyed on: the WHOLE job when this handle holds one shard of it
+        (every shard layout then runs the same kernels: bit-equal results); 0 = this handle's own batch"""
+        self._check(self._lib.fbus_ekf_set_policy_batch(self._h, int(total_filters)), "fbus_ekf_set_policy_batch")
+
+    def launch_info(self, what, arg=0):
+        v = C.c_int(0)
+        self._check(self._lib.fbus_ekf_launch_info(self._h, int(what), int(arg), C.byref(v)), "fbus_ekf_launch_info")
+        return v.value
+
+    def launch_policy(self, M=4, K=7):
+        """the handle's launch policy as a dict (what bench.py records beside its numbers)"""
+        c = capi
+        return {"simds": self.launch_info(c.INFO_SIMDS), "one_round_filters": self.launch_info(c.INFO_ONE_ROUND_FILTERS),
+                "two_wave_min_b": self.launch_info(c.INFO_TWO_WAVE_MIN_B), "big_records_MB": self.launch_info(c.INFO_BIG_RECORDS_MB),
+                "mall_MB": self.launch_info(c.INFO_MALL_MB), "l2_KB": self.launch_info(c.INFO_L2_KB),
+                "policy_batch": self.launch_info(c.INFO_POLICY_BATCH), "roles_predict": self.launch_info(c.INFO_ROLES_PREDICT, 1),
+                "roles_predict_n": self.launch_info(c.INFO_ROLES_PREDICT, K), "roles_meas": self.launch_info(c.INFO_ROLES_MEAS, M),
+                "team_frames": bool(self.launch_info(c.INFO_TEAM_FRAMES))}
+
     def wait_stream(self, stream):
         """work submitted to this filter from now on starts after everything already queued on `stream`"""
         self._check(self._lib.fbus_ekf_wait_stream(self._h, C.c_void_p(int(getattr(stream, "cuda_stream", stream)))), "wait_stream")

@@ -42,6 +42,9 @@ public:
     ShardedFilter(long total, int rank, int world, const UniqueId& id, const fbus_params& prm, int device, int nstate = 18)
         : total_(total), rank_(rank), world_(world), flt_(make(total, rank, world), prm, device, nstate)
     {
+        // the kernel-family choice is keyed on the WHOLE job, not on this shard: every shard layout runs the same kernels and
+        // produces the bits of the single-handle run (team and one-wave kernels agree to fp32 rounding only)
+        check(fbus_ekf_set_policy_batch(flt_.handle(), int(std::min<long>(total, 0x7fffffff))), "fbus_ekf_set_policy_batch");
         check(fbus_ekf_comm_init(flt_.handle(), id.data(), rank, world), "fbus_ekf_comm_init");
         size_t bpf = 0;
         check(fbus_ekf_records(flt_.handle(), nullptr, &bpf, nullptr), "fbus_ekf_records");

@@ -105,10 +105,11 @@ int fbus_params_validate(const fbus_params* prm, char* msg, size_t msg_len);
  * the caller's compile-time sizeof(fbus_params) and FBUS_ABI_VERSION to fbus_ekf_create_checked, which refuses a
  * mismatch with FBUS_ERR_ABI.  (Bindings that cannot use the macro -- ctypes, loadlibrary -- call
  * fbus_ekf_abi_version() / fbus_params_size() once after loading and compare; the Python mirror does.)
+ *   4  round 4: fbus_ekf_set_policy_batch, fbus_ekf_launch_info (struct unchanged)
  *   3  round 3: FBUS_ERR_ABI, create_checked, team kernels (fbus_ekf_set_team), fbus_ekf_gather
  *   2  round 2: r_pix in fbus_params, set_stream(NULL) = legacy default stream
  *   1  round 1 */
-#define FBUS_ABI_VERSION 3
+#define FBUS_ABI_VERSION 4
 int fbus_ekf_abi_version(void);
 size_t fbus_params_size(void);
 
@@ -143,6 +144,24 @@ int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream);
  * one step, the one-wave kernel as six sequential rank-1 passes), so a caller that compares runs BIT FOR BIT across batch
  * sizes or shard layouts pins the value. */
 int fbus_ekf_set_team(fbus_ekf_t h, int predict_roles, int correct_roles);
+/* (round 4) The batch the automatic kernel-FAMILY choice above is keyed on.  0 (default): this handle's own batch.  A job that is
+ * cut into shards over several handles / GPUs (fbus::ShardedFilter, bench.py --total-batch) names the WHOLE job here, so that every
+ * shard layout runs the same kernels and produces the same bits as the single-handle run (the team and the one-wave kernels agree
+ * to fp32 rounding only).  No reference counterpart (one filter, one thread: filter.cpp:190-250). */
+int fbus_ekf_set_policy_batch(fbus_ekf_t h, int total_filters);
+/* What the launch policy of this handle is (decided at create from the device: CU count, cache sizes; environment overrides are
+ * read there once -- no entry point reads the environment afterwards).  `arg`: K for FBUS_INFO_ROLES_PREDICT, M for
+ * FBUS_INFO_ROLES_MEAS, else ignored. */
+enum { FBUS_INFO_SIMDS = 0,            /* SIMDs of the device = CUs x 4 (FBUS_FAKE_SIMDS overrides it: tests)              */
+       FBUS_INFO_ONE_ROUND_FILTERS = 1,/* filters of one wave per SIMD = SIMDs x 64                                         */
+       FBUS_INFO_TWO_WAVE_MIN_B = 2,   /* from this many filters on the <= 256-register kernel forms run                   */
+       FBUS_INFO_BIG_RECORDS_MB = 3,   /* records above this take the default cache policy in predict                      */
+       FBUS_INFO_MALL_MB = 4, FBUS_INFO_L2_KB = 5,
+       FBUS_INFO_POLICY_BATCH = 6,     /* see fbus_ekf_set_policy_batch                                                    */
+       FBUS_INFO_ROLES_PREDICT = 7,    /* waves per tile the next predict (arg = 1) / predict_n (arg = K) would use       */
+       FBUS_INFO_ROLES_MEAS = 8,       /* ... correct_corners (stacked) / correct_pixels with arg = M marker slots          */
+       FBUS_INFO_TEAM_FRAMES = 9 };    /* 1: the fused frame / frame window entry points use the team kernel              */
+int fbus_ekf_launch_info(fbus_ekf_t h, int what, int arg, int* value);
 /* Cross-stream ordering without a host sync (hipEventRecord + hipStreamWaitEvent):
  * wait_stream   -- work submitted to the handle's stream after this call starts
  *                  only when everything already submitted to other_stream is done

@@ -1,0 +1,198 @@
+"""GPU suite for the launch policy (round 4): thresholds derived from the device, whole rounds as launches of their own past one
+wave per SIMD, and the policy batch that makes the kernel-family choice independent of the shard layout.
+No reference counterpart for any of it (the reference runs one filter on one thread, C++/src/filter.cpp:190-250); the arithmetic
+that must not change is ImuUpdate.m:36-82 / MeasureUpdate.m:37-103."""
+import os
+
+import numpy as np
+import pytest
+
+from fbus_ekf import BatchedFilter, capi, synth
+from replay_ref import OracleEngine
+from util import PLAIN_WINDOW_TOL, assert_parity
+
+pytestmark = pytest.mark.gpu
+DT = np.array([np.float64(np.float32(0.005))])
+
+
+def _r32(a):
+    return np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+
+
+class _env:
+    """environment knobs are read ONCE, at fbus_ekf_create: set them around the construction of a handle"""
+
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _inputs(B, M, dialect=0, seed=0, with_cov=True):
+    prm = capi.default_params(dialect)
+    nom, rot, P, prev = synth.initial_state(seed, seed + B, list(prm.p0_diag), 18, mixed_cov=with_cov, with_cov=with_cov)
+    nom, rot = _r32(nom), _r32(rot)
+    P = _r32(P) if P is not None else None
+    acc, gyr = synth.imu_samples(seed, seed + B, 0, 3, nom)
+    ids, pos, quat = synth.marker_frame(seed, seed + B, 0, M, nom, prm)
+    return prm, nom, rot, P, prev, _r32(acc), _r32(gyr), ids, _r32(pos), _r32(quat)
+
+
+def _run(flt, nom, rot, P, prev, acc, gyr, ids, pos, quat):
+    flt.set_state(nom, rot, P, prev)
+    if P is None:
+        flt.reset_cov()
+    for k in range(2):
+        flt.predict(acc[k], gyr[k], DT)
+    flt.correct(ids, pos, quat, capi.MODE_STACKED)
+    flt.predict(acc[2], gyr[2], DT)
+    return flt.get_state()
+
+
+def test_launch_policy_follows_the_device_and_halves_with_half_the_simds():
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    prm = capi.default_params(0)
+    with BatchedFilter(16384, prm) as flt:
+        p = flt.launch_policy(M=4, K=7)
+    assert p["simds"] == 4 * cus and p["one_round_filters"] == 256 * cus and p["two_wave_min_b"] == 256 * cus + 1
+    assert p["policy_batch"] == 16384
+    quarter = p["simds"] // 4
+    # 16 384 filters = 256 tiles: a quarter of a 1024-SIMD chip -> the per-call predict and the measurement folds divide the work
+    assert (p["roles_predict"], p["roles_meas"], p["team_frames"]) == ((3, 4, True) if 256 <= quarter else (1, 2 if 256 <= 2 * quarter else 1, 256 <= 2 * quarter))
+    with _env(FBUS_FAKE_SIMDS=p["simds"] // 2):
+        with BatchedFilter(16384, prm) as flt:
+            h = flt.launch_policy(M=4, K=7)
+    assert h["simds"] == p["simds"] // 2 and h["one_round_filters"] == p["one_round_filters"] // 2
+    assert h["two_wave_min_b"] == p["one_round_filters"] // 2 + 1 and h["mall_MB"] == p["mall_MB"] // 2
+    assert h["big_records_MB"] == p["big_records_MB"] // 2
+    if p["simds"] == 1024:
+        assert (h["roles_predict"], h["roles_meas"]) == (1, 2)          # 256 tiles are half of a 512-SIMD device
+        with BatchedFilter(8192, prm) as flt:
+            assert flt.launch_info(capi.INFO_ROLES_PREDICT, 1) == 3      # 128 tiles: a quarter of this device ...
+        with _env(FBUS_FAKE_SIMDS=512):
+            with BatchedFilter(8192, prm) as flt:
+                assert flt.launch_info(capi.INFO_ROLES_PREDICT, 1) == 3  # ... and exactly a quarter of the halved one
+            with BatchedFilter(8256, prm) as flt:
+                assert flt.launch_info(capi.INFO_ROLES_PREDICT, 1) == 1
+
+
+def test_parity_holds_with_half_the_simds():
+    """FBUS_FAKE_SIMDS = half the device: 40 000 filters are then more than one wave per SIMD and take the two-wave kernel forms:
+    the same results as the default policy to an ulp, and parity with the oracle on a strided subset"""
+    B, M = 40000, 4
+    prm, nom, rot, P, prev, acc, gyr, ids, pos, quat = _inputs(B, M, with_cov=False)
+    with BatchedFilter(B, prm) as flt:
+        simds = flt.launch_info(capi.INFO_SIMDS)
+        ref = _run(flt, nom, rot, None, prev, acc, gyr, ids, pos, quat)
+    with _env(FBUS_FAKE_SIMDS=simds // 2):
+        with BatchedFilter(B, prm) as flt:
+            assert flt.launch_info(capi.INFO_TWO_WAVE_MIN_B) == simds // 2 * 64 + 1
+            got = _run(flt, nom, rot, None, prev, acc, gyr, ids, pos, quat)
+    for a, b in zip(got[:3], ref[:3]):       # the two-wave forms against the one-wave forms: equal to an ulp (see below)
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        scale = np.maximum(np.abs(b).max(axis=tuple(range(1, b.ndim)), keepdims=True), 1.0)
+        assert np.abs((a - b) / scale).max() <= 8 * 1.2e-7
+    assert np.array_equal(got[3], ref[3])
+    sub = np.arange(0, B, 977)
+    eng = OracleEngine(len(sub), 0, 18)
+    P0 = np.broadcast_to(np.diag(np.repeat(np.array(list(prm.p0_diag)), 3)), (len(sub), 18, 18)).copy()
+    eng.set_state(nom[sub], rot[sub], P0, prev[sub])
+    for k in range(2):
+        eng.predict(acc[k][sub], gyr[k][sub], DT)
+    eng.correct(ids[sub], pos[sub], quat[sub], capi.MODE_STACKED)
+    eng.predict(acc[2][sub], gyr[2][sub], DT)
+    assert_parity([x[sub] for x in got], eng.get_state(), 32, "half the SIMDs", plain_tol=PLAIN_WINDOW_TOL)
+
+
+@pytest.mark.parametrize("B", [73728, 70001])
+def test_more_filters_than_one_wave_per_simd(B):
+    """past one wave per SIMD the launcher takes the <= 256-register kernel forms (row-split correct): against the one-wave forms
+    (FBUS_TWO_WAVE_MIN_B out of reach) -- the same operations in the same order, compiled apart: equal to an ulp -- and against the
+    oracle on a subset; 70 001 filters: ragged last tile"""
+    M = 4
+    prm, nom, rot, P, prev, acc, gyr, ids, pos, quat = _inputs(B, M, with_cov=False)
+    res = {}
+    for two in (1 << 30, None):
+        with _env(**({"FBUS_TWO_WAVE_MIN_B": two} if two else {})):
+            with BatchedFilter(B, prm) as flt:
+                one_round = flt.launch_info(capi.INFO_ONE_ROUND_FILTERS)
+                assert flt.launch_info(capi.INFO_TWO_WAVE_MIN_B) == (two if two else one_round + 1)
+                res[two] = _run(flt, nom, rot, None, prev, acc, gyr, ids, pos, quat)
+                assert (flt.applied() == 1).all()
+    for name, a, b in zip(("nominal", "rot", "P"), res[1 << 30][:3], res[None][:3]):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        scale = np.maximum(np.abs(b).max(axis=tuple(range(1, b.ndim)), keepdims=True), 1.0)
+        print(f"[two-wave forms] {B} {name}: max |d| / scale {np.abs((a - b) / scale).max():.2e}, elements that differ {(a != b).mean():.4f}")
+        assert np.abs((a - b) / scale).max() <= 8 * 1.2e-7
+    assert np.array_equal(res[1 << 30][3], res[None][3])
+    sub = np.concatenate([np.arange(0, B, 1499), np.arange(B - 3, B)])
+    eng = OracleEngine(len(sub), 0, 18)
+    P0 = np.broadcast_to(np.diag(np.repeat(np.array(list(prm.p0_diag)), 3)), (len(sub), 18, 18)).copy()
+    eng.set_state(nom[sub], rot[sub], P0, prev[sub])
+    for k in range(2):
+        eng.predict(acc[k][sub], gyr[k][sub], DT)
+    eng.correct(ids[sub], pos[sub], quat[sub], capi.MODE_STACKED)
+    eng.predict(acc[2][sub], gyr[2][sub], DT)
+    assert_parity([x[sub] for x in res[None]], eng.get_state(), 32, f"{B} filters", plain_tol=PLAIN_WINDOW_TOL)
+
+
+def test_shards_equal_the_single_handle_bit_for_bit_under_the_policy_batch():
+    """24 576 filters as ONE handle (384 tiles: four-role predict_n and frame kernels, one-wave per-call predict) and as three shards
+    of 8 192 (128 tiles each: left alone they would take the three-role per-call predict as well).  With the policy batch set to
+    the whole job -- what fbus::ShardedFilter and bench.py --total-batch do -- every shard runs the single handle's kernels and the
+    gathered result is bit-equal; without it the results agree to fp32 rounding only."""
+    total, M, K = 24576, 4, 7
+    prm, nom, rot, P, prev, acc3, gyr3, ids, pos, quat = _inputs(total, M, with_cov=False)
+    acc, gyr = synth.imu_samples(0, total, 0, K, nom)
+    acc, gyr = _r32(acc), _r32(gyr)
+    dts = np.full(K, DT[0])
+
+    def job(flt, lo, hi):
+        flt.set_state(nom[lo:hi], rot[lo:hi], None, prev[lo:hi])
+        flt.reset_cov()
+        flt.predict(acc[0][lo:hi], gyr[0][lo:hi], DT)
+        flt.predict_n(np.ascontiguousarray(acc[:, lo:hi]), np.ascontiguousarray(gyr[:, lo:hi]), dts)
+        flt.correct(ids[lo:hi], pos[lo:hi], quat[lo:hi], capi.MODE_STACKED)
+        import torch
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+        flt.frame(f32(acc[:3, lo:hi]), f32(gyr[:3, lo:hi]), f32(dts[:3]), torch.from_numpy(np.ascontiguousarray(ids[lo:hi])).cuda(),
+                  f32(pos[lo:hi]), f32(quat[lo:hi]), capi.MODE_STACKED, fused=True)
+        flt.sync()
+        return flt.get_state()
+
+    with BatchedFilter(total, prm) as flt:
+        if flt.launch_info(capi.INFO_SIMDS) != 1024:
+            pytest.skip("thresholds of the 1024-SIMD device")
+        single = job(flt, 0, total)
+        fam = (flt.launch_info(capi.INFO_ROLES_PREDICT, 1), flt.launch_info(capi.INFO_ROLES_PREDICT, K), flt.launch_info(capi.INFO_TEAM_FRAMES))
+    assert fam == (1, 4, 1)
+    for pinned in (True, False):
+        parts = []
+        for r in range(3):
+            lo, hi = r * 8192, (r + 1) * 8192
+            with BatchedFilter(hi - lo, prm) as flt:
+                if pinned:
+                    flt.set_policy_batch(total)
+                    assert (flt.launch_info(capi.INFO_ROLES_PREDICT, 1), flt.launch_info(capi.INFO_ROLES_PREDICT, K),
+                            flt.launch_info(capi.INFO_TEAM_FRAMES)) == fam
+                else:
+                    assert flt.launch_info(capi.INFO_ROLES_PREDICT, 1) == 3
+                parts.append(job(flt, lo, hi))
+        gathered = [np.concatenate([p[i] for p in parts]) for i in range(4)]
+        if pinned:
+            for a, b in zip(gathered, single):
+                assert np.array_equal(a, b)
+        else:
+            d0 = np.abs(gathered[0].astype(np.float64) - single[0]).max()
+            print(f"[shards] un-pinned shards against the single handle: max |d nominal| {d0:.2e}, bit-equal {np.array_equal(gathered[0], single[0])}")
+            assert d0 < 1e-4

@@ -144,6 +144,15 @@ static void run(float* recs, const float* acc, const float* gyr, const float* dt
         printf("   %-22s min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us\n", MODE ? lbl1[k] : lbl0[k], v[0], v[tiles / 10],
                v[tiles / 2], v[tiles * 9 / 10], v[tiles - 1]);
     }
+    if (tiles > 1024) {
+        // the workgroups past the first 1024 (one per SIMD): when do they start, when do they end?
+        std::vector<double> a, b_, c;
+        for (int t = 1024; t < tiles; ++t) { a.push_back(double(s[t * 5] - base) * 0.01); b_.push_back(double(s[t * 5 + 4] - base) * 0.01); }
+        for (int t = 0; t < 1024; ++t) c.push_back(double(s[t * 5 + 4] - base) * 0.01);
+        std::sort(a.begin(), a.end()); std::sort(b_.begin(), b_.end()); std::sort(c.begin(), c.end());
+        printf("   workgroups >= 1024 (%zu): entry min %6.2f p50 %6.2f max %6.2f us; done p50 %6.2f max %6.2f us | first 1024: done p50 %6.2f max %6.2f us\n",
+               a.size(), a[0], a[a.size() / 2], a.back(), b_[b_.size() / 2], b_.back(), c[512], c.back());
+    }
     // per-wave phase lengths
     for (int k = 1; k < 5; ++k) {
         std::vector<double> v(tiles);
@@ -152,6 +161,27 @@ static void run(float* recs, const float* acc, const float* gyr, const float* dt
         printf("   phase %d->%d             min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us\n", k - 1, k, v[0], v[tiles / 10],
                v[tiles / 2], v[tiles * 9 / 10], v[tiles - 1]);
     }
+}
+
+template <int LD, int ST>
+static void run_lib_pol(float* recs, const float* acc, const float* gyr, const float* dt, int B, int pool, const char* name)
+{
+    DevConst<float> dc = {};
+    dc.qd[0] = 1e-4f; dc.qd[1] = 1e-6f; dc.qd[2] = 1e-8f; dc.qd[3] = 1e-10f;
+    const int tiles = B / 64, reps = 200;
+    reset_records(recs);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto go = [&](int r) {
+        const size_t o = (size_t)(r % pool) * B * 3;
+        predict_kernel<float, 18, 0, false, LD, ST><<<tiles, 64>>>(recs, B, 1, acc + o, gyr + o, dt, 0, dc);
+    };
+    for (int r = 0; r < 5; ++r) go(r);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) go(r);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("   B %6d (%4d waves) library predict_kernel %s: %.2f us per launch\n", B, tiles, name, ms * 1e3 / reps);
 }
 
 static void run_lib(float* recs, const float* acc, const float* gyr, const float* dt, int B, int pool)
@@ -203,7 +233,7 @@ static void run_mixed(float* recs, const float* acc, const float* gyr, const flo
 
 int main()
 {
-    const int B = 65536;
+    const int B = getenv("TAIL_B") ? atoi(getenv("TAIL_B")) : 65536;
     float *recs, *acc, *gyr, *dt; unsigned long long* d_st;
     CK(hipMalloc(&recs, (size_t)B / 64 * RC::NCH * 1024));
     CK(hipMalloc(&acc, (size_t)B * 12 * 96)); CK(hipMalloc(&gyr, (size_t)B * 12 * 96)); CK(hipMalloc(&dt, 4));
@@ -245,6 +275,18 @@ int main()
         // Infinity Cache residency: the same launches with the IMU sample taken from a pool of 1 .. 96 slices
         // (build with -DIMU_NT for non-temporal IMU loads: the times then stay at the pool-1 level)
         for (int pool : {1, 1, 8, 32, 96, 1, 1}) run_lib(recs, acc, gyr, dt, B, pool);
+        return 0;
+    }
+    if (getenv("TAIL_POL")) {
+        run_lib_pol<AUX_NT, AUX_NT>(recs, acc, gyr, dt, B, 8, "nt loads, nt stores          ");
+        run_lib_pol<AUX_DEFAULT, AUX_NT>(recs, acc, gyr, dt, B, 8, "default loads, nt stores     ");
+        run_lib_pol<AUX_DEFAULT, AUX_DEFAULT>(recs, acc, gyr, dt, B, 8, "default loads, default stores");
+        run_lib_pol<AUX_NT, AUX_DEFAULT>(recs, acc, gyr, dt, B, 8, "nt loads, default stores     ");
+        return 0;
+    }
+    if (getenv("TAIL_B")) {
+        run_lib(recs, acc, gyr, dt, B, 8);
+        run<1, 2>(recs, acc, gyr, dt, d_st, B, "staged stream, nt stores", 1, 0, true, 8);
         return 0;
     }
     run_lib(recs, acc, gyr, dt, B, 8);
