@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Builds fbus-ekf_amd/lib/libfbus_ekf.so (HIP, gfx950) in-tree with hipcc.
 
-The library is 23 translation units compiled in parallel and linked into one shared object:
+The library is 19 translation units compiled in parallel and linked into one shared object:
   fbus_ekf.hip                          handle, C ABI, the small kernels (pack/unpack, init, EMA, marker pose)
-  kernels_tu.hip x 22                   one kernel family (predict / correct / fused frame / corners / frame window / team / pixel rows) for one
+  kernels_tu.hip x 18                   one kernel family (predict / correct / fused frame / frame window / team / corner + pixel rows) for one
                                         (float|double, N = 18|15), both dialects: -DFBUS_TU_T/N/FAMILY
 Objects live in fbus-ekf_amd/lib/obj/ (git-ignored) and are rebuilt when a source they include is newer.
   python build.py [--force] [--only f32_18_correct,...] [--jobs N]
@@ -21,7 +21,7 @@ HEADERS = [os.path.join(CSRC, h) for h in ("ekf_kernels.hpp", "ekf_device.hpp", 
 OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so")   # FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds
 OBJDIR = os.environ.get("FBUS_OBJDIR") or os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("FBUS_OUT") else
                                                        "obj_" + os.path.splitext(os.path.basename(OUT))[0])
-FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4, "frames": 5, "team": 6, "meas": 7}
+FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "frames": 5, "team": 6, "meas": 7}
 # Per-family scheduler choice (measured in one run, B = 65 536, tools/ab_bench.sh, profiles/logs/r02_ab2.log): the
 # max-ILP strategy of the AMDGPU machine scheduler shortens the per-call kernels, where one wave per SIMD has nothing
 # but its own independent instructions to cover dependent-issue stalls (predict 13.4 -> 13.05 us, stacked correct
@@ -29,7 +29,7 @@ FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "corners": 4, "frames": 5, "
 # v_accvgpr traffic), which therefore keeps the default strategy.
 FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "correct": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-                "frame": [], "corners": [], "frames": [],
+                "frame": [], "frames": [],
                 "team": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "meas": os.environ.get("FBUS_MEAS_FLAGS", "").split()}
 TYPES = {"f32": "float", "f64": "double"}
 

@@ -1060,337 +1060,8 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
     }
 }
 
-// correct() from stereo corners: triangulation + 12 corner rows per marker (north-star extension).
-template <typename T, int N, int DIALECT, int COV>
-__global__ void __launch_bounds__(BLOCK)
-correct_corners_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
-                       const T* __restrict__ right, int geometry, int mode, T size,
-                       const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied, DevConst<T> dc,
-                       VisConst<T> vc)
-{
-    using L = Lay<N>;
-    using RC = Rec<T, N>;
-    const int b = blockIdx.x * BLOCK + threadIdx.x;
-    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
-    const int bc = b < B ? b : 0;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
-    // One wave per SIMD (config 3: 16 384 filters are ONE wave per CU): every dependent global load costs its whole latency.
-    // The marker map is looked up in LDS (as in correct_kernel; every lane carries a piece of it, so dead lanes run along
-    // until it is written), and the id and the 16 (12) corner coordinates of marker i + 1 are requested before marker i is
-    // triangulated and folded.  (B = 16 384, M = 4, refractive, stacked: 26.6 -> 25.6 us; 65 536 x 16 markers: 82.4 -> 76.0 us --
-    // the kernel is bound by the ~2600 VALU instructions per marker of the triangulation and the 12 row folds.)
-    __shared__ MarkerLDS<T> tbl;
-    struct Meas { int id; T l[12], r[8]; };
-    const bool c3d = geometry == VIS_CORNERS3D;
-    const int lw = c3d ? 12 : 8;
-    auto fetch = [&](int i, Meas& m) __attribute__((always_inline)) {
-        const size_t o = (size_t)bc * M + i;
-        m.id = ids[o];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m.l[j] = ld_meas(left + o * lw + j);
-#pragma unroll
-        for (int j = 8; j < 12; ++j) m.l[j] = c3d ? ld_meas(left + o * lw + j) : T(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m.r[j] = c3d ? T(0) : ld_meas(right + o * 8 + j);
-    };
-    auto corner = [&](const Meas& m, int c, T* out) __attribute__((always_inline)) {   // corner c (a constant after unrolling) in the left camera frame
-        if (geometry == VIS_CORNERS3D) { out[0] = m.l[3 * c]; out[1] = m.l[3 * c + 1]; out[2] = m.l[3 * c + 2]; return; }
-        if (geometry == VIS_REFRACTIVE) refraction_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
-        else pinhole_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
-    };
-    Meas cur, nxt;
-    T pqr[L::NPQR];
-    T prev_raw = T(0);
-    {
-        MarkerTableRegs<T> treg;
-        treg.load(dc);
-        order_fence();
-        if (M > 0) fetch(0, cur);
-        if (mode == MODE_NEAREST && DIALECT == DIALECT_CPP) prev_raw = recs[elem_index<T, N>(bc, L::OFF_PREV)];
-        order_fence();
-        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
-        order_fence();
-        treg.to_lds(tbl);
-        order_fence();
-    }
-    if (!live) { if (b < B) applied[b] = 0; return; }
-    int used = 0, new_prev = -1;
-    InfoAcc<T> acc;
-    PoseFold<T, N, DIALECT_MATLAB> fold;                 // position-type rows only: the dialect-dependent quaternion part is not used
-    fold.clear();
-    MarkerCommon<T, N> mc;
-    mc.build(pqr, dc);
-    // The rows of all markers are folded into the 6x6 information matrix BEFORE the covariance is requested: the 16
-    // ray intersections per marker are hundreds of live values, and with the 171 covariance registers reserved as load
-    // targets at the same time the fp64 instantiation spilled 600-800 bytes per lane to scratch (fp32: 20 bytes in
-    // the Joseph variants).
-    auto fold_marker = [&](const Meas& m) __attribute__((always_inline)) {
-        const bool ok = m.id >= 0 && m.id <= FBUS_MAX_MARKER_ID;
-        const int slot = ok ? (int)tbl.id2slot[ok ? m.id : 0] : -1;
-        if (slot < 0) return false;
-        T mk[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
-        T C[12];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) corner(m, c, C + 3 * c);
-        fold.add_corners(pqr, dc, mc, mk, C, size);
-        return true;
-    };
-    if (mode == MODE_NEAREST) {
-        // nearest visible marker by its first corner, C++ dialect: hysteresis against the previous one (filter.cpp:639-664)
-        const int prev_id = (int)prev_raw;
-        int min_i = -1, prev_i = -1;
-        T min_d = T(10), prev_d = T(0);
-#pragma unroll 1
-        for (int i = 0; i < M; ++i) {
-            fetch(i + 1 < M ? i + 1 : M - 1, nxt);          // always a fresh load (no conditional merge of the two records)
-            if (cur.id >= 0) {
-                T c0[3];
-                corner(cur, 0, c0);
-                const T dist = fb_sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
-                if (dist < min_d) { min_d = dist; min_i = i; }
-                if (DIALECT == DIALECT_CPP && cur.id == prev_id) { prev_d = dist; prev_i = i; }
-            }
-            cur = nxt;
-        }
-        if (min_i < 0) { applied[b] = 0; return; }
-        if (DIALECT == DIALECT_CPP && prev_i >= 0 && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) min_i = prev_i;
-        fetch(min_i, cur);                              // the chosen marker once more (a copy kept per candidate lived in scratch)
-        if (!fold_marker(cur)) { applied[b] = 0; return; }
-        if (DIALECT == DIALECT_CPP) new_prev = cur.id;
-        used = 1;
-    } else {
-#pragma unroll 1
-        for (int i = 0; i < M; ++i) {
-            fetch(i + 1 < M ? i + 1 : M - 1, nxt);          // always a fresh load (no conditional merge of the two records)
-            if (fold_marker(cur)) ++used;
-            cur = nxt;
-        }
-    }
-    if (used == 0) { applied[b] = 0; return; }
-    constexpr bool LEAN = sizeof(T) == 8;                // fp64: row-split passes, see correct_kernel
-    constexpr int RS = 9;
-    using Stash = LateStash<T, N, RS>;
-    using Hook = RowStore<T, N, AUX_DEFAULT>;
-    __shared__ T stash_mem[LEAN ? Stash::NVAL * BLOCK : 1];
-    InfoFactors<T> fac;
-    fold.finish(acc, pqr, dc, mc);
-    joint_factor<T>(acc, fac);
-    order_fence();
-    T P[RC::NCOVP];
-    T dx[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) dx[i] = T(0);
-    if constexpr (LEAN) {
-        const Stash stash{ stash_mem + threadIdx.x };
-        constexpr int E_END = cov_final_before_row<N>(RS);
-        constexpr int C_E = RC::CH_NOM + (E_END + RC::EPC - 1) / RC::EPC;
-        load_chunks<T, N, RC::CH_NOM, C_E, AUX_NT>(rs, my_lane(), P);
-        joint_apply_early<T, N, COV, RS, Hook>(P, dx, fac, Hook{ rs, my_lane(), P }, stash);
-        order_fence();
-        load_chunks<T, N, C_E, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_E - RC::CH_NOM) * RC::EPC);
-        joint_apply_late<T, N, COV, RS>(P, dx, stash);
-    } else {
-        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
-        joint_apply<T, N, COV>(P, dx, fac);
-    }
-    T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
-    inject<T, N>(nom, dx);
-    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
-    store_chunks<T, N, 0, RC::CH_PQ>(rs, my_lane(), nom);
-    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, my_lane(), nom + L::NPQR);
-    constexpr int C_REST = LEAN ? Hook::fin(RS) : RC::CH_NOM;        // LEAN: the early rows went out in the last pass
-    store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
-    applied[b] = 1;
-}
-
-// Pixel rows of one marker into the information accumulator (north-star extension, no reference counterpart):
-// for each of the four corners the predicted position X in the left camera frame (the geometry of PoseFold::add_corners), its
-// flat-port projection into the left (and right) camera with the closed-form 2 x 3 Jacobian, and 2 (4) rows
-// (d pi/dX) [ -R_IL R' | R_IL [R'(c_w - p)]x ] with the pixel residuals.
-template <typename T, int N>
-__device__ __forceinline__ void pixel_info(InfoAcc<T>& acc, const T* pqr, const DevConst<T>& dc, const VisConst<T>& vc,
-                                           const T* mk, const T* ylv, const T* yrv /* null: left camera only */, T size, T w_pix)
-{
-    using L = Lay<N>;
-    const T* p = pqr + L::OFF_P3; const T* R = pqr + L::OFF_R;
-    T Rm[9];
-    {
-        const T Qm[4] = { mk[3], mk[4], mk[5], mk[6] };
-        quat_to_rotmat_m(Qm, Rm);
-    }
-    T Hpp[9];                                            // -R_IL R': the same for every corner
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            Hpp[3 * i + j] = -(dc.R_IL[3 * i] * R[3 * j] + dc.R_IL[3 * i + 1] * R[3 * j + 1] + dc.R_IL[3 * i + 2] * R[3 * j + 2]);
-    T RP[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) RP[i] = R[3 * i] * dc.P_IL[0] + R[3 * i + 1] * dc.P_IL[1] + R[3 * i + 2] * dc.P_IL[2];
-    // ylv / yrv: the marker's 8 + 8 image coordinates in registers (the kernel requests them one marker ahead); a corner
-    // picks its pair with selects -- an indexed local array would live in scratch
-    auto pick = [](const T* v, int k, int o) {
-        return k == 0 ? v[o] : (k == 1 ? v[2 + o] : (k == 2 ? v[4 + o] : v[6 + o]));
-    };
-#pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        const T cx = (k >= 2) ? size : T(0), cy = (k == 1 || k == 2) ? size : T(0);
-        T u[3], d[3], ru[3], t[3], X[3], Hpt[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            u[i] = mk[i] + Rm[3 * i] * cx + Rm[3 * i + 1] * cy - p[i];
-            d[i] = u[i] - RP[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            t[i] = R[i] * d[0] + R[3 + i] * d[1] + R[6 + i] * d[2];
-            ru[i] = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const T l0 = dc.R_IL[3 * i], l1 = dc.R_IL[3 * i + 1], l2 = dc.R_IL[3 * i + 2];
-            X[i] = l0 * t[0] + l1 * t[1] + l2 * t[2];
-            Hpt[3 * i + 0] = l1 * ru[2] - l2 * ru[1];
-            Hpt[3 * i + 1] = l2 * ru[0] - l0 * ru[2];
-            Hpt[3 * i + 2] = l0 * ru[1] - l1 * ru[0];
-        }
-        // refraction frame of the left camera: the triangulation's axis flip undone (vision.cpp:597-599)
-        const T XL[3] = { -X[0], -X[1], X[2] };
-        auto rows = [&](const T* Xr, const T* y, const T* Mx /* d Xr / d X, 3 x 3 */) {
-            // in front of the port and inside its field of view (in water the ray cannot lean further than
-            // asin(n_air / n_water); 0.9 of that limit): otherwise the corner contributes no rows
-            {
-                const T z = dot3(Xr, vc.nrm), zw = z - vc.d_air - vc.d_glass, a1 = vc.alpha0 * vc.alpha1;
-                const T l0 = Xr[0] - z * vc.nrm[0], l1 = Xr[1] - z * vc.nrm[1], l2 = Xr[2] - z * vc.nrm[2];
-                const T lim = T(0.9) * zw * a1;
-                if (!(zw > T(0)) || !((l0 * l0 + l1 * l1 + l2 * l2) * (T(1) - a1 * a1) < lim * lim)) return;
-            }
-            T uv[2], J[6];
-            refraction_project(vc, Xr, uv, J);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                T jx[3], hA[3], hB[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) jx[c] = J[3 * q] * Mx[c] + J[3 * q + 1] * Mx[3 + c] + J[3 * q + 2] * Mx[6 + c];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    hA[c] = jx[0] * Hpp[c] + jx[1] * Hpp[3 + c] + jx[2] * Hpp[6 + c];
-                    hB[c] = jx[0] * Hpt[c] + jx[1] * Hpt[3 + c] + jx[2] * Hpt[6 + c];
-                }
-                acc.add6(hA, hB, y[q] - uv[q], w_pix);
-            }
-        };
-        const T F[9] = { T(-1), T(0), T(0), T(0), T(-1), T(0), T(0), T(0), T(1) };
-        const T ylk[2] = { pick(ylv, k, 0), pick(ylv, k, 1) };
-        rows(XL, ylk, F);
-        if (yrv) {
-            const T yrk[2] = { pick(yrv, k, 0), pick(yrv, k, 1) };
-            const T dl[3] = { XL[0] - vc.P_LR[0], XL[1] - vc.P_LR[1], XL[2] - vc.P_LR[2] };
-            T XR[3], MR[9];
-            m3v(vc.R_RL_inv, dl, XR);                                           // X_L = R_RL X_R + P_LR  (vision.cpp:555-556)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { MR[3 * i] = -vc.R_RL_inv[3 * i]; MR[3 * i + 1] = -vc.R_RL_inv[3 * i + 1]; MR[3 * i + 2] = vc.R_RL_inv[3 * i + 2]; }
-            rows(XR, yrk, MR);
-        }
-    }
-}
-
-// correct() from corner pixels: all visible markers, 2 (left camera) or 4 (stereo) reprojection rows per corner.
-template <typename T, int N, int DIALECT, int COV>
-__global__ void __launch_bounds__(BLOCK)
-correct_pixels_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
-                      const T* __restrict__ right, T size, T r_pix, const unsigned char* __restrict__ skip,
-                      unsigned char* __restrict__ applied, DevConst<T> dc, VisConst<T> vc)
-{
-    using L = Lay<N>;
-    using RC = Rec<T, N>;
-    const int b = blockIdx.x * BLOCK + threadIdx.x;
-    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
-    const int bc = b < B ? b : 0;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
-    // One wave per SIMD: a load costs its whole latency where its value is first needed, and id -> map slot -> marker
-    // constants are two dependent lookups per marker.  So the marker map goes to LDS with the first loads (as in
-    // correct_kernel: every lane carries a piece, which is why dead lanes run along until the map is written), and the id
-    // and the 8 + 8 image coordinates of marker i + 1 are requested before marker i is folded.
-    // (114.9 -> 104-107 us at 65 536 filters x 14.7 markers, left camera.)
-    __shared__ MarkerLDS<T> tbl;
-    struct Meas { int id; T l[8], r[8]; };
-    auto fetch = [&](int i, Meas& m) {
-        const size_t o = (size_t)bc * M + i;
-        m.id = ids[o];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { m.l[j] = ld_meas(left + o * 8 + j); m.r[j] = right ? ld_meas(right + o * 8 + j) : T(0); }
-    };
-    Meas cur, nxt;
-    T pqr[L::NPQR];
-    {
-        MarkerTableRegs<T> treg;
-        treg.load(dc);
-        order_fence();
-        if (M > 0) fetch(0, cur);
-        order_fence();
-        load_chunks<T, N, 0, RC::CH_PQR>(rs, my_lane(), pqr);
-        order_fence();
-        treg.to_lds(tbl);
-        order_fence();
-    }
-    if (!live) { if (b < B) applied[b] = 0; return; }
-    int used = 0;
-    InfoAcc<T> acc;
-    acc.clear();
-    const T w_pix = T(1) / r_pix;
-#pragma unroll 1
-    for (int i = 0; i < M; ++i) {                     // the fold runs before the covariance is requested (see correct_corners_kernel)
-        fetch(i + 1 < M ? i + 1 : M - 1, nxt);              // always a fresh load (no conditional merge of the two records)
-        const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
-        const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
-        if (slot >= 0) {
-            T mk[7];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) mk[k] = tbl.mk[slot * MK_STRIDE + k];
-            pixel_info<T, N>(acc, pqr, dc, vc, mk, cur.l, right ? cur.r : nullptr, size, w_pix);
-            ++used;
-        }
-        cur = nxt;
-    }
-    if (used == 0) { applied[b] = 0; return; }
-    constexpr bool LEAN = sizeof(T) == 8;                // fp64: row-split passes, see correct_kernel
-    constexpr int RS = 9;
-    using Stash = LateStash<T, N, RS>;
-    using Hook = RowStore<T, N, AUX_DEFAULT>;
-    __shared__ T stash_mem[LEAN ? Stash::NVAL * BLOCK : 1];
-    InfoFactors<T> fac;
-    joint_factor<T>(acc, fac);
-    order_fence();
-    T P[RC::NCOVP];
-    T dx[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) dx[i] = T(0);
-    if constexpr (LEAN) {
-        const Stash stash{ stash_mem + threadIdx.x };
-        constexpr int E_END = cov_final_before_row<N>(RS);
-        constexpr int C_E = RC::CH_NOM + (E_END + RC::EPC - 1) / RC::EPC;
-        load_chunks<T, N, RC::CH_NOM, C_E, AUX_NT>(rs, my_lane(), P);
-        joint_apply_early<T, N, COV, RS, Hook>(P, dx, fac, Hook{ rs, my_lane(), P }, stash);
-        order_fence();
-        load_chunks<T, N, C_E, RC::NCH, AUX_NT>(rs, my_lane(), P + (C_E - RC::CH_NOM) * RC::EPC);
-        joint_apply_late<T, N, COV, RS>(P, dx, stash);
-    } else {
-        load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, my_lane(), P);
-        joint_apply<T, N, COV>(P, dx, fac);
-    }
-    T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, my_lane(), nom);
-    inject<T, N>(nom, dx);
-    store_chunks<T, N, 0, RC::CH_PQ>(rs, my_lane(), nom);
-    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, my_lane(), nom + L::NPQR);
-    constexpr int C_REST = LEAN ? Hook::fin(RS) : RC::CH_NOM;
-    store_chunks<T, N, C_REST, RC::NCH>(rs, my_lane(), P + (C_REST - RC::CH_NOM) * RC::EPC);
-    applied[b] = 1;
-}
+// (correct() from stereo corners / from corner pixels: csrc/ekf_meas.hpp.  The round-1..3 kernels that lived here -- fp32 fold, six
+// sequential rank-1 passes -- were removed in round 4.)
 
 // One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
 template <typename T>

@@ -41,17 +41,8 @@ void launch_frames_k(hipStream_t s, T* recs, int B, int F, const unsigned char* 
                      const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode, bool joseph,
                      const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
 
-template <typename T, int N, int D>
-void launch_corners_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right,
-                      int geometry, int mode, bool joseph, T size, const unsigned char* skip, unsigned char* applied,
-                      const DevConst<T>& dc, const VisConst<T>& vc);
-
-template <typename T, int N, int D>
-void launch_pixels_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, bool joseph, T size,
-                     T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc);
-
 // ---- team kernels (ekf_team.hpp): several waves per 64-filter tile, fp32 only -------------------------------------------
-// roles: waves per tile (predict 2..4, predict_n always 4, correct 2..4); policy as in launch_predict_k
+// roles: waves per tile (predict 2..4, predict_n always 4); policy as in launch_predict_k
 template <typename T, int N, int D>
 void launch_predict_team_k(hipStream_t s, T* recs, int B, int K, int roles, int policy, const T* accel, const T* gyro,
                            const T* dt, int dt_stride, const DevConst<T>& dc);
@@ -59,17 +50,6 @@ template <typename T, int N, int D>
 void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro,
                           const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode,
                           const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
-template <typename T, int N, int D>
-void launch_corners_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int geometry,
-                           int roles, T size, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc,
-                           const VisConst<T>& vc);
-template <typename T, int N, int D>
-void launch_pixels_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, T size,
-                          T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc);
-template <typename T, int N, int D>
-void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode, int roles,
-                           const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc);
-
 
 // ---- correct() from corner pixels, round-4 kernel (ekf_meas.hpp) ---------------------------------------------------------
 constexpr int MKC_STRIDE = 10;      // doubles per map slot: corner 0 in the world (3), marker x axis (3), y axis (3), pad

@@ -558,304 +558,9 @@ struct CorrectXch {
     float* pjj;                                                 // [21][64]
 };
 
-template <typename T, int N, int DIALECT, bool JOINT, int NR>
-__global__ void __launch_bounds__(64 * NR)
-correct_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ pos,
-                    const T* __restrict__ quat, const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied,
-                    DevConst<T> dc)
-{
-    using L = Lay<N>;
-    using RC = Rec<T, N>;
-    using PL = CorrectPlan<N, NR>;
-    using XC = CorrectXch<N, NR>;
-    constexpr int CN = RC::CH_NOM, NN = PL::NN, NP = N * (N + 1) / 2;
-    constexpr int NT = 64 * NR;
-    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned tile = blockIdx.x;
-    const int b = (int)(tile * 64u + lane);
-    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
-    const int bc = live ? b : (int)(tile * 64u);
-    const int* my_ids = ids + (size_t)bc * M;
-    const T* my_pos = pos + (size_t)bc * M * 3;
-    const T* my_quat = quat + (size_t)bc * M * 4;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
-
-    __shared__ MarkerLDS<T> tbl;
-    __shared__ u32x4 w_mem[XC::QW * 64];
-    __shared__ float part_mem[NR * XC::NPART * 64];
-    __shared__ float pjj_mem[21 * 64];
-    const XC xc{ w_mem + lane, part_mem + lane, pjj_mem + lane };
-
-    // ---- prologue: marker map -> LDS (all threads), this role's measurements, nominal state, covariance chunks -----------
-    {
-        constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(T) * FBUS_MAX_MARKERS * MK_STRIDE / 16;
-        constexpr int PI = (NI + NT - 1) / NT, PM = (NM + NT - 1) / NT;
-        const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
-        const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
-        u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
-        u32x4* dm = reinterpret_cast<u32x4*>(tbl.mk);
-        u32x4 vi[PI], vm[PM];
-#pragma unroll
-        for (int k = 0; k < PI; ++k) { const int i = threadIdx.x + k * NT; vi[k] = si[i < NI ? i : 0]; }
-#pragma unroll
-        for (int k = 0; k < PM; ++k) { const int i = threadIdx.x + k * NT; vm[k] = sm[i < NM ? i : 0]; }
-#pragma unroll
-        for (int k = 0; k < PI; ++k) { const int i = threadIdx.x + k * NT; if (i < NI) di[i] = vi[k]; }
-#pragma unroll
-        for (int k = 0; k < PM; ++k) { const int i = threadIdx.x + k * NT; if (i < NM) dm[i] = vm[k]; }
-    }
-    const int last = live ? M : 0;
-    // measurements this role folds: stacked mode -- markers role, role + NR, ...; the first one is fetched here, ahead of
-    // the record loads (vector loads return in issue order).  Reference mode: every role scans all M markers (below).
-    int id0 = -1;
-    T y0[7];
-#pragma unroll
-    for (int k2 = 0; k2 < 7; ++k2) y0[k2] = T(0);
-    if (JOINT) {
-        const int i = (int)role < M ? (int)role : 0;
-        if (M > 0) {
-            id0 = my_ids[i];
-#pragma unroll
-            for (int k2 = 0; k2 < 3; ++k2) y0[k2] = ld_meas(my_pos + 3 * i + k2);
-#pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) y0[3 + k2] = ld_meas(my_quat + 4 * i + k2);
-        }
-        if ((int)role >= last) id0 = -1;
-    }
-    T prev_raw = T(0);
-    if (!JOINT && DIALECT == DIALECT_CPP) prev_raw = recs[elem_index<T, N>(bc, L::OFF_PREV)];
-    // reference mode: nearest visible marker (C++: hysteresis to the previous one), every role the same scan
-    int min_id = -1, pv_id = -1;
-    T min_d = T(10), prev_d = T(0);
-    T min_y[7], pv_y[7];
-#pragma unroll
-    for (int k2 = 0; k2 < 7; ++k2) { min_y[k2] = T(0); pv_y[k2] = T(0); }
-    if (!JOINT) {
-        const int prev_id = (int)prev_raw;
-        for (int i = 0; i < last; ++i) {                       // MeasureUpdate.m:51-60 ; filter.cpp:639-664
-            const int id = my_ids[i];
-            T y[7];
-#pragma unroll
-            for (int k2 = 0; k2 < 3; ++k2) y[k2] = ld_meas(my_pos + 3 * i + k2);
-#pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) y[3 + k2] = ld_meas(my_quat + 4 * i + k2);
-            if (id < 0) continue;
-            const T dist = fb_sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-            if (dist < min_d) {
-                min_d = dist; min_id = id;
-#pragma unroll
-                for (int k2 = 0; k2 < 7; ++k2) min_y[k2] = y[k2];
-            }
-            if (DIALECT == DIALECT_CPP && id == prev_id) {
-                prev_d = dist; pv_id = id;
-#pragma unroll
-                for (int k2 = 0; k2 < 7; ++k2) pv_y[k2] = y[k2];
-            }
-        }
-    }
-    order_fence();
-    T nom[L::NNOM], P[RC::NCOVP];
-    load_chunks<T, N, 0, CN>(rs, lane, nom);
-    order_fence();
-    auto load_mine = [&](auto r_) {
-        constexpr int R = decltype(r_)::value;
-        static_for<0, PL::NCC>([&](auto cc_) {
-            constexpr int cc = decltype(cc_)::value;
-            if constexpr (PL::loads_chunk(R, cc)) load_chunks<T, N, CN + cc, CN + cc + 1, FBUS_X_CORRECT_LD>(rs, lane, P + 4 * cc);
-        });
-    };
-    if (role == 0) load_mine(std::integral_constant<int, 0>{});
-    else if (role == 1) load_mine(std::integral_constant<int, 1>{});
-    else if (NR > 2 && role == 2) load_mine(std::integral_constant<int, (NR > 2 ? 2 : 0)>{});
-    else if (NR > 3) load_mine(std::integral_constant<int, (NR > 3 ? 3 : 0)>{});
-    order_fence();
-    team_barrier();                                             // the marker map is in LDS
-
-    // ---- fold this role's markers (only p, q, R and the map are needed: the covariance is still on its way in) ----------
-    InfoAcc<T> acc;
-    PoseFold<T, N, DIALECT> fold;
-    fold.clear();
-    int used = 0, new_prev = -1;
-    MarkerCommon<T, N> mc;
-    mc.build(nom, dc);
-    auto fold_one = [&](int id, const T* y) {
-        const bool ok = id >= 0 && id <= FBUS_MAX_MARKER_ID;
-        const int slot = ok ? (int)tbl.id2slot[ok ? id : 0] : -1;
-        if (slot < 0) return;
-        T mk[MK_STRIDE];
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) mk[k2] = tbl.mk[slot * MK_STRIDE + k2];
-        fold.add(nom, dc, mc, mk, y, y + 3);
-        ++used;
-    };
-    if (JOINT) {
-        fold_one(id0, y0);
-        for (int i = (int)role + NR; i < last; i += NR) {
-            const int id = my_ids[i];
-            T y[7];
-#pragma unroll
-            for (int k2 = 0; k2 < 3; ++k2) y[k2] = ld_meas(my_pos + 3 * i + k2);
-#pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) y[3 + k2] = ld_meas(my_quat + 4 * i + k2);
-            fold_one(id, y);
-        }
-    } else {
-        if (min_id >= 0 && DIALECT == DIALECT_CPP && pv_id >= 0 && fb_abs(prev_d - min_d) < dc.switch_thres && prev_d != T(0)) {
-            min_id = pv_id;
-#pragma unroll
-            for (int k2 = 0; k2 < 7; ++k2) min_y[k2] = pv_y[k2];
-        }
-        fold_one(min_id, min_y);                                // filter.cpp:671-673: not in the map -> no update
-        if (used > 0 && DIALECT == DIALECT_CPP) new_prev = min_id;   // filter.cpp:675
-    }
-
-    // ---- exchange 1: this role's partial sums of the fold (stacked mode) and P_JJ ---------------------------------------------
-    if (JOINT) {
-#pragma unroll
-        for (int i = 0; i < PoseFold<T, N, DIALECT>::NVAL; ++i) xc.part[((int)role * XC::NPART + i) * 64] = fold.at(i);
-    }
-    auto put_pjj = [&](auto r_) {
-        constexpr int R = decltype(r_)::value;
-        static_for<0, 6>([&](auto k_) {
-            constexpr int k2 = decltype(k_)::value;
-            constexpr int i = jcol(k2);
-            if constexpr (i >= PL::row0(R) && i < PL::row0(R + 1)) {
-#pragma unroll
-                for (int c = k2; c < 6; ++c) xc.pjj[lidx(k2, c) * 64] = P[pidx<N>(i, jcol(c))];
-            }
-        });
-    };
-    if (role == 0) put_pjj(std::integral_constant<int, 0>{});
-    else if (role == 1) put_pjj(std::integral_constant<int, 1>{});
-    else if (NR > 2 && role == 2) put_pjj(std::integral_constant<int, (NR > 2 ? 2 : 0)>{});
-    else if (NR > 3) put_pjj(std::integral_constant<int, (NR > 3 ? 3 : 0)>{});
-    team_barrier();
-    if (JOINT) {
-        // every role sums the partials in role order: the same sums in every role, bit for bit
-        fold.clear();
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-#pragma unroll
-            for (int i = 0; i < PoseFold<T, N, DIALECT>::NVAL; ++i) fold.at(i) += xc.part[(r * XC::NPART + i) * 64];
-        }
-        used = (int)fold.cnt;
-    }
-    fold.finish(acc, nom, dc, mc);
-    T PJ[21];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) PJ[i] = xc.pjj[i * 64];
-
-    // ---- the 6 x 6 problem (every role, the same arithmetic) ---------------------------------------------------------------
-    T Z[36], gam[6];
-    info_gain<T>(acc, PJ, Z, gam);
-
-    // ---- rows of W = V Z, a-major into LDS ------------------------------------------------------------------------------
-    auto w_rows = [&](auto r_) {
-        constexpr int R = decltype(r_)::value;
-        constexpr int I0 = PL::row0(R), I1 = PL::row0(R + 1);
-        static_for<0, 6>([&](auto a_) {
-            constexpr int a = decltype(a_)::value;
-            T wa[NN];
-            if constexpr (PackedMath<T, N>::on) {
-#pragma unroll
-                for (int i = I0; i < I1; i += 2) {
-                    PairAcc<N> pa;
-#pragma unroll
-                    for (int k2 = 0; k2 < 6; ++k2) pa.add(P, Z[6 * k2 + a], jcol(k2), i);
-                    const f32x2 v = pa.get();
-                    wa[i] = v.x; wa[i + 1] = v.y;
-                }
-            } else {
-#pragma unroll
-                for (int i = I0; i < I1; ++i) {
-                    T s = T(0);
-#pragma unroll
-                    for (int k2 = 0; k2 < 6; ++k2) s += P[pidx<N>(i, jcol(k2))] * Z[6 * k2 + a];
-                    wa[i] = s;
-                }
-                if constexpr ((I1 & 1) != 0) wa[I1] = T(0);        // the padding row of an odd N
-            }
-            // cells of 8 bytes: a * NN + i is even for even i
-            float* wl = reinterpret_cast<float*>(xc.w);
-            constexpr int I1P = (I1 + 1) / 2 * 2;
-#pragma unroll
-            for (int i = I0; i < I1P; i += 2) {
-                const int e = a * NN + i;                          // float index in the lane's W: cell e / 4, slot e % 4
-                *reinterpret_cast<f32x2*>(wl + (e / 4) * 256 + (e % 4)) = f32x2{ wa[i], wa[i + 1] };
-            }
-        });
-    };
-    if (role == 0) w_rows(std::integral_constant<int, 0>{});
-    else if (role == 1) w_rows(std::integral_constant<int, 1>{});
-    else if (NR > 2 && role == 2) w_rows(std::integral_constant<int, (NR > 2 ? 2 : 0)>{});
-    else if (NR > 3) w_rows(std::integral_constant<int, (NR > 3 ? 3 : 0)>{});
-    team_barrier();
-
-    // ---- exchange 2: all of W, then P -= W W' on this role's chunks ---------------------------------------------------------
-    T Wt[XC::QW * 4];                                           // [a][i], i padded to NN
-#pragma unroll
-    for (int q = 0; q < XC::QW; ++q) {
-        const u32x4 v = xc.w[q * 64];
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Wt[4 * q + i] = e[i];
-    }
-    const bool go = live && used > 0;
-    auto update_store = [&](auto r_) {
-        constexpr int R = decltype(r_)::value;
-        constexpr int C0 = PL::ch0(R), C1 = PL::ch0(R + 1);
-        static_for<C0, C1>([&](auto cc_) {
-            constexpr int cc = decltype(cc_)::value;
-            static_for<0, 2>([&](auto h_) {
-                constexpr int e = 4 * cc + 2 * decltype(h_)::value;
-                if constexpr (e + 1 < NP && PackedMath<T, N>::on && cov_row<N>(e) == cov_row<N>(e + 1) && cov_col<N>(e + 1) == cov_col<N>(e) + 1 &&
-                              cov_col<N>(e) % 2 == 0) {
-                    constexpr int i = cov_row<N>(e), c = cov_col<N>(e);
-                    f32x2 v = f32x2{ P[e], P[e + 1] };
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) v -= Wt[a * NN + i] * f32x2{ Wt[a * NN + c], Wt[a * NN + c + 1] };
-                    P[e] = v.x; P[e + 1] = v.y;
-                } else {
-                    static_for<0, 2>([&](auto s_) {
-                        constexpr int e1 = e + decltype(s_)::value;
-                        if constexpr (e1 < NP) {
-                            constexpr int i = cov_row<N>(e1), c = cov_col<N>(e1);
-                            T v = P[e1];
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) v -= Wt[a * NN + i] * Wt[a * NN + c];
-                            P[e1] = v;
-                        }
-                    });
-                }
-            });
-        });
-        if constexpr (C1 == PL::NCC) {
-            if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
-        }
-        if (go) store_chunks<T, N, CN + C0, CN + C1, FBUS_X_CORRECT_ST>(rs, lane, P + 4 * C0);
-    };
-    if (role == 0) {
-        // role 0 also owns the state: dx = W gamma, injection (MeasureUpdate.m:89-98 ; filter.cpp:723-733)
-        T dx[NN];
-#pragma unroll
-        for (int i = 0; i < NN; ++i) {
-            T s = Wt[i] * gam[0];
-#pragma unroll
-            for (int a = 1; a < 6; ++a) s += Wt[a * NN + i] * gam[a];
-            dx[i] = s;
-        }
-        if (go) {
-            inject<T, N>(nom, dx);
-            store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
-            store_chunks<T, N, RC::CH_PQR, CN, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
-        }
-        if (b < B) applied[b] = go ? 1 : 0;
-        update_store(std::integral_constant<int, 0>{});
-    } else if (role == 1) update_store(std::integral_constant<int, 1>{});
-    else if (NR > 2 && role == 2) update_store(std::integral_constant<int, (NR > 2 ? 2 : 0)>{});
-    else if (NR > 3) update_store(std::integral_constant<int, (NR > 3 ? 3 : 0)>{});
-}
+// (correct_team_kernel -- the pose rows' one-shot update P - W W' divided over 2-4 waves per tile -- was removed in round 4: parity-green
+// since round 3 but slower than the one-wave kernel at every batch size (4096 filters 6.4 -> 7.6 us, 16 384: 7.2 -> 9.2, 32 768: 10.0 -> 17.9),
+// and never selected.  Its building blocks live on in frames_team_kernel below.)
 
 
 // =================================================================================
@@ -1289,163 +994,6 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
 }
 
 
-// =================================================================================
-// correct from stereo corners / from corner pixels (stacked mode): the markers of a filter divided among the roles
-// =================================================================================
-// correct_corners_kernel is bound by the triangulation (two refracted rays per camera and corner, vision.cpp:472-618) and the
-// 12 row folds of every marker: ~2600 VALU instructions per marker on ONE wave per tile, the 4 markers of BASELINE config 3 one
-// after the other on a quarter of the chip's SIMDs; correct_pixels_kernel likewise by the flat-port projections of its
-// reprojection rows (~550 instructions each, 4 or 8 per marker).  The markers are independent until their rows meet in the
-// 6 x 6 information matrix: role r folds markers r, r + NR, ...; roles 1.. leave their partial sums in LDS (PoseFold's 26
-// values, or the 27 of the information matrix and vector for the pixel rows) and are done; role 0 adds them in role order and
-// applies the update as the one-wave kernels do (joint_factor / joint_apply, the covariance requested behind the fold).
-// Same device functions; the sums of the fold are taken in a different order (fp32 rounding).  Stacked mode, simple
-// covariance form, fp32.
-template <typename T, int N, int NR, bool PIXELS>
-__global__ void __launch_bounds__(64 * NR)
-correct_meas_team_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
-                         const T* __restrict__ right, int geometry, T size, T r_pix, const unsigned char* __restrict__ skip,
-                         unsigned char* __restrict__ applied, DevConst<T> dc, VisConst<T> vc)
-{
-    using L = Lay<N>;
-    using RC = Rec<T, N>;
-    using Fold = PoseFold<T, N, DIALECT_MATLAB>;         // position-type rows only, as in correct_corners_kernel
-    constexpr int NT = 64 * NR, NPART = PIXELS ? 28 : Fold::NVAL;
-    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned tile = blockIdx.x;
-    const int b = (int)(tile * 64u + lane);
-    const bool live = b < B && !(skip && skip[b < B ? b : 0]);
-    const int bc = b < B ? b : (int)(tile * 64u);
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
-    __shared__ MarkerLDS<T> tbl;
-    __shared__ float part_mem[(NR - 1) * NPART * 64];
-    struct Meas { int id; T l[12], r[8]; };
-    const bool c3d = !PIXELS && geometry == VIS_CORNERS3D;
-    const int lw = c3d ? 12 : 8;
-    const bool has_right = PIXELS ? right != nullptr : !c3d;
-    auto fetch = [&](int i, Meas& m) __attribute__((always_inline)) {
-        const size_t o = (size_t)bc * M + i;
-        m.id = ids[o];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m.l[j] = ld_meas(left + o * lw + j);
-#pragma unroll
-        for (int j = 8; j < 12; ++j) m.l[j] = c3d ? ld_meas(left + o * lw + j) : T(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m.r[j] = has_right ? ld_meas(right + o * 8 + j) : T(0);
-    };
-    auto corner = [&](const Meas& m, int c, T* out) __attribute__((always_inline)) {
-        if (geometry == VIS_CORNERS3D) { out[0] = m.l[3 * c]; out[1] = m.l[3 * c + 1]; out[2] = m.l[3 * c + 2]; return; }
-        if (geometry == VIS_REFRACTIVE) refraction_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
-        else pinhole_corner(vc, m.l[2 * c], m.l[2 * c + 1], m.r[2 * c], m.r[2 * c + 1], out);
-    };
-    Meas cur, nxt;
-    T pqr[L::NPQR];
-    {
-        // the marker map -> LDS (all threads), this role's first marker, the pose part of the nominal state
-        constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(T) * FBUS_MAX_MARKERS * MK_STRIDE / 16;
-        constexpr int PI = (NI + NT - 1) / NT, PM = (NM + NT - 1) / NT;
-        const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
-        const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
-        u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
-        u32x4* dm = reinterpret_cast<u32x4*>(tbl.mk);
-        u32x4 vi[PI], vm[PM];
-#pragma unroll
-        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; vi[q] = si[i < NI ? i : 0]; }
-#pragma unroll
-        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; vm[q] = sm[i < NM ? i : 0]; }
-        order_fence();
-        if (M > 0) fetch((int)role < M ? (int)role : M - 1, cur);
-        order_fence();
-        load_chunks<T, N, 0, RC::CH_PQR>(rs, lane, pqr);
-        order_fence();
-#pragma unroll
-        for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; if (i < NI) di[i] = vi[q]; }
-#pragma unroll
-        for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; if (i < NM) dm[i] = vm[q]; }
-        order_fence();
-    }
-    team_barrier();                                              // the marker map is in LDS
-    Fold fold;
-    fold.clear();
-    InfoAcc<T> acc;
-    acc.clear();
-    T npix = T(0);                                               // markers folded into acc (pixel rows)
-    MarkerCommon<T, N> mc;
-    if constexpr (!PIXELS) mc.build(pqr, dc);
-    const T w_pix = PIXELS ? T(1) / r_pix : T(0);
-    const int last = live ? M : 0;
-#pragma unroll 1
-    for (int i = (int)role; i < last; i += NR) {
-        fetch(i + NR < M ? i + NR : M - 1, nxt);                // always a fresh load (no conditional merge of the two records)
-        const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
-        const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
-        if (slot >= 0) {
-            T mk[7];
-#pragma unroll
-            for (int q = 0; q < 7; ++q) mk[q] = tbl.mk[slot * MK_STRIDE + q];
-            if constexpr (PIXELS) {
-                pixel_info<T, N>(acc, pqr, dc, vc, mk, cur.l, right ? cur.r : nullptr, size, w_pix);
-                npix += T(1);
-            } else {
-                T C[12];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) corner(cur, c, C + 3 * c);
-                fold.add_corners(pqr, dc, mc, mk, C, size);
-            }
-        }
-        cur = nxt;
-    }
-    // partial sums through LDS: value i of role r at part_mem[((r - 1) * NPART + i) * 64 + lane]
-    if (role != 0) {
-        float* part = part_mem + ((role - 1) * NPART) * 64 + lane;
-        if constexpr (PIXELS) {
-#pragma unroll
-            for (int i = 0; i < 21; ++i) part[i * 64] = acc.Lam[i];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) part[(21 + i) * 64] = acc.b[i];
-            part[27 * 64] = npix;
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPART; ++i) part[i * 64] = fold.at(i);
-        }
-        team_barrier();
-        return;
-    }
-    team_barrier();                                              // the other roles' partial sums are in LDS
-#pragma unroll
-    for (int r = 1; r < NR; ++r) {
-        const float* part = part_mem + ((r - 1) * NPART) * 64 + lane;
-        if constexpr (PIXELS) {
-#pragma unroll
-            for (int i = 0; i < 21; ++i) acc.Lam[i] += part[i * 64];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc.b[i] += part[(21 + i) * 64];
-            npix += part[27 * 64];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPART; ++i) fold.at(i) += part[i * 64];
-        }
-    }
-    const int used = PIXELS ? (int)npix : (int)fold.cnt;         // (add_corners counts 4 points per marker)
-    if (!live || used == 0) { if (b < B) applied[b] = 0; return; }
-    InfoFactors<T> fac;
-    if constexpr (!PIXELS) fold.finish(acc, pqr, dc, mc);
-    joint_factor<T>(acc, fac);
-    order_fence();
-    T P[RC::NCOVP];
-    T dx[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) dx[i] = T(0);
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
-    joint_apply<T, N, COV_SIMPLE>(P, dx, fac);
-    T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
-    inject<T, N>(nom, dx);
-    store_chunks<T, N, 0, RC::CH_PQ>(rs, lane, nom);
-    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM>(rs, lane, nom + L::NPQR);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH>(rs, lane, P);
-    applied[b] = 1;
-}
+// (correct from stereo corners / from corner pixels with the markers divided among the roles: csrc/ekf_meas.hpp since round 4.)
 
 }  // namespace

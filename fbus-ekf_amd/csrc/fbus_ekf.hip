@@ -145,7 +145,6 @@ struct fbus_ekf {
     void* d_mk = nullptr;
     double* d_mkc = nullptr;            // HostConst::mkc on the device
     short* d_id2slot = nullptr;
-    bool pixels_legacy = false;         // FBUS_PIXELS_LEGACY=1 (A/B runs): the round-3 fp32 pixel-row kernels instead of ekf_meas.hpp
     unsigned char* d_applied = nullptr;
     void* d_ema_carry = nullptr;        // B x 6, previous EMA-filtered IMU sample
     bool ema_has_carry = false;
@@ -280,18 +279,9 @@ int team_roles_predict(const fbus_ekf* h, int K)
     if (K > 1) return tiles <= half_chip(h) ? 4 : 1;
     return tiles <= quarter_chip(h) ? 3 : 1;
 }
-// correct from stereo corners (stacked mode) / from corner pixels (correct_meas_team_kernel: the markers of a filter divided among the
-// roles; these kernels are bound by the VALU work per marker -- ~2600 instructions of triangulation and row folds, 4 or 8 flat-port
-// projections).  fbus_ekf_set_team's correct_roles: 1 = never,
-// 2 = two roles, 3..4 = four; 0 = four up to 256 tiles, two up to 512 (measured: profiles/logs/r03_team_corners.txt).
-int team_roles_corners(const fbus_ekf* h, int mode, int M)
-{
-    if (h->dtype != 32 || h->prm.cov_form == FBUS_COV_JOSEPH || mode != MODE_STACKED || M < 2 || h->team_correct == 1) return 1;
-    if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
-    const int tiles = policy_tiles(h);
-    return tiles <= quarter_chip(h) ? 4 : (tiles <= half_chip(h) ? 2 : 1);
-}
-// round-4 pixel-row kernel (correct_pixels2_kernel): roles divide the markers; both record types
+// correct from stereo corners (stacked mode) / from corner pixels (ekf_meas.hpp: the markers of a filter divided among the roles; these
+// kernels are bound by the VALU work per marker).  fbus_ekf_set_team's correct_roles: 1 = never, 2 = two roles, 3..4 = four;
+// 0 = four up to a quarter of the chip, two up to half.  Both record types.
 int team_roles_pixels(const fbus_ekf* h, int M)
 {
     if (M < 2 || h->team_correct == 1) return 1;
@@ -311,13 +301,6 @@ bool team_frames(const fbus_ekf* h, int mode)
     if (h->team_frame == 2 || h->team_predict >= 2) return true;
     return policy_tiles(h) <= half_chip(h);
 }
-int team_roles_correct(const fbus_ekf* h, int mode)
-{
-    if (h->dtype != 32 || h->team_correct <= 1 || h->prm.cov_form == FBUS_COV_JOSEPH) return 1;
-    if (mode != MODE_NEAREST && mode != MODE_STACKED) return 1;
-    return h->team_correct > 4 ? 4 : h->team_correct;
-}
-
 // (round 4, measured and NOT kept: a batch of more than one wave per SIMD as launches of one round each.  The per-call kernels run
 // 65 536 filters -- 52 MB of records, exactly one wave per SIMD -- at 7.7 TB/s because the records stay cache-resident from launch
 // to launch; two such launches over the two halves of 131 072 filters do NOT run at twice 12.2 us (29.1 us against 28.0 us for the
@@ -370,14 +353,7 @@ int launch_correct_t(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, c
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT);
     h->records_warm = h->warm_after_correct;   // false: written through (sc1), the next predict streams them like any other
-    const int roles = team_roles_correct(h, mode);
-    if constexpr (sizeof(T) == 4) {
-        if (roles > 1)
-            launch_correct_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
-                                           roles, (const unsigned char*)skip, h->d_applied, make_dc<T>(h));
-    }
-    if (roles <= 1 || sizeof(T) != 4)
-        launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
+    launch_correct_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)pos, (const T*)quat, mode,
                                   h->prm.cov_form == FBUS_COV_JOSEPH, (const unsigned char*)skip, h->d_applied, make_dc<T>(h), h->lp);
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
@@ -645,29 +621,12 @@ int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void
                              int mode, const uint8_t* skip)
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
-    h->records_warm = true;
-    if (!h->pixels_legacy) {
-        // round 4: triangulation and fold in double, non-cancelling update (ekf_meas.hpp), as the pixel rows
-        h->records_warm = h->warm_after_correct;
-        const int roles = mode == MODE_STACKED ? team_roles_pixels(h, M) : 1;
-        launch_corners2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
-                                   roles, h->prm.marker_size, h->prm.r_pos, h->prm.switch_thres, (const unsigned char*)skip,
-                                   h->d_applied, h->d_id2slot, make_mc(h), make_vc<double>(h), make_vc<T>(h));
-        timing_end(h, ev);
-        HIP_TRY(h, hipGetLastError());
-        return FBUS_OK;
-    }
-    const int roles = team_roles_corners(h, mode, M);
-    if constexpr (sizeof(T) == 4) {
-        if (roles > 1)
-            launch_corners_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry,
-                                           roles, (T)h->prm.marker_size, (const unsigned char*)skip, h->d_applied, make_dc<T>(h),
-                                           make_vc<T>(h));
-    }
-    if (roles <= 1 || sizeof(T) != 4)
-    launch_corners_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry,
-                              mode, h->prm.cov_form == FBUS_COV_JOSEPH, (T)h->prm.marker_size, (const unsigned char*)skip,
-                              h->d_applied, make_dc<T>(h), make_vc<T>(h));
+    // triangulation and fold in double, non-cancelling update (ekf_meas.hpp); records written through (sc1) as correct_kernel's
+    h->records_warm = h->warm_after_correct;
+    const int roles = mode == MODE_STACKED ? team_roles_pixels(h, M) : 1;
+    launch_corners2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode,
+                               roles, h->prm.marker_size, h->prm.r_pos, h->prm.switch_thres, (const unsigned char*)skip,
+                               h->d_applied, h->d_id2slot, make_mc(h), make_vc<double>(h), make_vc<T>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -677,30 +636,12 @@ template <typename T, int N, int D>
 int launch_correct_pixels_t(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, const uint8_t* skip)
 {
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
-    h->records_warm = true;
-    if (!h->pixels_legacy) {
-        h->records_warm = h->warm_after_correct;      // written through (sc1), as correct_kernel's records
-        // round 4: double-precision fold + non-cancelling update (ekf_meas.hpp), both record types, either covariance form
-        // (the form is symmetric by construction and subtracts nothing on the rows the measurement shrinks: what Joseph's
-        // form is chosen for)
-        const int roles = team_roles_pixels(h, M);
-        launch_pixels2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, roles,
-                                  h->prm.marker_size, h->prm.r_pix, (const unsigned char*)skip, h->d_applied, h->d_id2slot, make_mc(h));
-        timing_end(h, ev);
-        HIP_TRY(h, hipGetLastError());
-        return FBUS_OK;
-    }
-    const int roles = team_roles_corners(h, MODE_STACKED, M);          // the pixel form is always stacked
-    if constexpr (sizeof(T) == 4) {
-        if (roles > 1)
-            launch_pixels_team_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, roles,
-                                          (T)h->prm.marker_size, (T)h->prm.r_pix, (const unsigned char*)skip, h->d_applied,
-                                          make_dc<T>(h), make_vc<T>(h));
-    }
-    if (roles <= 1 || sizeof(T) != 4)
-    launch_pixels_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right,
-                             h->prm.cov_form == FBUS_COV_JOSEPH, (T)h->prm.marker_size, (T)h->prm.r_pix,
-                             (const unsigned char*)skip, h->d_applied, make_dc<T>(h), make_vc<T>(h));
+    // double-precision fold + non-cancelling update (ekf_meas.hpp), both record types, either covariance form (the form is
+    // symmetric by construction and subtracts nothing on the rows the measurement shrinks: what Joseph's form is chosen for)
+    h->records_warm = h->warm_after_correct;          // written through (sc1), as correct_kernel's records
+    const int roles = team_roles_pixels(h, M);
+    launch_pixels2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, roles,
+                              h->prm.marker_size, h->prm.r_pix, (const unsigned char*)skip, h->d_applied, h->d_id2slot, make_mc(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -896,7 +837,6 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
     if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
     if (const char* e = std::getenv("FBUS_TEAM_FRAME")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->team_frame = v; }
-    if (const char* e = std::getenv("FBUS_PIXELS_LEGACY")) h->pixels_legacy = std::atoi(e) != 0;
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
     h->device = device;

@@ -3,10 +3,10 @@
 //   1 predict (per-call streamed kernel, both record-load policies, and predict_n)
 //   2 correct (nearest / stacked x simple / Joseph)
 //   3 fused frame (K predicts + correct in one launch)
-//   4 correct from stereo corners
+//   4 (removed in round 4: the fp32-fold corner / pixel kernels; see 7)
 //   5 frame window (F frames per launch)
-//   6 team kernels (several waves per tile: predict, predict_n, correct; fp32 only)
-//   7 correct from corner pixels, round-4 kernel (ekf_meas.hpp: double-precision fold, non-cancelling update)
+//   6 team kernels (several waves per tile: predict, predict_n, frame window; fp32 only)
+//   7 correct from corner pixels / from stereo corners (ekf_meas.hpp: double-precision fold, non-cancelling update)
 // gfx950 only.
 #include <cstdlib>
 #include "ekf_kernels.hpp"
@@ -126,41 +126,6 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
                                                           const unsigned char*, unsigned char*,                       \
                                                           const DevConst<FBUS_TU_T>&, const LaunchPolicy&);
 
-#elif FBUS_TU_FAMILY == 4
-template <typename T, int N, int D>
-void launch_corners_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right,
-                      int geometry, int mode, bool joseph, T size, const unsigned char* skip, unsigned char* applied,
-                      const DevConst<T>& dc, const VisConst<T>& vc)
-{
-    const int grid = (B + BLOCK - 1) / BLOCK;
-    if (joseph)
-        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
-                           left, right, geometry, mode, size, skip, applied, dc, vc);
-    else
-        hipLaunchKernelGGL((correct_corners_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
-                           left, right, geometry, mode, size, skip, applied, dc, vc);
-}
-template <typename T, int N, int D>
-void launch_pixels_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, bool joseph, T size,
-                     T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc)
-{
-    const int grid = (B + BLOCK - 1) / BLOCK;
-    if (joseph)
-        hipLaunchKernelGGL((correct_pixels_kernel<T, N, D, COV_JOSEPH>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, left,
-                           right, size, r_pix, skip, applied, dc, vc);
-    else
-        hipLaunchKernelGGL((correct_pixels_kernel<T, N, D, COV_SIMPLE>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids, left,
-                           right, size, r_pix, skip, applied, dc, vc);
-}
-#define FBUS_INST(D)                                                                                                  \
-    template void launch_corners_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,            \
-                                                            const FBUS_TU_T*, const FBUS_TU_T*, int, int, bool,       \
-                                                            FBUS_TU_T, const unsigned char*, unsigned char*,          \
-                                                            const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&);  \
-    template void launch_pixels_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,             \
-                                                           const FBUS_TU_T*, const FBUS_TU_T*, bool, FBUS_TU_T,       \
-                                                           FBUS_TU_T, const unsigned char*, unsigned char*,           \
-                                                           const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&);
 #elif FBUS_TU_FAMILY == 5
 template <typename T, int N, int D>
 void launch_frames_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro,
@@ -214,20 +179,6 @@ void launch_predict_team_k(hipStream_t s, T* recs, int B, int K, int roles, int 
 #undef FBUS_LAUNCH_PT
 }
 template <typename T, int N, int D>
-void launch_correct_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* pos, const T* quat, int mode, int roles,
-                           const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
-{
-    const int tiles = (B + 63) / 64;
-    const bool joint = mode == MODE_STACKED;
-#define FBUS_LAUNCH_CT(JOINT, NR)                                                                                          \
-    hipLaunchKernelGGL((correct_team_kernel<T, N, D, JOINT, NR>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, pos, quat, \
-                       skip, applied, dc)
-    if (roles <= 2) { if (joint) FBUS_LAUNCH_CT(true, 2); else FBUS_LAUNCH_CT(false, 2); }
-    else if (roles == 3) { if (joint) FBUS_LAUNCH_CT(true, 3); else FBUS_LAUNCH_CT(false, 3); }
-    else { if (joint) FBUS_LAUNCH_CT(true, 4); else FBUS_LAUNCH_CT(false, 4); }
-#undef FBUS_LAUNCH_CT
-}
-template <typename T, int N, int D>
 void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro,
                           const T* dt, int dt_stride, int M, const int* ids, const T* pos, const T* quat, int mode,
                           const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc)
@@ -250,40 +201,7 @@ void launch_frames_team_k(hipStream_t s, T* recs, int B, int F, const unsigned c
     hipLaunchKernelGGL((frames_team_kernel<T, N, D>), dim3(tiles), dim3(256), lds, s, recs, B, F, kc, accel, gyro, dt, dt_stride, M,
                        ids, pos, quat, mode, skip, applied, dc);
 }
-template <typename T, int N, int D>
-void launch_corners_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int geometry,
-                           int roles, T size, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc,
-                           const VisConst<T>& vc)
-{
-    const int tiles = (B + 63) / 64;
-    if (roles >= 3)
-        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 4, false>), dim3(tiles), dim3(256), 0, s, recs, B, M, ids, left, right,
-                           geometry, size, T(0), skip, applied, dc, vc);
-    else
-        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 2, false>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right,
-                           geometry, size, T(0), skip, applied, dc, vc);
-}
-template <typename T, int N, int D>
-void launch_pixels_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, T size,
-                          T r_pix, const unsigned char* skip, unsigned char* applied, const DevConst<T>& dc, const VisConst<T>& vc)
-{
-    const int tiles = (B + 63) / 64;
-    if (roles >= 3)
-        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 4, true>), dim3(tiles), dim3(256), 0, s, recs, B, M, ids, left, right, 0,
-                           size, r_pix, skip, applied, dc, vc);
-    else
-        hipLaunchKernelGGL((correct_meas_team_kernel<T, N, 2, true>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right, 0,
-                           size, r_pix, skip, applied, dc, vc);
-}
 #define FBUS_INST(D)                                                                                                   \
-    template void launch_corners_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,        \
-                                                                 const FBUS_TU_T*, const FBUS_TU_T*, int, int, FBUS_TU_T, \
-                                                                 const unsigned char*, unsigned char*,                 \
-                                                                 const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&); \
-    template void launch_pixels_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,         \
-                                                                const FBUS_TU_T*, const FBUS_TU_T*, int, FBUS_TU_T, FBUS_TU_T, \
-                                                                const unsigned char*, unsigned char*,                  \
-                                                                const DevConst<FBUS_TU_T>&, const VisConst<FBUS_TU_T>&); \
     template void launch_frames_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const unsigned char*, \
                                                                 const FBUS_TU_T*, const FBUS_TU_T*, const FBUS_TU_T*, int, \
                                                                 int, const int*, const FBUS_TU_T*, const FBUS_TU_T*, int, \
@@ -291,10 +209,6 @@ void launch_pixels_team_k(hipStream_t s, T* recs, int B, int M, const int* ids, 
                                                                 const DevConst<FBUS_TU_T>&);                           \
     template void launch_predict_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, int, int, const FBUS_TU_T*, \
                                                                  const FBUS_TU_T*, const FBUS_TU_T*, int,              \
-                                                                 const DevConst<FBUS_TU_T>&);                          \
-    template void launch_correct_team_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*,        \
-                                                                 const FBUS_TU_T*, const FBUS_TU_T*, int, int,         \
-                                                                 const unsigned char*, unsigned char*,                 \
                                                                  const DevConst<FBUS_TU_T>&);
 #elif FBUS_TU_FAMILY == 7
 template <typename T, int N, int D>
@@ -334,7 +248,7 @@ void launch_corners2_k(hipStream_t s, T* recs, int B, int M, const int* ids, con
                                                              const unsigned char*, unsigned char*, const short*,       \
                                                              const MeasConst&, const VisConst<double>&, const VisConst<FBUS_TU_T>&);
 #else
-#error "FBUS_TU_FAMILY must be 1..7"
+#error "FBUS_TU_FAMILY must be 1, 2, 3, 5, 6 or 7"
 #endif
 
 FBUS_INST(DIALECT_MATLAB)

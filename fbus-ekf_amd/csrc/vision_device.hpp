@@ -106,95 +106,8 @@ __device__ __forceinline__ void refraction_corner(const VisConst<T>& vc, T xl, T
     }
 }
 
-// Forward flat-port projection with its Jacobian (north-star extension; the reference only back-projects).
-// Xp: point in a camera's refraction frame (the frame of the rays of vision.cpp:496-552).  The ray to it stays in the
-// plane of the port normal and the point, so t = tan(theta_air) solves one monotone scalar equation
-//     rho = L(t) = d_air t + d_glass tan(theta_glass) + (z - d_air - d_glass) tan(theta_water)          (Snell twice)
-// (z = depth along the normal, rho = distance from the axis).  L is increasing and concave in t, so Newton from the
-// paraxial start t0 = rho / (d_air + a0 d_glass + a1 (z - d_air - d_glass)) <= t* climbs monotonically to the root and
-// converges quadratically; the loop leaves when no lane of the wave moved by more than a relative NEWTON_TOL (a step
-// that small leaves an error of its square), which takes 2-3 steps inside a camera's field of view and is capped at
-// NEWTON_MAX towards the 0.9-of-critical-angle rim that pixel_info admits.  One more evaluation at the root gives
-// dL/dt and tan(theta_water) for the Jacobian.
-// uv = normalised image point, J = d uv / d Xp (2 x 3, row-major), in closed form by implicit differentiation.
-// fp32 evaluates L with v_rsq_f32 / v_rcp_f32 (1 ulp, a quarter-rate instruction each) instead of IEEE divisions and
-// square roots (10-15 instructions each): (1 + t^2)^-1/2, cos^-1 of the glass and water angles, and the cubes of
-// those for dL/dt.  This is what the pixel-row correct spends its time in (59-118 projections per filter).
-template <typename T> struct PortRay { T L, Lt, Lz; };
-
-__device__ __forceinline__ float fb_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double fb_rsq(double x) { return 1.0 / sqrt(x); }
-__device__ __forceinline__ float fb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double fb_rcp(double x) { return 1.0 / x; }
-
-template <typename T>
-__device__ __forceinline__ PortRay<T> port_ray(const VisConst<T>& vc, T a0, T a1, T zw, T t)
-{
-    const T r = fb_rsq(T(1) + t * t);                                // cos(theta_air)
-    const T s_ = t * r, dsdt = r * r * r;                            // sin(theta_air), d sin / d t
-    const T s2 = s_ * s_;
-    const T icg = fb_rsq(T(1) - a0 * a0 * s2), icw = fb_rsq(T(1) - a1 * a1 * s2);      // 1 / cos(theta_glass), 1 / cos(theta_water)
-    const T g = vc.d_glass * a0 * icg, w = zw * a1 * icw;
-    PortRay<T> o;
-    o.L = vc.d_air * t + s_ * (g + w);
-    o.Lt = vc.d_air + (g * icg * icg + w * icw * icw) * dsdt;
-    o.Lz = a1 * s_ * icw;                                            // tan(theta_water)
-    return o;
-}
-
-template <typename T>
-__device__ __forceinline__ void refraction_project(const VisConst<T>& vc, const T* Xp, T* uv, T* J)
-{
-    const T* n = vc.nrm;
-    const T a0 = vc.alpha0, a1 = vc.alpha0 * vc.alpha1;           // n_air / n_glass, n_air / n_water
-    const T z = dot3(Xp, n);
-    const T lat[3] = { Xp[0] - z * n[0], Xp[1] - z * n[1], Xp[2] - z * n[2] };
-    const T rho = fb_sqrt(dot3(lat, lat));
-    const T zw = z - vc.d_air - vc.d_glass;
-    T t = rho / (vc.d_air + a0 * vc.d_glass + a1 * zw);
-    constexpr int NEWTON_MAX = (sizeof(T) == 4) ? 7 : 10;
-    // A lane stops after a step of <= NEWTON_TOL t (quadratic convergence: what is left is its square, ~1e-7 t for the
-    // slowest lane in fp32, far less for the others).  3e-4 is round 2's bound, so a wave runs as many steps as it did then;
-    // the difference is that a lane now FREEZES once it has converged instead of following its slowest neighbour (tighter
-    // bounds were measured: 1e-4 costs correct_pixels 15 %, 2e-5 11 % on another box, for figures that only move inside
-    // their noise band -- tests/test_pixels_gpu.py).
-    constexpr T NEWTON_TOL = (sizeof(T) == 4) ? T(3e-4) : T(1e-8);
-    // Convergence is decided PER LANE: a lane that has converged keeps its t while the wave runs on for its slower
-    // lanes (the vote only ends the loop).  A filter's iteration count, and with it the last bits of its result, must not
-    // depend on which other filters share its wave -- the batch composition and the shard layout.
-    bool conv = false;
-#pragma unroll 1
-    for (int it = 0; it < NEWTON_MAX; ++it) {
-        const PortRay<T> f = port_ray(vc, a0, a1, zw, t);
-        const T dt = (rho - f.L) * fb_rcp(f.Lt);
-        const T tn = fmax(t + dt, T(0));
-        t = conv ? t : tn;
-        conv = conv || !(fb_abs(dt) > NEWTON_TOL * tn);
-        if (!__any(!conv)) break;
-    }
-    const PortRay<T> f = port_ray(vc, a0, a1, zw, t);
-    const T Lt = f.Lt, Lz = f.Lz;
-    const bool on_axis = !(rho > T(0));
-    const T irho = on_axis ? T(0) : T(1) / rho;
-    const T k = on_axis ? T(1) / Lt : t * irho;
-    const T e[3] = { lat[0] * irho, lat[1] * irho, lat[2] * irho };
-    const T D[3] = { n[0] + k * lat[0], n[1] + k * lat[1], n[2] + k * lat[2] };
-    const T iDz = T(1) / D[2];
-    uv[0] = D[0] * iDz; uv[1] = D[1] * iDz;
-    // dD/dX = e e' (1/Lt - k) - (Lz/Lt) e n' + k (I - n n')
-    const T c1 = T(1) / Lt - k, c2 = Lz / Lt;
-    T dD[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            dD[3 * i + j] = c1 * e[i] * e[j] - c2 * e[i] * n[j] + k * ((i == j ? T(1) : T(0)) - n[i] * n[j]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        J[j] = (dD[j] - uv[0] * dD[6 + j]) * iDz;
-        J[3 + j] = (dD[3 + j] - uv[1] * dD[6 + j]) * iDz;
-    }
-}
+// (The forward flat-port projection with its Jacobian -- the north-star extension the reference has no counterpart of -- lives in
+// ekf_meas.hpp since round 4: closed-form thin-port start + one Halley step in double.)
 
 // cyclic Jacobi on a symmetric NxN matrix held in registers (N = 3 or 4): A -> diag, V = eigenvectors (columns).
 template <typename T, int N>

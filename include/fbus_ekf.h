@@ -134,15 +134,17 @@ int fbus_ekf_destroy(fbus_ekf_t h);
  * below). */
 #define FBUS_STREAM_OWN ((void*)(intptr_t)-1)
 int fbus_ekf_set_stream(fbus_ekf_t h, void* hip_stream);
-/* Waves per 64-filter tile of predict / correct (fp32; no reference counterpart -- the reference runs one filter on one
- * thread, filter.cpp:190-250).  0 (default): chosen per launch from what was measured faster (predict: 3 waves per tile up to
- * 16 384 filters, predict_n: 4 up to 32 768, correct: always one; the fused frame / frame window entry points follow the
- * predict setting: four waves per tile up to 32 768 filters -- DESIGN.md section 4.5); 1: always one wave per tile;
- * 2..4: always that many ("team" kernels).  correct_roles also governs fbus_ekf_correct_corners (stacked mode) and fbus_ekf_correct_pixels,
- * whose markers are divided among the waves of a tile: 0 = four waves up to 16 384 filters, two up to 32 768; 1 = never; 2 = two; 3..4 = four.  Results agree to fp32 rounding whatever the choice (predict: the same arithmetic, 1 ulp on a few
- * covariance elements where the compiler fuses a different product; correct: the team kernel applies the stacked update in
- * one step, the one-wave kernel as six sequential rank-1 passes), so a caller that compares runs BIT FOR BIT across batch
- * sizes or shard layouts pins the value. */
+/* Waves per 64-filter tile ("team" kernels; no reference counterpart -- the reference runs one filter on one thread,
+ * filter.cpp:190-250).  predict_roles governs predict / predict_n and the fused frame / frame window entry points (fp32): 0 (default):
+ * chosen per launch from how much of the chip a one-wave launch would leave idle -- predict: 3 waves per tile up to a quarter of the
+ * chip's SIMDs in tiles (16 384 filters on MI355X), predict_n and the fused entry points: 4 up to half (32 768); 1: always one wave
+ * per tile; 2..4: always that many.  correct_roles governs fbus_ekf_correct_corners (stacked mode) and fbus_ekf_correct_pixels, whose
+ * markers are divided among the waves of a tile (both record types): 0 = four waves up to a quarter of the chip, two up to half;
+ * 1 = never; 2 = two; 3..4 = four.  The pose-row fbus_ekf_correct always runs one wave per tile (its team form was measured slower at
+ * every batch size and removed in round 4).  Results agree to fp32 rounding whatever the choice (predict: the same arithmetic, 1 ulp
+ * on a few covariance elements where the compiler fuses a different product; the folds: double-precision sums in a different
+ * order), so a caller that compares runs BIT FOR BIT across batch sizes pins the value -- or, for shards of one job, names the job's
+ * size with fbus_ekf_set_policy_batch. */
 int fbus_ekf_set_team(fbus_ekf_t h, int predict_roles, int correct_roles);
 /* (round 4) The batch the automatic kernel-FAMILY choice above is keyed on.  0 (default): this handle's own batch.  A job that is
  * cut into shards over several handles / GPUs (fbus::ShardedFilter, bench.py --total-batch) names the WHOLE job here, so that every

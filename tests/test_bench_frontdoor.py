@@ -106,7 +106,16 @@ def test_two_rank_rehearsal_weak_and_strong_scaling():
     one = _run_bench(["--batch", "4096"], _env())
     assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["config"]["ranks_seen"] == 1
     assert one["state_finite"] and one["roofline"]["frac"] > 0 and one["roofline"]["launches"] > 0
-    assert one["roofline"]["bytes_moved_per_launch"] == 1436 * 4096
+    # 4096 filters = 64 tiles: the per-call predict is the 3-role team kernel there, and the line says so instead of pricing it with
+    # the one-wave kernel's byte model (round-3 advisor finding)
+    pol = one["roofline"]["launch_policy"]
+    assert pol["roles_predict"] == (3 if 64 <= pol["simds"] // 4 else 1) and pol["policy_batch"] == 4096
+    if pol["roles_predict"] > 1:
+        assert "predict_team_kernel" in one["roofline"]["kernel"] and one["roofline"]["bytes_moved_per_launch"] is None
+        assert one["roofline"]["frac"] == one["roofline"]["frac_api"]
+    else:
+        assert one["roofline"]["bytes_moved_per_launch"] == 1436 * 4096
+    assert any(l.startswith("roofline_hbm_resident: --no-hbm-leg") for l in one["legs_skipped"])
     # the metric names the run's own batch; the gather of a single rank already goes through the library's RCCL entry point
     assert "batch=4096" in one["metric"] and one["gather_via"].startswith("fbus_ekf_gather") and one["gathered_bytes"] == 4096 * 800
     weak = _run_bench(["--gpus", "2", "--batch", "4096"], env)
@@ -114,10 +123,14 @@ def test_two_rank_rehearsal_weak_and_strong_scaling():
     assert weak["config"]["total_filters"] == 8192 and weak["config"]["batch_per_gpu"] == 4096
     assert weak["gathered_bytes"] == 2 * 4096 * 800 and weak["state_finite"]
     assert weak["config"]["collective_backend"] == "gloo" and weak["cpu_baseline"] is None
+    # an N > 1 line names the single-GPU side legs it does not carry
+    assert {l.split(":")[0] for l in weak["legs_skipped"]} >= {"roofline_hbm_resident", "fp64", "north_star_rows", "cpu_baseline"}
     strong = _run_bench(["--gpus", "2", "--total-batch", "8192"], env)
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["ranks_seen"] == 2
     assert strong["config"]["total_filters"] == 8192 and strong["config"]["batch_per_gpu"] == 4096
     assert strong["gathered_bytes"] == 8192 * 800 and strong["state_finite"]
+    # strong scaling keys the kernel-family choice on the whole job (fbus_ekf_set_policy_batch): the same kernels on every shard layout
+    assert strong["roofline"]["launch_policy"]["policy_batch"] == 8192
     # value counts the filters of ALL ranks
     assert strong["value"] == pytest.approx(8192 * 230 * 3 / (strong["ms_per_step"] * 3e-3), rel=1e-6)
 

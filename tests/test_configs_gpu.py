@@ -271,7 +271,10 @@ def test_config5_sixteen_slots_fp32_against_fp64():
             # line).  The maximum over all 65 536 filters of fp32 against fp64 after 7 fp32 PREDICTS + the 144-row update is what
             # the pose form's comment above describes -- the fp32 nominal state the update starts from, times the gain of 144
             # rows -- and gets the pose form's multipliers (3x / 5x; literal 2e-5: measured 1.1e-5, round 3: 1.4e-5 under a 5e-5 gate).
-            assert_parity([x[sub] for x in res[32][0]], eng.get_state(), 32, "config 5 corner rows, fp32 device vs oracle, one frame")
+            # (eight chained fp32 steps without re-seeding: literal 4.6e-6; the sigma-aware velocity figure reads 1.04e-5 -- the 144-row
+            # gain on the fp32 predicted state, see the pose form's comment -- and gets 2x)
+            assert_parity([x[sub] for x in res[32][0]], eng.get_state(), 32, "config 5 corner rows, fp32 device vs oracle, one frame",
+                          state_tol=2 * STATE_TOL)
             gates = ((0, "one frame", 3 * STATE_TOL, 5 * PLAIN_TOL, COV_BLOCK_TOL, 2e-5),
                      (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL, STATE_TOL))
         for i, name, st, pl, cb, lit in gates:

@@ -3,9 +3,9 @@
 predict / predict_n run the SAME device functions on the same operands as the one-wave kernels; the results are equal up to
 the compiler's FMA contraction, which picks a different product of an `a*b + c*d` to fuse in a few expressions of the
 differently specialised kernels (measured: 1 ulp on 5 of the 171 covariance elements of 17 of 311 filters, 1 ulp on single
-nominal components) -- asserted to ulp-level bounds.  correct applies the stacked update in one step (P - W W') instead of six sequential rank-1 passes: it goes
-through the parity gate against the fp64 oracle (tests/util.py) like every other kernel, and is compared with the
-one-wave kernel's posterior.  Reference operations: matlab/ImuUpdate.m:63-81, matlab/MeasureUpdate.m:71-102,
+nominal components) -- asserted to ulp-level bounds.  (The team form of the pose-row correct -- P - W W' in one step, divided over
+2-4 waves -- was removed in round 4: parity-green, slower than the one-wave kernel at every batch size, never selected.  Its
+one-shot update lives on inside the team frame-window kernel, tested below.)  Reference operations: matlab/ImuUpdate.m:63-81, matlab/MeasureUpdate.m:71-102,
 C++/src/filter.cpp:588-616,622-741."""
 import numpy as np
 import pytest
@@ -101,56 +101,6 @@ def test_team_predict_n_equals_one_wave_predict_n(dialect, n):
         assert e["literal"] < 2e-6 and e["cov_block"] < 2e-6, (K, e)   # resident vs streamed: same functions, fp32 rounding of reloads only
 
 
-@pytest.mark.parametrize("n", [18, 15])
-@pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("dialect", [0, 1])
-def test_team_correct_parity(dialect, mode, n):
-    """MeasureUpdate through 2, 3 and 4 roles: the parity gate against the oracle, the one-wave kernel's posterior, the applied
-    flags, prev_id; filters without a usable marker, with ids outside the map, skipped filters; M = 1, 4, 7, 16"""
-    B = 4 * 64 - 3
-    prm, nom, rot, P, prev = _batch(B, dialect, n, seed_off=5)
-    rng = np.random.default_rng(5)
-    for M in (1, 4, 7, 16):
-        ids, pos, quat = synth.marker_frame(5, 5 + B, 0, min(M, 12), nom, prm)
-        if M > 12:
-            pad = M - 12
-            ids = np.concatenate([ids, np.full((B, pad), -1, np.int32)], axis=1)
-            pos = np.concatenate([pos, np.zeros((B, pad, 3))], axis=1)
-            quat = np.concatenate([quat, np.tile([1.0, 0, 0, 0], (B, pad, 1))], axis=1)
-        pos = _r32(pos + rng.normal(0, 0.02, pos.shape))
-        quat = _r32(quat)
-        ids[0] = -1
-        ids[1] = 9
-        if M > 1:
-            ids[2, 1] = -1
-            ids[3, 0] = 9
-        prev_in = rng.choice([0, 1, 2, 16], B).astype(np.int32)
-        skip = np.zeros(B, np.uint8)
-        skip[7] = 1
-        eng = OracleEngine(B, dialect, n)
-        eng.set_state(nom, rot, P, prev_in)
-        eng.correct(ids, pos, quat, mode)
-        ref = [np.array(x) for x in eng.get_state()]
-        for x, x0 in zip(ref, (nom, rot, P, prev_in)):          # the oracle has no skip mask: a skipped filter keeps its state
-            x[7] = x0[7]
-        one = None
-        for roles in (1, 2, 3, 4):
-            with BatchedFilter(B, prm, nstate=n) as flt:
-                flt.set_team(1, roles)
-                flt.set_state(nom, rot, P, prev_in)
-                flt.correct(ids, pos, quat, mode, skip)
-                got = flt.get_state()
-                app = flt.applied()
-            assert_parity(got, ref, 32, f"correct {roles} roles mode {mode} dialect {dialect} N {n} M {M}")
-            if one is None:
-                one, app1 = got, app
-            else:
-                assert np.array_equal(app, app1)
-                e = parity_errors(got, one)
-                assert e["literal"] < 2e-6 and e["sigma"] < 5e-6 and e["cov_block"] < 5e-6 and e["prev_equal"], (roles, M, e)
-        assert app1[0] == 0 and app1[1] == 0 and app1[7] == 0 and app1[10] == 1
-
-
 def test_team_is_the_default_for_small_batches():
     """the launcher's choice: with the default setting a 4096-filter predict must give the team kernel's result (bit-equal to
     an explicit set_team; correct stays on the one-wave kernel) -- and the whole per-call frame (K predicts + correct) stays
@@ -187,9 +137,9 @@ def test_team_is_the_default_for_small_batches():
 
 @pytest.mark.parametrize("B", [4096, 16384, 32768, 65536])
 def test_team_kernels_parity_at_the_config_batch_sizes(B):
-    """the round-2 review's batch sizes: team predict (3 roles), team predict_n (K = 7, 4 roles) and team correct (stacked, 4 roles;
-    nearest, 3 roles) FORCED at 4096 / 16 384 / 32 768 / 65 536 filters, same gate and same oracle as every other kernel, on a
-    strided subset; and the whole batch against the one-wave kernels (every filter)"""
+    """the round-2 review's batch sizes: team predict (3 roles) and team predict_n (K = 7, 4 roles) FORCED at 4096 / 16 384 /
+    32 768 / 65 536 filters with the (one-wave) correct behind them, same gate and same oracle as every other kernel, on a strided
+    subset; and the whole batch against the one-wave kernels (every filter)"""
     dialect, n, M = 0, 18, 4
     prm, nom, rot, P, prev = _batch(B, dialect, n, seed_off=21)
     acc, gyr = synth.imu_samples(21, 21 + B, 0, 8, nom)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4: corner-row update -- launch times (new kernel vs FBUS_PIXELS_LEGACY=1) and the tests that gate it
+# round 4: corner-row update -- launch times and the tests that gate it (the round-3 kernels it replaced: profiles/r04_corners_times.txt)
 mkdir -p gpurun_out/r04
 {
-for leg in "" "FBUS_PIXELS_LEGACY=1"; do
+for leg in ""; do
   echo "== ${leg:-round-4 kernels}"
   env $leg python3 tools/run_pixels.py --corners 2>&1 | grep correct_
   env $leg python3 tools/run_pixels.py --corners --batch 16384 --slots 4 2>&1 | grep correct_

@@ -1,12 +1,12 @@
 #!/bin/bash
-# round 4: the reprojection-row update at 65 536 filters x 16 marker slots -- launch times (new kernel vs FBUS_PIXELS_LEGACY=1),
+# round 4: the reprojection-row update at 65 536 filters x 16 marker slots -- launch times (the round-3 kernel it replaced: profiles/r04_pixels_times.txt),
 # kernel trace and SQ counters (own passes: --pmc never together with other trace domains).  TAG=$1 names the output directory.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-a}
 export OUT=gpurun_out/r04/pix_$TAG
 mkdir -p $OUT
 python3 tools/run_pixels.py --both > $OUT/times.txt 2>&1
-FBUS_PIXELS_LEGACY=1 python3 tools/run_pixels.py --both >> $OUT/times.txt 2>&1
+
 python3 tools/run_pixels.py --both --batch 16384 --slots 4 >> $OUT/times.txt 2>&1
 python3 bench.py --only-pixels > $OUT/north_star_rows.json 2> $OUT/north_star_rows.err
 cat $OUT/times.txt
