@@ -193,6 +193,9 @@ __device__ __forceinline__ float fb_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double fb_sqrt(double x) { return sqrt(x); }
 // 1 / sqrt(x), x > 0.  fp32: the 1-ulp hardware estimate + one Newton step (4 instructions; sqrtf followed by an IEEE division is ~25),
 // fp64: the reference's own two operations.
+// v_rsq_f32 does not handle denormal inputs (the estimate of 0 < x < 1.18e-38 is +inf and the Newton step turns it into NaN): callers
+// that can see such an x -- the squared norm of a rate or of a rotation increment below 1.1e-19 -- test x >= FB_RSQRT_MIN, not x > 0
+constexpr float FB_RSQRT_MIN = 1.17549435e-38f;
 __device__ __forceinline__ float fb_rsqrt(float x) { const float r = __builtin_amdgcn_rsqf(x); return r * (1.5f - 0.5f * x * r * r); }
 __device__ __forceinline__ double fb_rsqrt(double x) { return 1.0 / sqrt(x); }
 // 1 / x.  fp32: hardware estimate + one Newton step (3 instructions instead of the ~10 of the IEEE sequence); fp64: a division.
@@ -564,7 +567,7 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
     // fp32: |w| and 1 / |w| from one reciprocal square root (|w| = |w|^2 / |w|); a rate of exactly zero gives 0, 0
     const T wn2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     T wn, iwn;
-    if constexpr (sizeof(T) == 4) { iwn = (wn2 > T(0)) ? fb_rsqrt(wn2) : T(0); wn = wn2 * iwn; }
+    if constexpr (sizeof(T) == 4) { iwn = (wn2 >= T(FB_RSQRT_MIN)) ? fb_rsqrt(wn2) : T(0); wn = wn2 * iwn; }
     else { wn = fb_sqrt(wn2); iwn = (wn > T(0)) ? T(1) / wn : T(0); }          // fp64: the reference's operations
 
 #pragma unroll
@@ -1415,7 +1418,7 @@ __device__ __forceinline__ void inject(T* rec /* the 28 nominal + rotation eleme
     }
     const T n2 = dx[6] * dx[6] + dx[7] * dx[7] + dx[8] * dx[8];
     T nn, inn;                                                     // |dtheta| and its reciprocal (fp32: one refined rsq, see predict_nominal)
-    if constexpr (sizeof(T) == 4) { inn = (n2 > T(0)) ? fb_rsqrt(n2) : T(0); nn = n2 * inn; }
+    if constexpr (sizeof(T) == 4) { inn = (n2 >= T(FB_RSQRT_MIN)) ? fb_rsqrt(n2) : T(0); nn = n2 * inn; }
     else { nn = fb_sqrt(n2); inn = (nn > T(0)) ? T(1) / nn : T(0); }
     T s, c;
     fb_sincos(nn * T(0.5), s, c);

@@ -1041,6 +1041,7 @@ struct Rccl {
     using UniqueId = struct { char internal[128]; };
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -1065,6 +1066,7 @@ Rccl& rccl()
         auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p && x.err.empty()) x.err = std::string("RCCL symbol missing: ") + n; return p; };
         x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
+        x.CommInitAll = (decltype(x.CommInitAll))sym("ncclCommInitAll");
         x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
         x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
         x.Broadcast = (decltype(x.Broadcast))sym("ncclBroadcast");
@@ -1109,6 +1111,56 @@ int fbus_ekf_comm_init(fbus_ekf_t h, const void* id128, int rank, int world)
     const int rc = r.CommInitRank(&comm, world, id, rank);         // binds to the current device = the handle's
     if (rc != 0) return rccl_fail(h, "ncclCommInitRank", rc);
     h->comm = comm; h->own_comm = true; h->comm_rank = rank; h->comm_world = world;
+    return FBUS_OK;
+}
+
+int fbus_ekf_comm_init_all(fbus_ekf_t* handles, int n)
+{
+    // one process, n handles on n DIFFERENT devices (fbus::NodeFilter): ncclCommInitAll, rank k = handles[k]
+    if (!handles || n < 1) return FBUS_ERR_INVALID;
+    for (int k = 0; k < n; ++k) {
+        if (!handles[k]) return FBUS_ERR_INVALID;
+        for (int j = 0; j < k; ++j)
+            if (handles[j]->device == handles[k]->device)
+                return fail(handles[k], FBUS_ERR_INVALID, "fbus_ekf_comm_init_all: two handles on one device (RCCL wants one rank per device)");
+    }
+    Rccl& r = rccl();
+    if (!r.ok) return fail(handles[0], FBUS_ERR_UNSUPPORTED, r.err);
+    std::vector<int> devs(n);
+    std::vector<void*> comms(n, nullptr);
+    for (int k = 0; k < n; ++k) { devs[k] = handles[k]->device; (void)fbus_ekf_comm_destroy(handles[k]); }
+    const int rc = r.CommInitAll(comms.data(), n, devs.data());
+    if (rc != 0) return rccl_fail(handles[0], "ncclCommInitAll", rc);
+    for (int k = 0; k < n; ++k) { handles[k]->comm = comms[k]; handles[k]->own_comm = true; handles[k]->comm_rank = k; handles[k]->comm_world = n; }
+    return FBUS_OK;
+}
+
+int fbus_ekf_gather_group(fbus_ekf_t* handles, int n, void* const* out_dev, const size_t* bytes_of_rank)
+{
+    // the gather of ALL ranks of one process in one RCCL group (a single thread may not issue the ranks' collectives one by one)
+    if (!handles || !out_dev || n < 1) return FBUS_ERR_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) return fail(handles[0], FBUS_ERR_UNSUPPORTED, r.err);
+    int rc = r.GroupStart();
+    int first = FBUS_OK;
+    for (int k = 0; k < n && rc == 0; ++k) {
+        const int e = fbus_ekf_gather(handles[k], out_dev[k], bytes_of_rank);
+        if (e != FBUS_OK && first == FBUS_OK) first = e;
+    }
+    const int rc2 = r.GroupEnd();
+    if (first != FBUS_OK) return first;
+    if (rc != 0 || rc2 != 0) return rccl_fail(handles[0], "ncclGroupStart / ncclGroupEnd", rc != 0 ? rc : rc2);
+    return FBUS_OK;
+}
+
+int fbus_ekf_copy_records(fbus_ekf_t h, void* dst, int dst_device)
+{
+    // this handle's packed records -> dst on dst_device (any device of the process), on the handle's stream: the gather of a
+    // single-process job whose consumer sits on ONE device (or whose shards share a device) without a communicator
+    DeviceGuard guard_(h);
+    if (!h || !dst || dst_device < 0) return FBUS_ERR_INVALID;
+    if (dst_device == h->device) HIP_TRY(h, hipMemcpyAsync(dst, h->recs, h->rec_bytes, hipMemcpyDeviceToDevice, h->stream));
+    else HIP_TRY(h, hipMemcpyPeerAsync(dst, dst_device, h->recs, h->device, h->rec_bytes, h->stream));
     return FBUS_OK;
 }
 

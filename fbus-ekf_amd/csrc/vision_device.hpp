@@ -54,7 +54,7 @@ __device__ __forceinline__ double vs_rsq(double x) { return 1.0 / sqrt(x); }    
 __device__ __forceinline__ float vs_sqrt(float x)
 {
     const float r = __builtin_amdgcn_rsqf(x), s_ = x * r;
-    return x > 0.0f ? s_ + 0.5f * r * (x - s_ * s_) : 0.0f;
+    return x >= 1.17549435e-38f ? s_ + 0.5f * r * (x - s_ * s_) : 0.0f;      // (v_rsq_f32 of a denormal is +inf: treated as 0)
 }
 __device__ __forceinline__ double vs_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float vs_div(float a, float x) { const float r = __builtin_amdgcn_rcpf(x); return a * (r * (2.0f - x * r)); }

@@ -110,6 +110,9 @@ def load_library():
         "fbus_ekf_comm_attach": ([H, vp, C.c_int, C.c_int], C.c_int),
         "fbus_ekf_comm_destroy": ([H], C.c_int),
         "fbus_ekf_gather": ([H, vp, C.POINTER(C.c_size_t)], C.c_int),
+        "fbus_ekf_comm_init_all": ([C.POINTER(H), C.c_int], C.c_int),
+        "fbus_ekf_gather_group": ([C.POINTER(H), C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)], C.c_int),
+        "fbus_ekf_copy_records": ([H, vp, C.c_int], C.c_int),
         "fbus_ekf_predict": ([H, vp, vp, vp, C.c_int], C.c_int),
         "fbus_ekf_predict_dev": ([H, vp, vp, vp, C.c_int], C.c_int),
         "fbus_ekf_predict_n": ([H, C.c_int, vp, vp, vp, C.c_int], C.c_int),

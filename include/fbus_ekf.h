@@ -204,6 +204,14 @@ int fbus_ekf_comm_init(fbus_ekf_t h, const void* id128, int rank, int world);
 int fbus_ekf_comm_attach(fbus_ekf_t h, void* nccl_comm, int rank, int world);
 int fbus_ekf_comm_destroy(fbus_ekf_t h);
 int fbus_ekf_gather(fbus_ekf_t h, void* out_dev, const size_t* bytes_of_rank);
+/* (round 4) ONE process that owns several devices (fbus::NodeFilter -- the closest thing to the reference's one stateful object,
+ * filter.cpp:190-250, owning a whole node).  comm_init_all: ncclCommInitAll over the handles' devices, rank k = handles[k] (one handle
+ * per device).  gather_group: the fbus_ekf_gather of all n ranks inside one RCCL group (out_dev[k] on handles[k]'s device).
+ * copy_records: this handle's packed records to a buffer on any device of the process, on the handle's stream (hipMemcpyPeerAsync) --
+ * the gather when the consumer sits on one device, or when the shards share a device; no communicator needed. */
+int fbus_ekf_comm_init_all(fbus_ekf_t* handles, int n);
+int fbus_ekf_gather_group(fbus_ekf_t* handles, int n, void* const* out_dev, const size_t* bytes_of_rank);
+int fbus_ekf_copy_records(fbus_ekf_t h, void* dst, int dst_device);
 /* Point the handle at caller-owned device storage of total_bytes (as reported
  * by fbus_ekf_records) so that a framework tensor can alias the records. */
 int fbus_ekf_attach_records(fbus_ekf_t h, void* dev_ptr, size_t total_bytes);

@@ -698,6 +698,16 @@ def test_long_run_stability_and_degenerate_inputs():
         s = flt.get_state()
         assert np.isfinite(s[0]).all() and np.isfinite(s[2]).all()
         assert np.abs(s[0][:, 6:10] - nom[:, 6:10]).max() < 1e-6           # identity rotation, not NaN
+        # ... and a rate whose SQUARE is an fp32 denormal (|w| between 4e-23 and 1.1e-19): v_rsq_f32 returns +inf for it and the
+        # Newton step behind it NaN -- the kernels test against the smallest normal number, not against 0 (round-3 advisor finding)
+        bias = nom[:, 13:16].astype(np.float32).astype(np.float64)
+        nz = nom.copy(); nz[:, 13:16] = 0.0
+        for w in (3e-20, 1e-21, 5e-23):
+            flt.set_state(nz, rot, P, prev)
+            flt.predict(acc[0], np.full((B, 3), w), DT)
+            s = flt.get_state()
+            assert np.isfinite(s[0]).all() and np.isfinite(s[2]).all(), w
+            assert np.abs(s[0][:, 6:10] - nz[:, 6:10]).max() < 1e-6
 
 
 def test_device_state_io_records_aliasing_and_checkpoint_resume():
