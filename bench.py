@@ -79,6 +79,9 @@ def parse():
                          "leg as the main workload: --batch 1048576 --tile 16)")
     ap.add_argument("--only-pixels", action="store_true", help="run only the compute-bound correct_pixels leg (profiling)")
     ap.add_argument("--markers", type=int, default=4)
+    ap.add_argument("--dtype", type=int, choices=[32, 64], default=32,
+                    help="record / arithmetic type of the MAIN workload (64: the reference's own arithmetic as the main line -- what "
+                         "tools/profile_gpu.sh profiles for the fp64 digests; the headline and the driver's run are 32)")
     ap.add_argument("--mode", choices=["stacked", "nearest"], default="stacked")
     ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,6 +146,21 @@ def pmc_traffic(batch, args, world, kernel="predict"):
         for name, v in d.items():
             if name.startswith(kernel + "_kernel<float, 18") and "fetch_bytes" in v:
                 return v["fetch_bytes"] + v["write_bytes"], os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
+def pmc_traffic_named(name, batch, args, kernel_prefix):
+    """as pmc_traffic, from a named digest under profiles/ (the fp64 legs)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        cfg = d.get("_config", {})
+        if (cfg.get("batch"), cfg.get("dialect"), cfg.get("markers"), cfg.get("mode")) != (batch, args.dialect, args.markers, args.mode):
+            return None, None
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and "fetch_bytes" in v:
+                return v["fetch_bytes"] + v["write_bytes"], os.path.join("profiles", name)
     except Exception:
         pass
     return None, None
@@ -408,11 +426,20 @@ def fp64_leg(torch, dev, local_rank, args, capi):
     pn_ms, pn_n = w.flt.timing_read(capi.KERNEL_PREDICT_N)
     c_ms, c_n = w.flt.timing_read(capi.KERNEL_CORRECT)
     w.flt.timing_enable(False)
-    roof, corr = roofline_block(w, p_ms, p_n, c_ms, c_n, None, None)
+    tr, src = pmc_traffic_named(f"r04_digest_f64_b{w.B}.json", w.B, args, "predict_kernel<double, 18")
+    roof, corr = roofline_block(w, p_ms, p_n, c_ms, c_n, tr, src)
     roof.pop("note")
+    # (round 4) the same frames as ONE launch each: frame2_kernel<double> -- the parked K-step predict loop + the row-split passes
+    # with the record resident in registers / LDS -- instead of K + 1 launches
+    w.reset_state()
+    elf = timed(torch, lambda i: w.step(i, fused=True), steps, warm, before_timing=lambda: w.flt._keep.clear())
     blk = {"value": w.B * STEPS_PER_BENCH_STEP * steps / el, "unit": "EKF steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
            "dtype": "f64", "batch": w.B, "records_MB": w.B * 1600 / 1e6, "roofline": roof, "correct_kernel": corr,
-           "note": "per-call API, fp64 kernels (the verification path: same device functions instantiated for double, 1600-byte records)"}
+           "fused_frame": {"value": w.B * STEPS_PER_BENCH_STEP * steps / elf, "unit": "EKF steps/s", "ms_per_step": elf / steps * 1e3,
+                           "vs_per_call": el / elf,
+                           "note": "one launch per camera frame (K predicts + correct resident: frame2_kernel<double>, 512 registers + 44 KiB of "
+                                   "LDS per wave, 132-188 bytes of scratch at N = 18); rounds 1-3 ran an fp64 frame as K + 1 launches"},
+           "note": "per-call API, fp64 kernels (the reference's own arithmetic: same device functions instantiated for double, 1600-byte records)"}
     w.flt.close()
     return blk
 
@@ -585,7 +612,7 @@ def main():
         emit(json.dumps({"north_star_rows": north_star_rows_leg(torch, dev, local_rank, args, capi)}))
         return
     w = Workload(torch, dev, local_rank, lo, hi, args, POOL if args.tile == 1 else 2, with_cov=(hi - lo) <= 131072 and args.tile == 1,
-                 tile=args.tile)
+                 tile=args.tile, dtype=args.dtype)
     flt = w.flt
     if strong:
         flt.set_policy_batch(args.total_batch)      # the same kernels whatever the shard layout (fbus_ekf_set_policy_batch)
@@ -675,7 +702,7 @@ def main():
             "value": value, "unit": "EKF steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.dtype == 32 else "f64", "data": "synthetic",
             "dtype_note": "f32 is the arithmetic BASELINE.json's north_star quotes the metric on; the reference itself computes in "
                           "double (common.hpp:205-247, filter.cpp:533-741) -- the same workload through the fp64 kernels is the "
                           "`fp64` block of this line",

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Builds fbus-ekf_amd/lib/libfbus_ekf.so (HIP, gfx950) in-tree with hipcc.
 
-The library is 19 translation units compiled in parallel and linked into one shared object:
+The library is 21 translation units compiled in parallel and linked into one shared object:
   fbus_ekf.hip                          handle, C ABI, the small kernels (pack/unpack, init, EMA, marker pose)
-  kernels_tu.hip x 18                   one kernel family (predict / correct / fused frame / frame window / team / corner + pixel rows) for one
+  kernels_tu.hip x 20                   one kernel family (predict / correct / fused frame / frame window / team / corner + pixel rows) for one
                                         (float|double, N = 18|15), both dialects: -DFBUS_TU_T/N/FAMILY
 Objects live in fbus-ekf_amd/lib/obj/ (git-ignored) and are rebuilt when a source they include is newer.
   python build.py [--force] [--only f32_18_correct,...] [--jobs N]
@@ -47,8 +47,8 @@ def units():
     for tn, t in TYPES.items():
         for n in (18, 15):
             for fam, code in FAMILIES.items():
-                if fam in ("frame", "frames", "team") and tn == "f64":
-                    continue                    # no fused fp64 kernels: fbus_ekf.hip runs predict_n + correct instead
+                if fam in ("frames", "team") and tn == "f64":
+                    continue                    # fp64: one fused frame kernel (family "frame": frame2_kernel), windows frame by frame
                 out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
                             [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"] +
                             # fp32 only: the fp64 kernels sit at the 512-register limit and spill more under max-ILP

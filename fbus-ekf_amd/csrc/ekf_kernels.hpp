@@ -451,8 +451,14 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
 // parking is pure overhead, 31.4 -> 32.4 us.  Parking rows p alone leaves 16-32 bytes of scratch, all 7 nominal chunks
 // cost 20 KiB of LDS for nothing (profiles/logs/r02_park.log).
 constexpr int PARK_NOM_CHUNKS = 4;
+// fp64 (round 4: the reference's own arithmetic as a resident K-step loop): 171 covariance doubles are 342 of a lane's 512 registers,
+// so ALL of the nominal state waits in LDS between its uses (14 chunks of two doubles)
+#ifndef FBUS_X_PARK_NOM_F64
+#define FBUS_X_PARK_NOM_F64 14
+#endif
+template <typename T> constexpr int park_nom_chunks() { return sizeof(T) == 8 ? FBUS_X_PARK_NOM_F64 : PARK_NOM_CHUNKS; }
 template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST, bool PARK = false>
-__global__ void __launch_bounds__(BLOCK, PARK ? 2 : 1)
+__global__ void __launch_bounds__(BLOCK, (PARK && sizeof(T) == 4) ? 2 : 1)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
                const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
 {
@@ -466,7 +472,7 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
         if constexpr (PARK) {
-            using Park = StepPark<T, N, PARK_NOM_CHUNKS>;
+            using Park = StepPark<T, N, park_nom_chunks<T>()>;
             __shared__ u32x4 park_mem[Park::NCHUNK * BLOCK];
             predict_steps<T, N, DIALECT, NoMidHook, Park>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd, NoMidHook(),
                                                           Park{ park_mem + threadIdx.x });
@@ -970,7 +976,7 @@ frames_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __res
 // Same device functions as K predict launches + one correct launch; per filter the order of operations is that of the
 // row-split correct_kernel.
 template <typename T, int N, int DIALECT>
-__global__ void __launch_bounds__(BLOCK, 2)
+__global__ void __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1)
 frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
               const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ pos,
               const T* __restrict__ quat, const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied,
@@ -979,13 +985,14 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
     using L = Lay<N>;
     using RC = Rec<T, N>;
     constexpr int RS = 9, EPC = RC::EPC, CN = RC::CH_NOM;
-    using Park = StepPark<T, N, PARK_NOM_CHUNKS>;
+    using Park = StepPark<T, N, park_nom_chunks<T>()>;
     using Stash = LateStash<T, N, RS>;
     using Hook = RowStore<T, N, AUX_DEFAULT>;
-    static_assert(Stash::NVAL * sizeof(T) <= Park::NCHUNK * 16, "the stash of the passes reuses the parking area");
+    // the stash of the passes reuses the parking area (fp32: 17 chunks hold both; fp64: the stash, 66 doubles, is the larger one)
+    constexpr int LDS_CH = Park::NCHUNK * 16 >= (int)(Stash::NVAL * sizeof(T)) ? Park::NCHUNK : (int)((Stash::NVAL * sizeof(T) + 15) / 16);
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     __shared__ MarkerLDS<T> tbl;
-    __shared__ u32x4 lds_mem[Park::NCHUNK * BLOCK];
+    __shared__ u32x4 lds_mem[LDS_CH * BLOCK];
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
     {

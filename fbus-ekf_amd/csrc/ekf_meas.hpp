@@ -669,16 +669,35 @@ __device__ __forceinline__ void info_solve(const double* Lam, const double* b, c
 //   P(a, c) -= x_a' Sinv x_c                  a <= c in r                     (the physical cancellation only)
 //   P(J, c)  = G x_c                          all c: a product, nothing is subtracted
 __host__ __device__ constexpr int rcol(int k) { return k < 3 ? 3 + k : 6 + k; }           // k-th state index outside J
-template <typename T, int N>
-__device__ __forceinline__ void direct_update(T* P, T* dx, const T* G, const T* Sinv, const T* m)
+// the 63 coefficients of the update (G 36, Sinv 21, m 6), in registers beside the resident covariance.  (fp64 records: 342 registers
+// of covariance leave too little, the kernels spill 650-780 bytes per lane; keeping the coefficients in LDS and loading the
+// covariance after the 6 x 6 stage were both tried in round 4 and changed nothing, see EXPERIMENTS.md)
+template <typename T>
+struct RegCoef {
+    T g[36], s[21], m_[6];
+    __device__ __forceinline__ T G(int i, int j) const { return g[6 * i + j]; }
+    __device__ __forceinline__ T S(int i, int j) const { return s[i <= j ? lidx(i, j) : lidx(j, i)]; }
+    __device__ __forceinline__ T m(int k) const { return m_[k]; }
+    __device__ __forceinline__ void set(const T* G_, const T* S_, const T* M_)
+    {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) g[i] = G_[i];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) s[i] = S_[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m_[i] = M_[i];
+    }
+};
+template <typename T, int N, typename COEF>
+__device__ __forceinline__ void direct_update(T* P, T* dx, const COEF& cf)
 {
 #define PS(i, j) P[pidx<N>((i), (j))]
     constexpr int NR_ = N - 6;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        T s = PS(i, jcol(0)) * m[0];
+        T s = PS(i, jcol(0)) * cf.m(0);
 #pragma unroll
-        for (int k = 1; k < 6; ++k) s += PS(i, jcol(k)) * m[k];
+        for (int k = 1; k < 6; ++k) s += PS(i, jcol(k)) * cf.m(k);
         dx[i] = s;
     }
     // the block outside J, column by column: t = Sinv x_c, then P(a, c) -= x_a . t for the columns a <= c (the x are still the old ones)
@@ -687,9 +706,9 @@ __device__ __forceinline__ void direct_update(T* P, T* dx, const T* G, const T* 
         T t[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            T s = Sinv[lidx(0, i)] * PS(jcol(0), rcol(c));
+            T s = cf.S(0, i) * PS(jcol(0), rcol(c));
 #pragma unroll
-            for (int j = 1; j < 6; ++j) s += Sinv[j <= i ? lidx(j, i) : lidx(i, j)] * PS(jcol(j), rcol(c));
+            for (int j = 1; j < 6; ++j) s += cf.S(j, i) * PS(jcol(j), rcol(c));
             t[i] = s;
         }
 #pragma unroll
@@ -707,9 +726,9 @@ __device__ __forceinline__ void direct_update(T* P, T* dx, const T* G, const T* 
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = i; j < 6; ++j) {
-                T s = G[6 * i] * PS(jcol(0), jcol(j));
+                T s = cf.G(i, 0) * PS(jcol(0), jcol(j));
 #pragma unroll
-                for (int k = 1; k < 6; ++k) s += G[6 * i + k] * PS(jcol(k), jcol(j));
+                for (int k = 1; k < 6; ++k) s += cf.G(i, k) * PS(jcol(k), jcol(j));
                 nj[lidx(i, j)] = s;
             }
 #pragma unroll
@@ -724,15 +743,53 @@ __device__ __forceinline__ void direct_update(T* P, T* dx, const T* G, const T* 
         for (int j = 0; j < 6; ++j) x[j] = PS(jcol(j), rcol(c));
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            T s = G[6 * i] * x[0];
+            T s = cf.G(i, 0) * x[0];
 #pragma unroll
-            for (int j = 1; j < 6; ++j) s += G[6 * i + j] * x[j];
+            for (int j = 1; j < 6; ++j) s += cf.G(i, j) * x[j];
             y[i] = s;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) PS(jcol(i), rcol(c)) = y[i];
     }
 #undef PS
+}
+
+// the tail both measurement kernels share: the sums -> information matrix -> 6 x 6 stage -> update -> injection -> stores
+template <typename T, int N>
+__device__ __forceinline__ void meas_update_tail(const __amdgpu_buffer_rsrc_t rs, unsigned lane, const PixAcc& acc, const double* Rd, double w,
+                                                 int new_prev)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    // the covariance is requested here: it arrives under the 6 x 6 stage
+    T P[RC::NCOVP];
+    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
+    double Lam[21], bv[6];
+    acc.finish(Rd, w, Lam, bv);
+    T dx[N];
+    {
+        T G[36], Sinv[21], m[6];
+        {
+            double PJJ[36];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
+            info_solve<T>(Lam, bv, PJJ, G, Sinv, m);
+        }
+        RegCoef<T> cf;
+        cf.set(G, Sinv, m);
+        direct_update<T, N>(P, dx, cf);
+    }
+    T nom[L::NNOM];
+    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
+    inject<T, N>(nom, dx);
+    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    // write-through (sc1) as correct_kernel: the lines reach the Infinity Cache at once instead of being written back from the L2s
+    // under the tail of the launch
+    store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
+    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
+    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);
 }
 
 // Marker map of the pixel fold in LDS: id -> slot (the table of the other kernels) and the double-precision corner frame of
@@ -856,30 +913,7 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         }
     }
     if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
-    // the covariance is requested here: it arrives under the 6 x 6 stage
-    T P[RC::NCOVP];
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
-    double Lam[21], bv[6];
-    acc.finish(Rd, 1.0 / r_pix, Lam, bv);
-    T G[36], Sinv[21], m[6];
-    {
-        double PJJ[36];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
-        info_solve<T>(Lam, bv, PJJ, G, Sinv, m);
-    }
-    T dx[N];
-    direct_update<T, N>(P, dx, G, Sinv, m);
-    T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
-    inject<T, N>(nom, dx);
-    // write-through (sc1) as correct_kernel: the lines reach the Infinity Cache at once instead of being written back from the L2s
-    // under the tail of the launch
-    store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
-    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);
+    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pix, -1);
     applied[b] = 1;
 }
 
@@ -1050,28 +1084,7 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
         }
     }
     if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
-    T P[RC::NCOVP];
-    load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
-    double Lam[21], bv[6];
-    acc.finish(Rd, 1.0 / r_pos, Lam, bv);
-    T G[36], Sinv[21], m[6];
-    {
-        double PJJ[36];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
-        info_solve<T>(Lam, bv, PJJ, G, Sinv, m);
-    }
-    T dx[N];
-    direct_update<T, N>(P, dx, G, Sinv, m);
-    T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
-    inject<T, N>(nom, dx);
-    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
-    store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
-    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);
+    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pos, new_prev);
     applied[b] = 1;
 }
 

@@ -390,15 +390,26 @@ template <typename T, int N, int D>
 int launch_frame_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter, int M,
                    const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
 {
-    if (sizeof(T) == 8 || (h->prm.cov_form == FBUS_COV_JOSEPH && mode != MODE_STACKED)) {
-        // fp64 is the verification path: there is no fused fp64 kernel (K predict steps and a correct step with the
-        // record resident need more than the 512 registers a lane has in fp64), and none for the Joseph form with the
-        // reference mode's 7 row-by-row updates (it spilled); those frames are one predict_n launch and one correct
-        // launch -- the same arithmetic
+    const bool f64_fused = sizeof(T) == 8 && mode == MODE_STACKED && h->prm.cov_form != FBUS_COV_JOSEPH && K > 0 && K <= 255;
+    if ((sizeof(T) == 8 && !f64_fused) || (h->prm.cov_form == FBUS_COV_JOSEPH && mode != MODE_STACKED)) {
+        // no fused kernel for fp64 outside (stacked, simple) and none for the Joseph form with the reference mode's 7 row-by-row
+        // updates (it spilled): those frames are one predict_n launch and one correct launch -- the same arithmetic
         int rc = FBUS_OK;
         if (K > 0) rc = launch_predict_t<T, N, D>(h, K, accel, gyro, dt, dt_per_filter);
         if (rc == FBUS_OK && M > 0) rc = launch_correct_t<T, N, D>(h, M, ids, pos, quat, mode, skip);
         return rc;
+    }
+    if constexpr (sizeof(T) == 8) {
+        // (round 4) fp64, stacked, simple form: ONE launch per camera frame -- the parked K-step predict loop + the row-split passes
+        // with the record resident in registers / LDS (frame2_kernel<double>)
+        const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
+        h->records_warm = true;
+        launch_frame_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, (const T*)accel, (const T*)gyro, (const T*)dt,
+                                dt_per_filter ? 1 : 0, M, (const int*)ids, (const T*)pos, (const T*)quat, mode, false,
+                                (const unsigned char*)skip, h->d_applied, make_dc<T>(h), h->lp);
+        timing_end(h, ev);
+        HIP_TRY(h, hipGetLastError());
+        return FBUS_OK;
     }
     if constexpr (sizeof(T) == 4) {
     const int ev = timing_begin(h, FBUS_KERNEL_FRAME);

@@ -46,12 +46,11 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
         else FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD, FBUS_X_PREDICT_ST);
 #undef FBUS_LAUNCH_PREDICT
     } else if constexpr (sizeof(T) == 8) {
-        // fp64 is the verification path: K resident steps need more than the 512 registers a lane has in fp64 (the
-        // kernel spilled ~580 bytes per lane), so predict_n is K launches of the streamed per-call kernel
-        for (int k = 0; k < K; ++k)
-            hipLaunchKernelGGL((predict_kernel<T, N, D, false, AUX_NT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, 1,
-                               accel + (size_t)k * B * 3, gyro + (size_t)k * B * 3, dt + (size_t)k * (dt_stride ? B : 1),
-                               dt_stride, dc);
+        // fp64 (the reference's own arithmetic): K resident steps with rows p of the covariance and the whole nominal state parked in
+        // LDS between their uses (StepPark; 512 registers, one wave per SIMD).  Rounds 1-3 ran predict_n as K launches of the per-call
+        // kernel -- the resident loop spilled 580 bytes per lane; the parked form spills 68 (N = 18) / 0 (N = 15).
+        hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
+                           K, accel, gyro, dt, dt_stride, dc);
     } else if (B >= lp.two_wave_min_b) {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
                            K, accel, gyro, dt, dt_stride, dc);
@@ -104,6 +103,13 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
     const bool joint = mode == MODE_STACKED;
+    if constexpr (sizeof(T) == 8) {
+        // fp64: one fused kernel, the parked predict loop + the row-split passes (frame2_kernel: 512 registers, 44 KiB of LDS, one wave
+        // per SIMD); stacked mode, simple form -- the caller (fbus_ekf.hip::launch_frame_t) runs every other combination as predict_n + correct
+        hipLaunchKernelGGL((frame2_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, dt_stride, M, ids,
+                           pos, quat, skip, applied, dc);
+        (void)joint; (void)joseph; (void)lp;
+    } else {
 #define FBUS_LAUNCH_FRAME(COV, JOINT)                                                                                 \
     hipLaunchKernelGGL((frame_kernel<T, N, D, COV, JOINT>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, \
                        dt_stride, M, ids, pos, quat, mode, skip, applied, dc)
@@ -118,6 +124,7 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
     if (joseph) { FBUS_LAUNCH_FRAME(COV_JOSEPH, true); }
     else        { if (joint) FBUS_LAUNCH_FRAME(COV_SIMPLE, true); else FBUS_LAUNCH_FRAME(COV_SIMPLE, false); }
 #undef FBUS_LAUNCH_FRAME
+    }
 }
 #define FBUS_INST(D)                                                                                                  \
     template void launch_frame_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const FBUS_TU_T*,        \

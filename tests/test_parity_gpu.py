@@ -645,6 +645,67 @@ def test_fused_frame_equals_per_call_launches(dialect, mode):
         assert cov_rel_err_blockwise(sb[2], sa[2]) < COV_BLOCK_TOL
 
 
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_fp64_resident_frame_and_predict_n(dialect, n):
+    """(round 4) the reference's own arithmetic as ONE launch per camera frame and one launch per K IMU samples: frame2_kernel<double>
+    (parked K-step predict loop + row-split passes) and the parked predict_n<double>, against the oracle at the fp64 gates (1e-9) and
+    against the per-call fp64 kernels, over two frames with invisible markers, ids outside the map and a masked frame.
+    Types of the reference: common.hpp:205-247; operations: filter.cpp:533-616, 622-741."""
+    import torch
+    B, M, K = 1000, 4, 7
+    prm, nom, rot, P, prev = _batch(B, dialect, n)
+    acc, gyr = _imu(0, B, 0, 2 * K, nom)
+    dev = torch.device("cuda:0")
+    f64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float64)).to(dev)
+    d_acc, d_gyr, d_dt = f64(acc), f64(gyr), f64(np.full(K, DT[0]))
+    frames = []
+    for f in range(2):
+        ids, pos, quat = _markers(0, B, f, M, nom, prm)
+        ids[5] = -1
+        ids[6, :] = 9
+        frames.append((torch.from_numpy(ids).to(dev), f64(pos), f64(quat)))
+    skip = torch.from_numpy((np.arange(B) % 7 == 3).astype(np.uint8)).to(dev)
+    with BatchedFilter(B, prm, dtype=64, nstate=n) as a, BatchedFilter(B, prm, dtype=64, nstate=n) as b:
+        for flt, fused in ((a, False), (b, True)):
+            flt.set_state(nom, rot, P, prev)
+            for f in range(2):
+                ids, pos, quat = frames[f]
+                flt.frame(d_acc[f * K:(f + 1) * K], d_gyr[f * K:(f + 1) * K], d_dt, ids, pos, quat, 1, skip if f == 1 else None, fused=fused)
+            flt.sync()
+        sa, sb = a.get_state(), b.get_state()
+        assert (a.applied() == b.applied()).all() and (sa[3] == sb[3]).all()
+        assert_parity(sb, sa, 64, f"fp64 resident frame vs per-call launches d{dialect} n{n}")
+        eng = OracleEngine(B, dialect, n)
+        eng.set_state(nom, rot, P, prev)
+        skip_h = skip.cpu().numpy()
+        for f in range(2):
+            for k in range(K):
+                eng.predict(acc[f * K + k], gyr[f * K + k], DT)
+            keep = eng.get_state()
+            ok = eng.correct(frames[f][0].cpu().numpy(), frames[f][1].cpu().numpy(), frames[f][2].cpu().numpy(), 1)
+            if f == 1:
+                now = eng.get_state()
+                for x, y in zip(now[:3], keep[:3]):
+                    x[skip_h == 1] = y[skip_h == 1]
+                now[3][skip_h == 1] = keep[3][skip_h == 1]
+                eng.set_state(*now)
+                ok[skip_h == 1] = 0
+        assert (b.applied() == ok).all()
+        assert_parity(sb, eng.get_state(), 64, f"fp64 resident frame vs oracle d{dialect} n{n}")
+        # K steps in one launch against K launches, and a frame without markers through the fused entry point
+        a.set_state(nom, rot, P, prev); b.set_state(nom, rot, P, prev)
+        for k in range(K):
+            a.predict(d_acc[k], d_gyr[k], d_dt[:1])
+        b.predict_n(d_acc[:K], d_gyr[:K], d_dt)
+        a.sync(); b.sync()
+        assert_parity(b.get_state(), a.get_state(), 64, f"fp64 resident predict_n vs per-call d{dialect} n{n}")
+        b.set_state(nom, rot, P, prev)
+        b.frame(d_acc[:K], d_gyr[:K], d_dt, None, None, None, 1, fused=True)
+        b.sync()
+        assert_parity(b.get_state(), a.get_state(), 64, f"fp64 resident frame without markers d{dialect} n{n}")
+
+
 def test_sixteen_marker_slots_stacked():
     """config 5 shape: M = 16 slots per frame (12 distinct map markers + 4 absent), stacked 84-row update"""
     B = 192
