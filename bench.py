@@ -437,8 +437,9 @@ def fp64_leg(torch, dev, local_rank, args, capi):
            "dtype": "f64", "batch": w.B, "records_MB": w.B * 1600 / 1e6, "roofline": roof, "correct_kernel": corr,
            "fused_frame": {"value": w.B * STEPS_PER_BENCH_STEP * steps / elf, "unit": "EKF steps/s", "ms_per_step": elf / steps * 1e3,
                            "vs_per_call": el / elf,
-                           "note": "one launch per camera frame (K predicts + correct resident: frame2_kernel<double>, 512 registers + 44 KiB of "
-                                   "LDS per wave, 132-188 bytes of scratch at N = 18); rounds 1-3 ran an fp64 frame as K + 1 launches"},
+                           "note": "one launch per camera frame (K predicts + correct resident: frame2_kernel<double>, 512 registers + 39 KiB of "
+                                   "LDS per wave = four workgroups per CU, 120-140 bytes of scratch at N = 18); rounds 1-3 ran an fp64 frame as "
+                                   "K + 1 launches"},
            "note": "per-call API, fp64 kernels (the reference's own arithmetic: same device functions instantiated for double, 1600-byte records)"}
     w.flt.close()
     return blk

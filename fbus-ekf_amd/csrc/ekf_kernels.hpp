@@ -991,11 +991,26 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
     // the stash of the passes reuses the parking area (fp32: 17 chunks hold both; fp64: the stash, 66 doubles, is the larger one)
     constexpr int LDS_CH = Park::NCHUNK * 16 >= (int)(Stash::NVAL * sizeof(T)) ? Park::NCHUNK : (int)((Stash::NVAL * sizeof(T) + 15) / 16);
     const int b = blockIdx.x * BLOCK + threadIdx.x;
-    __shared__ MarkerLDS<T> tbl;
+    // fp64 records: the parking area alone is 39 KiB; with the 4 KiB marker map beside it a workgroup would need 43 KiB and only
+    // three of them fit a CU's 160 KiB -- 1024 workgroups then run as two rounds (measured: 13.3 us per resident step instead of
+    // predict_n's 6.1).  The map therefore takes the last chunks of the parking area and is copied in BEHIND the predict loop
+    // (the head of the covariance parks four chunks fewer while the marker rows are folded): 39 KiB, four workgroups per CU.
+    constexpr bool MAP_LATE = sizeof(T) == 8;
+    constexpr int TBL_CH = MAP_LATE ? (int)((sizeof(MarkerLDS<T>) + 16 * BLOCK - 1) / (16 * BLOCK)) : 0;
+    constexpr int HEAD_CH = Park::NCHUNK - TBL_CH;                        // chunks of the covariance head parked during the fold
+    static_assert(!MAP_LATE || Stash::NVAL * sizeof(T) <= (size_t)(LDS_CH - TBL_CH) * 16, "stash and map overlap");
+    __shared__ std::conditional_t<MAP_LATE, int, MarkerLDS<T>> tbl_own;   // (fp64: never referenced, no LDS)
     __shared__ u32x4 lds_mem[LDS_CH * BLOCK];
+    MarkerLDS<T>* tblp;
+    if constexpr (MAP_LATE) tblp = reinterpret_cast<MarkerLDS<T>*>(lds_mem + (LDS_CH - TBL_CH) * BLOCK);
+    else tblp = &tbl_own;
+    MarkerLDS<T>& tbl = *tblp;
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
-    {
+    if constexpr (MAP_LATE) {
+        load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
+        load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
+    } else {
         MarkerTableRegs<T> treg;
         treg.load(dc);
         order_fence();
@@ -1022,10 +1037,22 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
     T dx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dx[i] = T(0);
+    if constexpr (MAP_LATE) {
+        // every lane of the batch takes part (also those whose frame is skipped); the lanes past the batch end have left: the copy
+        // is shared by the nact lanes that remain (wave-uniform)
+        const int nact = min(BLOCK, B - (int)blockIdx.x * BLOCK);
+        const u32x4* si = reinterpret_cast<const u32x4*>(dc.id2slot);
+        const u32x4* sm = reinterpret_cast<const u32x4*>(dc.mk);
+        u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
+        u32x4* dm = reinterpret_cast<u32x4*>(tbl.mk);
+        for (int i = threadIdx.x; i < MarkerTableRegs<T>::NI; i += nact) di[i] = si[i];
+        for (int i = threadIdx.x; i < MarkerTableRegs<T>::NM; i += nact) dm[i] = sm[i];
+        order_fence();
+    }
     if (last > 0) {
         // the head of the early rows waits in LDS while the rows of the markers are built and folded
 #pragma unroll
-        for (int c = 0; c < Park::NCHUNK; ++c) park.put(c, P + c * EPC, EPC);
+        for (int c = 0; c < HEAD_CH; ++c) park.put(c, P + c * EPC, EPC);
         order_fence();
         InfoAcc<T> acc;
         PoseFold<T, N, DIALECT> fold;
@@ -1046,7 +1073,7 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
         if (used > 0) { fold.finish(acc, nom, dc, mc); joint_factor<T>(acc, fac); }
         order_fence();
 #pragma unroll
-        for (int c = 0; c < Park::NCHUNK; ++c) park.get(c, P + c * EPC, EPC);
+        for (int c = 0; c < HEAD_CH; ++c) park.get(c, P + c * EPC, EPC);
         order_fence();
     }
     if (M > 0) applied[b] = used > 0 ? 1 : 0;

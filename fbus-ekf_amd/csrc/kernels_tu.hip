@@ -104,7 +104,7 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
     const int grid = (B + BLOCK - 1) / BLOCK;
     const bool joint = mode == MODE_STACKED;
     if constexpr (sizeof(T) == 8) {
-        // fp64: one fused kernel, the parked predict loop + the row-split passes (frame2_kernel: 512 registers, 44 KiB of LDS, one wave
+        // fp64: one fused kernel, the parked predict loop + the row-split passes (frame2_kernel: 512 registers, 39 KiB of LDS, one wave
         // per SIMD); stacked mode, simple form -- the caller (fbus_ekf.hip::launch_frame_t) runs every other combination as predict_n + correct
         hipLaunchKernelGGL((frame2_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, dt_stride, M, ids,
                            pos, quat, skip, applied, dc);
