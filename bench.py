@@ -27,9 +27,11 @@ launch (1436 B per filter: 828 read, 608 written -- the predict-invariant covari
 written back) / its average duration measured with HIP events on the launch stream inside the timed region;
 `achieved_api` prices SURVEY.md 8(d)'s full record round trip (1620 B) instead.  `roofline_hbm_resident` is the
 same measurement at 1 048 576 filters per GPU (839 MB of records: three times the 256 MiB Infinity Cache);
-`roofline_b262144` the round-2 leg (210 MB: partly cache-resident).  `fp64` is the same workload through the fp64 kernels,
-`north_star_rows` the same mixed schedule with the reprojection-row update (correct_pixels) in place of the pose update.  `cpu_baseline` is the fp64 dense oracle port (oracle/),
-timed on a bounded sample.
+`roofline_b262144` the round-2 leg (210 MB: partly cache-resident).  `fp64` is the same workload through the fp64 kernels
+(per-call, one launch per frame as `fp64.fused_frame`, and past the cache at 524 288 filters as `fp64.roofline_hbm_resident`),
+`north_star_rows` the same mixed schedule with the north star's own measurement updates (correct_pixels / correct_corners) in
+place of the pose update.  `legs_skipped` names the legs a line does not carry.  `cpu_baseline` is the fp64 dense oracle port
+(oracle/), timed on a bounded sample.
 """
 import argparse
 import json
@@ -61,6 +63,7 @@ POOL = 4                            # distinct 0.1 s input patterns (IMU samples
 # The HBM-roofline claim needs records that do NOT fit the 256 MiB (268 MB) Infinity Cache: 1 048 576 filters = 839 MB of records.
 # (Round 2 used 262 144 filters = 210 MB, which still fits: that leg is kept as `roofline_b262144`, labelled for what it is.)
 HBM_LEG_BATCH = 1048576
+F64_HBM_LEG_BATCH = 524288
 MID_LEG_BATCH = 262144
 HBM_COPY_CEILING_GBS = 6290.0       # MI355X_MICROARCH.md: what a float4 copy kernel reaches on this part (0.79 of the 8 TB/s spec)
 
@@ -442,6 +445,28 @@ def fp64_leg(torch, dev, local_rank, args, capi):
                                    "K + 1 launches"},
            "note": "per-call API, fp64 kernels (the reference's own arithmetic: same device functions instantiated for double, 1600-byte records)"}
     w.flt.close()
+    del w
+    # the fp64 kernels past the Infinity Cache: 524 288 filters = 839 MB of 1600-byte records, two input patterns of 168 MB
+    # (the fp32 leg of the same name holds 1 048 576 filters: the same bytes)
+    if not args.no_hbm_leg and args.batch < MID_LEG_BATCH:
+        torch.cuda.empty_cache()
+        w2 = Workload(torch, dev, local_rank, 0, F64_HBM_LEG_BATCH, args, 2, with_cov=False, dtype=64, tile=F64_HBM_LEG_BATCH // 65536)
+        steps2 = 2
+        w2.flt.timing_enable(True, stride=2)
+        el2 = timed(torch, w2.step, steps2, 1, before_timing=lambda: (w2.flt.timing_reset(), w2.flt._keep.clear()))
+        p_ms, p_n = w2.flt.timing_read(capi.KERNEL_PREDICT)
+        c_ms, c_n = w2.flt.timing_read(capi.KERNEL_CORRECT)
+        w2.flt.timing_enable(False)
+        tr2, src2 = pmc_traffic_named(f"r04_digest_f64_b{w2.B}.json", w2.B, args, "predict_kernel<double, 18")
+        roof2, corr2 = roofline_block(w2, p_ms, p_n, c_ms, c_n, tr2, src2)
+        roof2.pop("note")
+        roof2.update({"batch": w2.B, "records_MB": w2.B * 1600 / 1e6, "input_patterns": 2, "steps": steps2,
+                      "value": w2.B * STEPS_PER_BENCH_STEP * steps2 / el2, "unit_value": "EKF steps/s", "correct_kernel": corr2,
+                      "note": "the fp64 kernels at 524 288 filters: 839 MB of records (three times the 256 MiB Infinity Cache), nothing "
+                              "survives in the cache between launches -- the HBM streaming rate of the fp64 path"})
+        blk["roofline_hbm_resident"] = roof2
+        w2.flt.close()
+        del w2
     return blk
 
 
