@@ -3,8 +3,9 @@
 
 The library is 21 translation units compiled in parallel and linked into one shared object:
   fbus_ekf.hip                          handle, C ABI, the small kernels (pack/unpack, init, EMA, marker pose)
-  kernels_tu.hip x 20                   one kernel family (predict / correct / fused frame / frame window / team / corner + pixel rows) for one
-                                        (float|double, N = 18|15), both dialects: -DFBUS_TU_T/N/FAMILY
+  kernels_tu.hip x 20                   one kernel family for one (float|double, N = 18|15), both dialects (-DFBUS_TU_T/N/FAMILY):
+                                        float: predict / correct / frame / frames / team / meas (6 x 2 = 12),
+                                        double: predict / correct / frame / meas (4 x 2 = 8; len(units()) == 21 with fbus_ekf.hip)
 Objects live in fbus-ekf_amd/lib/obj/ (git-ignored) and are rebuilt when a source they include is newer.
   python build.py [--force] [--only f32_18_correct,...] [--jobs N]
 FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds (A/B of differently built kernels via FBUS_EKF_LIB).
