@@ -70,7 +70,11 @@ def needs_build():
         return True
     t = os.path.getmtime(OUT)
     srcs = {src for _, src, _ in units()} | set(HEADERS) | {os.path.abspath(__file__)}
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in srcs)
+    if any(os.path.exists(d) and os.path.getmtime(d) > t for d in srcs):
+        return True
+    # a partial rebuild (--only) links a library that is newer than every source while other objects are still stale
+    return os.path.isdir(OBJDIR) and any(_stale(os.path.join(OBJDIR, name + ".o"), src) for name, src, _ in units()
+                                         if os.path.exists(os.path.join(OBJDIR, name + ".o")))
 
 
 def build(force=False, verbose=False, only=None, jobs=None):
