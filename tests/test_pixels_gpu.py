@@ -52,8 +52,8 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo):
     eng.set_state(*now)
     ok[skip == 1] = 0
     assert ok[0] == 0 and ok[1] == 0 and ok[2:][skip[2:] == 0].all()
-    # fp32 at this batch size runs correct_meas_team_kernel by default (the markers divided among four waves per tile);
-    # the one-wave kernel (set_team correct_roles = 1) and the two-role form go through the same gate
+    # at this batch size the default is the four-role form of correct_pixels2_kernel (the markers divided among four waves per tile,
+    # DESIGN.md 4.3); the one-wave kernel (set_team correct_roles = 1) and the two-role form go through the same gate
     for dtype, roles in ((64, 0), (32, 0), (32, 1), (32, 2)):
         with BatchedFilter(B, prm, dtype=dtype) as flt:
             flt.set_team(0, roles)
