@@ -320,11 +320,11 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         // Start: the THIN-port solution in closed form, twice.  With the port's own offsets folded into an effective water depth
         // z_e = z_w + (d_air + d_glass a0) / a1 (exact in the paraxial limit) the equation is rho = z_e tan(theta_water) with
         // sin(theta_water) = a1 sin(theta_air):  t0 = u / sqrt(a1^2 - (1 - a1^2) u^2),  u = rho / z_e  -- within 1.4e-3 of the root for
-        // 0.25 .. 2 m of water and tangents up to 1.4, but 1.9e-2 at the rim of the admitted field of view (tangent 3).  Then the
-        // port's offsets AT t0 are taken off rho and the thin-port equation is solved once more for the water alone:
+        // 0.25 .. 2 m of water and tangents up to 1.4, 2.7e-2 up to 2.5, 1e-1 at the rim of the admitted field of view (tangent 3.16).
+        // Then the port's offsets AT t0 are taken off rho and the thin-port equation is solved once more for the water alone:
         //     u1 = (rho - d_air t0 - d_glass tan(theta_glass(t0))) / z_w,   t1 = u1 / sqrt(a1^2 - (1 - a1^2) u1^2)
-        // -- within 1.7e-3 everywhere, 1e-4 inside tangent 1.4 (tools/emul_meas_fold.py).  The hardware estimates (2^-23) are good
-        // enough for a start.  Measured in one run (65 536 filters x 16 slots, left / stereo): second pass always 79.4 / 120.0 us,
+        // -- within 1.2e-4 inside tangent 1.4, 6e-4 up to 2, 3.4e-3 up to 2.5, 1.8e-2 at the rim (tests/test_port_solver_cpu.py
+        // restates this solver in numpy and asserts the figures).  The hardware estimates (2^-23) are good enough for a start.  Measured in one run (65 536 filters x 16 slots, left / stereo): second pass always 79.4 / 120.0 us,
         // only for the waves that hold a tangent > 1.3 (voted, applied per lane) 78.3 / 124.0 -- the branch costs more than the
         // pass --, never 76.0 / 113.2 (and 1.6e-4 off at the rim).
         const double q1 = 1.0 - mc.a1 * mc.a1, a12 = mc.a1 * mc.a1, Gd0 = mc.d_glass * mc.a0;
@@ -349,9 +349,10 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
 #pragma unroll
         for (int q = 0; q < NP; ++q) t[q] = u[q] * w_[q];
     }
-    // ONE Halley step in double from there (cubic: a step of size dt leaves ~0.06 |dt|^3, measured -- <= 1.6e-10 from the start
-    // above, below what an fp32 posterior can see); fp64 records take a second one, which reaches double precision.  No
-    // iteration, no wave vote, and nothing depends on the measured image point.
+    // ONE Halley step in double from there (cubic): 1.4e-13 left inside tangent 1.4 (every lens; the recordings and test scenes stay
+    // below 0.8), 7e-12 up to 2, 9e-10 up to 2.5, 4.4e-8 = 1.4e-8 relative at the very rim -- below the fp32 rounding of the image
+    // point it is compared with; fp64 records take a second step, which reaches double precision (5e-15) everywhere.  No iteration,
+    // no wave vote, and nothing depends on the measured image point.
     // (Round-4 history: Newton in fp32 from the paraxial start, 3-4 voted steps; from the measured ray 2-3; Halley from the
     // measured ray 1-2, then one in double; this form: one evaluation of the port equation.)
     double iLt[NP], c2[NP];
