@@ -86,6 +86,53 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo):
             assert np.linalg.eigvalsh(Ps / (dg[:, :, None] * dg[:, None, :])).min() > 0
 
 
+def test_tilted_port_takes_the_general_normal_path():
+    """The reference's configuration has the port square to the camera (normal_vector 0 0 1: paramconfig.yml:39-42, refractinfo.yml:10-13)
+    and the kernels have a form specialised for it; a port tilted by two degrees goes through the general form: reprojection rows (left,
+    stereo) and triangulated corners against the oracle with the same normal, standard gates."""
+    B, M, dialect = 192, 4, 0
+    nrm = np.array([0.03, -0.02, 1.0]); nrm /= np.linalg.norm(nrm)
+    prm = capi.default_params(dialect)
+    prm.marker_size = SIZE
+    vp = oc.vision_params()
+    for i in range(3):
+        prm.port_normal[i] = float(nrm[i]); vp.normal[i] = float(nrm[i])
+    nom0, _, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18, mixed_cov=True)
+    truth, _, ids, left, right = pixel_scene(B, M, prm, SIZE, seed=21, noise=5e-4, nominal=nom0, vision=vp)
+    rng = np.random.default_rng(22)
+    nom = truth.copy()
+    nom[:, 0:3] += rng.normal(0, 0.004, (B, 3))
+    nom = r32(nom)
+    rot, P, left, right = r32(synth.q2R(nom[:, 6:10]).reshape(B, 9)), r32(P), r32(left), r32(right)
+    for stereo in (False, True):
+        rgt = right if stereo else None
+        eng = OracleEngine(B, dialect, 18)
+        eng.set_state(nom, rot, P, prev)
+        ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, rgt, SIZE, prm.r_pix, vision=vp)
+        assert ok.all()
+        for dtype in (64, 32):
+            with BatchedFilter(B, prm, dtype=dtype) as flt:
+                flt.set_team(0, 1)
+                flt.set_state(nom, rot, P, prev)
+                flt.correct_pixels(ids, left, rgt)
+                got = flt.get_state()
+            e = parity_errors(got, eng.get_state())
+            print(f"[parity] tilted port, correct_pixels {'stereo' if stereo else 'left'} fp{dtype}: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} "
+                  f"cov block-wise {e['cov_block']:.2e}")
+            if dtype == 64:
+                assert e["literal"] < 1e-6 and e["sigma"] < 1e-6 and e["cov_block"] < 1e-6
+            else:
+                assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL
+    # a square port gives a different answer on the same data (the tilt is not silently ignored)
+    prm0 = capi.default_params(dialect)
+    prm0.marker_size = SIZE
+    with BatchedFilter(B, prm0, dtype=64) as flt:
+        flt.set_state(nom, rot, P, prev)
+        flt.correct_pixels(ids, left, None)
+        sq = flt.get_state()
+    assert np.abs(sq[0][:, 0:3] - got[0][:, 0:3]).max() > 1e-4
+
+
 def test_correct_pixels_converges_on_the_true_pose():
     """repeated updates with the projections of the TRUE corners pull a displaced fp32 filter onto the truth (1 mm / 1 mrad),
     a different check from oracle parity: the Jacobian has the right sign and scale"""

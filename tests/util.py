@@ -164,7 +164,7 @@ def assert_parity(got, ref, dtype, what, state_tol=STATE_TOL, cov_tol=COV_TOL, p
 
 
 # ---- synthetic stereo-pixel scenes for the pixel-row measurement model (tests only) -----------------------------------
-def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None, depth=(0.6, 1.2)):
+def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None, depth=(0.6, 1.2), vision=None):
     """B filters, each looking at one map marker from 0.4 - 1.0 m (pose built with replay.pose_from_marker), plus whichever
     other map markers happen to be in front of the port; up to M visible markers per filter.  Returns
     (nominal (B,19), rot (B,9), ids (B,M) with -1 padding, left (B,M,8), right (B,M,8)): the flat-port projections of the true
@@ -172,7 +172,7 @@ def pixel_scene(B, M, prm, size, seed=0, noise=0.0, nominal=None, depth=(0.6, 1.
     import oracle_capi as oc
     from fbus_ekf import replay, synth
     rng = np.random.default_rng(seed)
-    p = oc.vision_params()
+    p = vision if vision is not None else oc.vision_params()      # (a port that is not square to the camera: the caller's parameters)
     R_IL, P_IL, _ = synth.camera_constants(prm)
     mids, mpos, mquat = synth.marker_table(prm)
     c = np.array([[0, 0, 0], [0, size, 0], [size, size, 0], [size, 0, 0.0]])
