@@ -208,6 +208,23 @@ struct PixAcc {
         sc[1] += np[2] * r[0] - np[0] * r[2];
         sc[2] += np[0] * r[1] - np[1] * r[0];
     }
+    // one row a (its theta part is c = a x r, r = ru = R'(c_w - p)) with residual res, accumulated directly: 33 operations per row --
+    // cheaper than add_corner's detour over N', n' while a corner has two rows (left camera alone: 66 against 18 + 70), dearer from
+    // four rows on (stereo: 132 against 36 + 70)
+    __device__ __forceinline__ void add_row(const double* a, double res, const double* r)
+    {
+        const double c[3] = { a[1] * r[2] - a[2] * r[1], a[2] * r[0] - a[0] * r[2], a[0] * r[1] - a[1] * r[0] };
+        Saa[0] += a[0] * a[0]; Saa[1] += a[0] * a[1]; Saa[2] += a[0] * a[2];
+        Saa[3] += a[1] * a[1]; Saa[4] += a[1] * a[2]; Saa[5] += a[2] * a[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Sac[3 * i + j] += a[i] * c[j];
+        Scc[0] += c[0] * c[0]; Scc[1] += c[0] * c[1]; Scc[2] += c[0] * c[2];
+        Scc[3] += c[1] * c[1]; Scc[4] += c[1] * c[2]; Scc[5] += c[2] * c[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { sa[i] += a[i] * res; sc[i] += c[i] * res; }
+    }
     // -> the 6 x 6 information matrix (upper triangle, lidx order) and vector of the stacked rows
     //    Lam_pp = w R S_aa R',  Lam_pt = -w R S_ac,  Lam_tt = w S_cc,  b_p = -w R s_a,  b_t = w s_c
     __device__ __forceinline__ void finish(const double* R, double w, double* Lam, double* b) const
@@ -251,15 +268,19 @@ __device__ __forceinline__ void filter_pil(const double* R, const double* P_IL, 
 // p, R: the filter's position and carried rotation (double copies of the record's values); pil = R'(R P_IL) (see filter_pil);
 // mkc: the map slot (corner 0, x axis, y axis); yl / yr: the 8 + 8 measured image coordinates.  Every stage is written across the NP = 4 NCAM projections (see md_rsq_n).
 // One evaluation of the port equation per projection in the common case (see below).
-template <int NCAM, typename T>
+// NZ: the port is square to the camera, normal = (0, 0, 1) exactly -- the reference's configuration (paramconfig.yml:39-42,
+// refractinfo.yml:10-13: normal_vector 0 0 1).  Then z = X_z, the lateral offset is (X_x, X_y, 0), D_z = 1 (no division), and in the
+// row  a = alpha e'M + beta n'M + k (M_r - uv_r M_z)  the two k uv_r M_z terms cancel: a = c1 e_r (e'M) + k M_r - c2 e_r M_z --
+// ~60 of ~360 instructions per corner less.  Any other normal takes the general form (tests/test_pixels_gpu.py: a tilted port).
+template <int NCAM, typename T, bool NZ>
 __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, const double* R, const double* pil,
                                                   const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size)
 {
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;           // Newton steps behind v_rsq_f64 / v_rcp_f64
     constexpr int NP = 4 * NCAM;
-    double ru[4][3];
+    double ru[4][3], rAx[3], rAy[3];
     {
-        double u0[3], ru0[3], rAx[3], rAy[3];
+        double u0[3], ru0[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) u0[i] = mkc[i] - p[i];
 #pragma unroll
@@ -283,30 +304,52 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
     {
         double X[NP][3], z[NP], r2[NP], zwq[NP], r2s[NP], xs[NP], ir0[NP], ze[NP];
         bool ok[NP];
+        // X = M_c (ru_k - pil) + t_c: corner 0 and the two edge vectors once per camera, the other corners by addition
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int k = q / NCAM, c = q % NCAM;
+        for (int c = 0; c < NCAM; ++c) {
             const double* M = c ? mc.McR : mc.McL;
-            const double tI[3] = { ru[k][0] - pil[0], ru[k][1] - pil[1], ru[k][2] - pil[2] };
+            const double tI[3] = { ru[0][0] - pil[0], ru[0][1] - pil[1], ru[0][2] - pil[2] };
+            double X0[3], MAx[3], MAy[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) X[q][i] = M[3 * i] * tI[0] + M[3 * i + 1] * tI[1] + M[3 * i + 2] * tI[2] + (c ? mc.tR[i] : 0.0);
+            for (int i = 0; i < 3; ++i) {
+                X0[i] = M[3 * i] * tI[0] + M[3 * i + 1] * tI[1] + M[3 * i + 2] * tI[2] + (c ? mc.tR[i] : 0.0);
+                MAx[i] = M[3 * i] * rAx[0] + M[3 * i + 1] * rAx[1] + M[3 * i + 2] * rAx[2];
+                MAy[i] = M[3 * i] * rAy[0] + M[3 * i + 1] * rAy[1] + M[3 * i + 2] * rAy[2];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                X[0 * NCAM + c][i] = X0[i];
+                X[1 * NCAM + c][i] = X0[i] + MAy[i];
+                X[2 * NCAM + c][i] = X0[i] + MAy[i] + MAx[i];
+                X[3 * NCAM + c][i] = X0[i] + MAx[i];
+            }
         }
+        if constexpr (NZ) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) z[q] = X[q][0] * n[0] + X[q][1] * n[1] + X[q][2] * n[2];
+            for (int q = 0; q < NP; ++q) {
+                z[q] = X[q][2];
+                lat[q][0] = X[q][0]; lat[q][1] = X[q][1]; lat[q][2] = 0.0;
+                r2[q] = X[q][0] * X[q][0] + X[q][1] * X[q][1];
+                zwq[q] = z[q] - (mc.d_air + mc.d_glass);
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < NP; ++q)
+            for (int q = 0; q < NP; ++q) z[q] = X[q][0] * n[0] + X[q][1] * n[1] + X[q][2] * n[2];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) lat[q][i] = X[q][i] - z[q] * n[i];
+            for (int q = 0; q < NP; ++q)
 #pragma unroll
-        for (int q = 0; q < NP; ++q) { r2[q] = lat[q][0] * lat[q][0] + lat[q][1] * lat[q][1] + lat[q][2] * lat[q][2]; zwq[q] = z[q] - mc.d_air - mc.d_glass; }
+                for (int i = 0; i < 3; ++i) lat[q][i] = X[q][i] - z[q] * n[i];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { r2[q] = lat[q][0] * lat[q][0] + lat[q][1] * lat[q][1] + lat[q][2] * lat[q][2]; zwq[q] = z[q] - mc.d_air - mc.d_glass; }
+        }
         // in front of the port and inside its field of view (in water no ray leans further than asin(n_air / n_water); 0.9 of that
         // limit, as the oracle): otherwise the corner contributes no rows to this camera.  A point out of view is replaced by a
         // harmless one on the axis (rho = 0, 1 / rho = 0, one metre of water): everything below stays finite, its rows get weight 0
         const double c0 = (mc.d_air + mc.d_glass * mc.a0) / mc.a1;
+        const double klim = 0.81 * mc.a1 * mc.a1 / (1.0 - mc.a1 * mc.a1);      // (0.9 a1)^2 / (1 - a1^2): wave-uniform
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const double lim = 0.9 * zwq[q] * mc.a1;
-            ok[q] = (zwq[q] > 0.0) && (r2[q] * (1.0 - mc.a1 * mc.a1) < lim * lim);
+            ok[q] = (zwq[q] > 0.0) && (r2[q] < klim * zwq[q] * zwq[q]);
             vis[q] = ok[q] ? 1.0 : 0.0;
             r2s[q] = ok[q] ? r2[q] : 0.0;
             const double zs = ok[q] ? zwq[q] : 1.0;
@@ -373,66 +416,106 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
 #pragma unroll
         for (int q = 0; q < NP; ++q) c2[q] = f.Lz[q] * iLt[q];
     }
-    double kk[NP], Dz[NP], iDz[NP], uv[NP][2], e[NP][3], eM[NP][3];
+    double kk[NP], uv[NP][2], a[NP][2][3], res[NP][2];
 #pragma unroll
     for (int q = 0; q < NP; ++q) kk[q] = (irho[q] > 0.0) ? t[q] * irho[q] : iLt[q];          // t / rho; on the axis its limit 1 / L_t
+    if constexpr (NZ) {
+        double e[NP][2], eM[NP][3];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) Dz[q] = n[2] + kk[q] * lat[q][2];
-    md_rcp_n<NS, NP>(Dz, iDz);
+        for (int q = 0; q < NP; ++q) {
+            uv[q][0] = kk[q] * lat[q][0];
+            uv[q][1] = kk[q] * lat[q][1];
+            e[q][0] = lat[q][0] * irho[q];
+            e[q][1] = lat[q][1] * irho[q];
+        }
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        uv[q][0] = (n[0] + kk[q] * lat[q][0]) * iDz[q];
-        uv[q][1] = (n[1] + kk[q] * lat[q][1]) * iDz[q];
+        for (int q = 0; q < NP; ++q) {
+            const double* M = (q % NCAM) ? mc.McR : mc.McL;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) e[q][i] = lat[q][i] * irho[q];
-    }
+            for (int j = 0; j < 3; ++j) eM[q][j] = e[q][0] * M[j] + e[q][1] * M[3 + j];
+        }
+        // a_r = vis (c1 e_r (e'M) + k M_r - c2 e_r M_z)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const double* M = (q % NCAM) ? mc.McR : mc.McL;
+        for (int q = 0; q < NP; ++q) {
+            const int k = q / NCAM, c = q % NCAM;
+            const double* M = c ? mc.McR : mc.McL;
+            const T* y = c ? yr : yl;
+            const double c1v = (iLt[q] - kk[q]) * vis[q], c2v = c2[q] * vis[q], kv = kk[q] * vis[q];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) eM[q][j] = e[q][0] * M[j] + e[q][1] * M[3 + j] + e[q][2] * M[6 + j];
-    }
-    // rows: J_r = alpha e' + beta n' + k g',  g = (unit_r - uv_r unit_z) / D_z;  a = (J_r Mc)' masked by visibility
-    double a[NP][2][3], res[NP][2];
+            for (int r = 0; r < 2; ++r) {
+                const double w1 = c1v * e[q][r], w3 = -c2v * e[q][r];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int k = q / NCAM, c = q % NCAM;
-        const double* M = c ? mc.McR : mc.McL;
-        const double* nM = c ? mc.nMR : mc.nML;
-        const T* y = c ? yr : yl;
-        const double c1 = iLt[q] - kk[q];
-        const double kz = kk[q] * iDz[q] * vis[q];
+                for (int j = 0; j < 3; ++j) a[q][r][j] = w1 * eM[q][j] + kv * M[3 * r + j] + w3 * M[6 + j];
+                res[q][r] = (double)y[2 * k + r] - uv[q][r];
+            }
+        }
+    } else {
+        double Dz[NP], iDz[NP], e[NP][3], eM[NP][3];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const double ge = (e[q][r] - uv[q][r] * e[q][2]) * iDz[q], gn = (n[r] - uv[q][r] * n[2]) * iDz[q];
-            const double am = ge * c1 * vis[q], bm = -(c2[q] * ge + kk[q] * gn) * vis[q];
+        for (int q = 0; q < NP; ++q) Dz[q] = n[2] + kk[q] * lat[q][2];
+        md_rcp_n<NS, NP>(Dz, iDz);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) a[q][r][j] = am * eM[q][j] + bm * nM[j] + kz * (M[3 * r + j] - uv[q][r] * M[6 + j]);
-            res[q][r] = (double)y[2 * k + r] - uv[q][r];
+        for (int q = 0; q < NP; ++q) {
+            uv[q][0] = (n[0] + kk[q] * lat[q][0]) * iDz[q];
+            uv[q][1] = (n[1] + kk[q] * lat[q][1]) * iDz[q];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) e[q][i] = lat[q][i] * irho[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double* M = (q % NCAM) ? mc.McR : mc.McL;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) eM[q][j] = e[q][0] * M[j] + e[q][1] * M[3 + j] + e[q][2] * M[6 + j];
+        }
+        // rows: J_r = alpha e' + beta n' + k g',  g = (unit_r - uv_r unit_z) / D_z;  a = (J_r Mc)' masked by visibility
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int k = q / NCAM, c = q % NCAM;
+            const double* M = c ? mc.McR : mc.McL;
+            const double* nM = c ? mc.nMR : mc.nML;
+            const T* y = c ? yr : yl;
+            const double c1 = iLt[q] - kk[q];
+            const double kz = kk[q] * iDz[q] * vis[q];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const double ge = (e[q][r] - uv[q][r] * e[q][2]) * iDz[q], gn = (n[r] - uv[q][r] * n[2]) * iDz[q];
+                const double am = ge * c1 * vis[q], bm = -(c2[q] * ge + kk[q] * gn) * vis[q];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[q][r][j] = am * eM[q][j] + bm * nM[j] + kz * (M[3 * r + j] - uv[q][r] * M[6 + j]);
+                res[q][r] = (double)y[2 * k + r] - uv[q][r];
+            }
         }
     }
-    double Np[4][6], np[4][3];
+    if constexpr (NCAM == 1) {
+        // two rows per corner: straight into the sums (PixAcc::add_row)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) Np[k][i] = 0.0;
+            for (int r = 0; r < 2; ++r) acc.add_row(a[k][r], res[k][r], ru[k]);
+    } else {
+        double Np[4][6], np[4][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) np[k][i] = 0.0;
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Np[k][i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) np[k][i] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < NCAM; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double* ar = a[k * NCAM + c][r];
+                    Np[k][0] += ar[0] * ar[0]; Np[k][1] += ar[0] * ar[1]; Np[k][2] += ar[0] * ar[2];
+                    Np[k][3] += ar[1] * ar[1]; Np[k][4] += ar[1] * ar[2]; Np[k][5] += ar[2] * ar[2];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) np[k][j] += ar[j] * res[k * NCAM + c][r];
+                }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc.add_corner(Np[k], np[k], ru[k]);
     }
-#pragma unroll
-    for (int c = 0; c < NCAM; ++c)
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double* ar = a[k * NCAM + c][r];
-                Np[k][0] += ar[0] * ar[0]; Np[k][1] += ar[0] * ar[1]; Np[k][2] += ar[0] * ar[2];
-                Np[k][3] += ar[1] * ar[1]; Np[k][4] += ar[1] * ar[2]; Np[k][5] += ar[2] * ar[2];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) np[k][j] += ar[j] * res[k * NCAM + c][r];
-            }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc.add_corner(Np[k], np[k], ru[k]);
 }
 
 // ---- correct() from stereo CORNERS: triangulation through the port in double, 3 position-type rows per corner ----------------
@@ -805,7 +888,7 @@ struct alignas(16) MeasLDS {
 // linearisation point.  One filter per lane; NR waves ("roles") per 64-filter tile divide the markers among themselves
 // (role r folds markers r, r + NR, ...; their sums meet in LDS, in role order) and role 0 applies the update.
 // =================================================================================
-template <typename T, int N, int NR>
+template <typename T, int N, int NR, bool NZ>
 __global__ void __launch_bounds__(64 * NR)
 correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
                        const T* __restrict__ right, double size, double r_pix, const unsigned char* __restrict__ skip,
@@ -888,8 +971,8 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
             double mk[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-            if (stereo) pixel_fold_marker<2, T>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-            else pixel_fold_marker<1, T>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
+            if (stereo) pixel_fold_marker<2, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+            else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
             nfold += 1.0;
         }
         cur = nxt;

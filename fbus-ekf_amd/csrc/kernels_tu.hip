@@ -223,9 +223,15 @@ void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
                       double r_pix, const unsigned char* skip, unsigned char* applied, const short* id2slot, const MeasConst& mc)
 {
     const int tiles = (B + 63) / 64;
+    // the port square to the camera (normal exactly (0, 0, 1): the reference's configuration) has its own, shorter fold
+    const bool nz = mc.n[0] == 0.0 && mc.n[1] == 0.0 && mc.n[2] == 1.0;
 #define FBUS_LAUNCH_PX(NR)                                                                                               \
-    hipLaunchKernelGGL((correct_pixels2_kernel<T, N, NR>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, right, size, \
-                       r_pix, skip, applied, id2slot, mc)
+    do {                                                                                                                 \
+        if (nz) hipLaunchKernelGGL((correct_pixels2_kernel<T, N, NR, true>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, \
+                                   right, size, r_pix, skip, applied, id2slot, mc);                                      \
+        else hipLaunchKernelGGL((correct_pixels2_kernel<T, N, NR, false>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, \
+                                right, size, r_pix, skip, applied, id2slot, mc);                                         \
+    } while (0)
     if (roles >= 3) FBUS_LAUNCH_PX(4);
     else if (roles == 2) FBUS_LAUNCH_PX(2);
     else FBUS_LAUNCH_PX(1);
