@@ -521,7 +521,8 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
 // ---- correct() from stereo CORNERS: triangulation through the port in double, 3 position-type rows per corner ----------------
 // vision.cpp:496-599 for the four corners of one marker (the arithmetic of vision_device.hpp::refraction_corner, in double and
 // written across the 8 rays / 4 corners -- see md_rsq_n): left / right normalised image points -> points in the left camera frame.
-template <typename T>
+// NZ: the port square to the camera (normal exactly (0, 0, 1), see pixel_fold_marker): v = r_z, and a refraction changes r_z only.
+template <typename T, bool NZ>
 __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& vc, const T* yl, const T* yr, double (&C)[4][3])
 {
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;
@@ -539,7 +540,7 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) r0[q][i] *= y[q];
-        v0[q] = r0[q][0] * n[0] + r0[q][1] * n[1] + r0[q][2] * n[2];
+        v0[q] = NZ ? r0[q][2] : r0[q][0] * n[0] + r0[q][1] * n[1] + r0[q][2] * n[2];
         x[q] = 1.0 - vc.alpha0 * vc.alpha0 * (1.0 - v0[q] * v0[q]);
     }
     md_rsq_n<NS, NQ>(x, y);                              // air -> glass   (vision.cpp:505-522)
@@ -548,8 +549,8 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
         const double root = x[q] * y[q];
         const double beta = vc.sqrt_minus0 ? (root - vc.alpha0 * v0[q]) : (vc.alpha0 * v0[q] - root);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) r1[q][i] = vc.alpha0 * r0[q][i] + beta * n[i];
-        v1[q] = r1[q][0] * n[0] + r1[q][1] * n[1] + r1[q][2] * n[2];
+        for (int i = 0; i < 3; ++i) r1[q][i] = (NZ && i < 2) ? vc.alpha0 * r0[q][i] : vc.alpha0 * r0[q][i] + beta * (NZ ? 1.0 : n[i]);
+        v1[q] = NZ ? r1[q][2] : r1[q][0] * n[0] + r1[q][1] * n[1] + r1[q][2] * n[2];
         x[q] = 1.0 - vc.alpha1 * vc.alpha1 * (1.0 - v1[q] * v1[q]);
     }
     md_rsq_n<NS, NQ>(x, y);                              // glass -> water (vision.cpp:524-543)
@@ -563,7 +564,7 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
         const double aq = vc.d_air * iv0[q], gq = vc.d_glass * iv1[q];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            r2[q][i] = vc.alpha1 * r1[q][i] + beta * n[i];
+            r2[q][i] = (NZ && i < 2) ? vc.alpha1 * r1[q][i] : vc.alpha1 * r1[q][i] + beta * (NZ ? 1.0 : n[i]);
             P1[q][i] = aq * r0[q][i] + gq * r1[q][i];      // exit point on the outer glass face (vision.cpp:546-552)
         }
     }
@@ -1007,7 +1008,7 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
 // nearest marker (by its first corner; C++ dialect: hysteresis against the previous one, filter.cpp:639-664) or all of them.
 // Same structure as correct_pixels2_kernel; the triangulation of the refractive geometry runs in double.
 // =================================================================================
-template <typename T, int N, int NR>
+template <typename T, int N, int NR, bool NZ>
 __global__ void __launch_bounds__(64 * NR)
 correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
                         const T* __restrict__ right, int geometry, int mode, int dialect, double size, double r_pos,
@@ -1052,7 +1053,7 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
     };
     // the four corners of a measured marker in the left camera frame
     auto corners = [&](const Meas& mm, double (&C)[4][3]) __attribute__((always_inline)) {
-        if (geometry == VIS_REFRACTIVE) { tri_corners_refractive<T>(vc, mm.l, mm.r, C); return; }
+        if (geometry == VIS_REFRACTIVE) { tri_corners_refractive<T, NZ>(vc, mm.l, mm.r, C); return; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (geometry == VIS_CORNERS3D) {

@@ -244,9 +244,14 @@ void launch_corners2_k(hipStream_t s, T* recs, int B, int M, const int* ids, con
 {
     const int tiles = (B + 63) / 64;
     if (mode != MODE_STACKED) roles = 1;
+    const bool nz = vc.nrm[0] == 0.0 && vc.nrm[1] == 0.0 && vc.nrm[2] == 1.0;       // the port square to the camera: the shorter triangulation
 #define FBUS_LAUNCH_CR(NR)                                                                                               \
-    hipLaunchKernelGGL((correct_corners2_kernel<T, N, NR>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, right,  \
-                       geometry, mode, D, size, r_pos, switch_thres, skip, applied, id2slot, mc, vc, vct)
+    do {                                                                                                                 \
+        if (nz) hipLaunchKernelGGL((correct_corners2_kernel<T, N, NR, true>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, \
+                                   right, geometry, mode, D, size, r_pos, switch_thres, skip, applied, id2slot, mc, vc, vct); \
+        else hipLaunchKernelGGL((correct_corners2_kernel<T, N, NR, false>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, \
+                                right, geometry, mode, D, size, r_pos, switch_thres, skip, applied, id2slot, mc, vc, vct); \
+    } while (0)
     if (roles >= 3) FBUS_LAUNCH_CR(4);
     else if (roles == 2) FBUS_LAUNCH_CR(2);
     else FBUS_LAUNCH_CR(1);

@@ -123,6 +123,27 @@ def test_tilted_port_takes_the_general_normal_path():
                 assert e["literal"] < 1e-6 and e["sigma"] < 1e-6 and e["cov_block"] < 1e-6
             else:
                 assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL
+    # the corner-row update triangulates through the same port (general form of tri_corners_refractive)
+    corners = np.zeros((B, M, 4, 3))
+    for b in range(B):
+        for m in range(M):
+            if ids[b, m] >= 0:
+                corners[b, m] = oc.refraction_triangulate(vp, left[b, m], right[b, m])
+    eng = OracleEngine(B, dialect, 18)
+    eng.set_state(nom, rot, P, prev)
+    ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids, corners, SIZE, capi.MODE_STACKED)
+    assert ok.all()
+    for dtype in (64, 32):
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            flt.set_state(nom, rot, P, prev)
+            flt.correct_corners(ids, left, right, capi.VIS_REFRACTIVE, capi.MODE_STACKED)
+            gc = flt.get_state()
+        e = parity_errors(gc, eng.get_state())
+        print(f"[parity] tilted port, correct_corners fp{dtype}: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} cov block-wise {e['cov_block']:.2e}")
+        if dtype == 64:
+            assert e["literal"] < 1e-9 and e["sigma"] < 1e-9 and e["cov_block"] < 1e-9
+        else:
+            assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL
     # a square port gives a different answer on the same data (the tilt is not silently ignored)
     prm0 = capi.default_params(dialect)
     prm0.marker_size = SIZE

@@ -190,7 +190,7 @@ def test_correct_from_stereo_corners_matches_oracle(dialect, mode, dtype, mult):
     eng = OracleEngine(B, dialect, 18)
     eng.set_state(nom, rot, P, prev)
     ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids, corners, size, mode)
-    # fp32 stacked mode at this batch size runs correct_corners_team_kernel (the markers divided among four waves per tile): the
+    # stacked mode at this batch size runs the four-role form of correct_corners2_kernel (the markers divided among four waves per tile): the
     # default, the one-wave kernel (set_team 1) and the two-role form all go through the same gate
     for roles in ((0, 1, 2) if (dtype == 32 and mode == 1) else (0,)):
         with BatchedFilter(B, prm, dtype=dtype) as flt:
