@@ -567,7 +567,7 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;
     constexpr int NQ = 8;                                 // ray q = 2 k + c: corner k, camera c
     const double* n = vc.nrm;
-    double r0[NQ][3], r1[NQ][3], r2[NQ][3], v0[NQ], v1[NQ], x[NQ], y[NQ];
+    double r0[NQ][3], r1[NQ][3], r2[NQ][3], v0[NQ], v1[NQ], x[NQ], y[NQ], iv0[NQ], iv1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const T* p = (q & 1) ? yr : yl;
@@ -575,6 +575,14 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
         x[q] = r0[q][0] * r0[q][0] + r0[q][1] * r0[q][1] + 1.0;
     }
     md_rsq_n<NS, NQ>(x, y);
+    // NZ: v0 = r0_z = 1 / |(x, y, 1)|, so 1 / v0 = |.|^2 / |.| costs one product; and where the refracted ray keeps the normal's side
+    // (sqrt_minus: the lower index first, as in air -> glass) v1 = alpha0 v0 + beta IS the root below, whose reciprocal is the
+    // reciprocal square root already taken -- no division for the two path lengths d_air / v0, d_glass / v1
+    const bool free_iv = NZ && vc.sqrt_minus0;           // wave-uniform
+    if constexpr (NZ) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) iv0[q] = x[q] * y[q];
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -590,12 +598,13 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
 #pragma unroll
         for (int i = 0; i < 3; ++i) r1[q][i] = (NZ && i < 2) ? vc.alpha0 * r0[q][i] : vc.alpha0 * r0[q][i] + beta * (NZ ? 1.0 : n[i]);
         v1[q] = NZ ? r1[q][2] : r1[q][0] * n[0] + r1[q][1] * n[1] + r1[q][2] * n[2];
+        iv1[q] = y[q];                                   // (= 1 / v1 if free_iv)
         x[q] = 1.0 - vc.alpha1 * vc.alpha1 * (1.0 - v1[q] * v1[q]);
     }
     md_rsq_n<NS, NQ>(x, y);                              // glass -> water (vision.cpp:524-543)
-    double P1[NQ][3], iv0[NQ], iv1[NQ];
-    md_rcp_n<NS, NQ>(v0, iv0);
-    md_rcp_n<NS, NQ>(v1, iv1);
+    double P1[NQ][3];
+    if constexpr (!NZ) md_rcp_n<NS, NQ>(v0, iv0);
+    if (!free_iv) md_rcp_n<NS, NQ>(v1, iv1);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const double root = x[q] * y[q];
