@@ -566,54 +566,84 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
 {
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;
     constexpr int NQ = 8;                                 // ray q = 2 k + c: corner k, camera c
-    const double* n = vc.nrm;
-    double r0[NQ][3], r1[NQ][3], r2[NQ][3], v0[NQ], v1[NQ], x[NQ], y[NQ], iv0[NQ], iv1[NQ];
+    double r2[NQ][3], P1[NQ][3];                          // the ray in the water and its exit point on the outer glass face
+    if (NZ && vc.sqrt_minus0 && vc.sqrt_minus1) {
+        // The port square to the camera and both refractions towards the normal's side (the reference's configuration; wave-uniform):
+        // everything follows from the image point (x, y) and three reciprocal square roots.  With s0 = 1 / |(x, y, 1)| = cos(theta_air):
+        //   cos(theta_glass) = root0 = sqrt(1 - alpha0^2 (1 - s0^2)),  cos(theta_water) = root1 = sqrt(1 - alpha1^2 (1 - root0^2)),
+        //   r2 = (alpha0 alpha1 s0 x, alpha0 alpha1 s0 y, root1),
+        //   P1 = d_air r0 / s0 + d_glass r1 / root0 = ((d_air + d_glass alpha0 s0 / root0) x, (same) y, d_air + d_glass)
+        // -- the same numbers as the general form below (vision.cpp:505-552) without normalising r0, without the two divisions.
+        double xx[NQ], yy[NQ], n2[NQ], s0[NQ], x1[NQ], y1[NQ], x2[NQ], y2[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const T* p = (q & 1) ? yr : yl;
-        r0[q][0] = (double)p[2 * (q >> 1)]; r0[q][1] = (double)p[2 * (q >> 1) + 1]; r0[q][2] = 1.0;
-        x[q] = r0[q][0] * r0[q][0] + r0[q][1] * r0[q][1] + 1.0;
-    }
-    md_rsq_n<NS, NQ>(x, y);
-    // NZ: v0 = r0_z = 1 / |(x, y, 1)|, so 1 / v0 = |.|^2 / |.| costs one product; and where the refracted ray keeps the normal's side
-    // (sqrt_minus: the lower index first, as in air -> glass) v1 = alpha0 v0 + beta IS the root below, whose reciprocal is the
-    // reciprocal square root already taken -- no division for the two path lengths d_air / v0, d_glass / v1
-    const bool free_iv = NZ && vc.sqrt_minus0;           // wave-uniform
-    if constexpr (NZ) {
+        for (int q = 0; q < NQ; ++q) {
+            const T* p = (q & 1) ? yr : yl;
+            xx[q] = (double)p[2 * (q >> 1)]; yy[q] = (double)p[2 * (q >> 1) + 1];
+            n2[q] = xx[q] * xx[q] + yy[q] * yy[q] + 1.0;
+        }
+        md_rsq_n<NS, NQ>(n2, s0);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) iv0[q] = x[q] * y[q];
-    }
+        for (int q = 0; q < NQ; ++q) x1[q] = 1.0 - vc.alpha0 * vc.alpha0 * (1.0 - s0[q] * s0[q]);
+        md_rsq_n<NS, NQ>(x1, y1);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+        for (int q = 0; q < NQ; ++q) { const double root0 = x1[q] * y1[q]; x2[q] = 1.0 - vc.alpha1 * vc.alpha1 * (1.0 - root0 * root0); }
+        md_rsq_n<NS, NQ>(x2, y2);
+        const double zP = vc.d_air + vc.d_glass, a01 = vc.alpha0 * vc.alpha1, ga = vc.d_glass * vc.alpha0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) r0[q][i] *= y[q];
-        v0[q] = NZ ? r0[q][2] : r0[q][0] * n[0] + r0[q][1] * n[1] + r0[q][2] * n[2];
-        x[q] = 1.0 - vc.alpha0 * vc.alpha0 * (1.0 - v0[q] * v0[q]);
-    }
-    md_rsq_n<NS, NQ>(x, y);                              // air -> glass   (vision.cpp:505-522)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double root = x[q] * y[q];
-        const double beta = vc.sqrt_minus0 ? (root - vc.alpha0 * v0[q]) : (vc.alpha0 * v0[q] - root);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) r1[q][i] = (NZ && i < 2) ? vc.alpha0 * r0[q][i] : vc.alpha0 * r0[q][i] + beta * (NZ ? 1.0 : n[i]);
-        v1[q] = NZ ? r1[q][2] : r1[q][0] * n[0] + r1[q][1] * n[1] + r1[q][2] * n[2];
-        iv1[q] = y[q];                                   // (= 1 / v1 if free_iv)
-        x[q] = 1.0 - vc.alpha1 * vc.alpha1 * (1.0 - v1[q] * v1[q]);
-    }
-    md_rsq_n<NS, NQ>(x, y);                              // glass -> water (vision.cpp:524-543)
-    double P1[NQ][3];
-    if constexpr (!NZ) md_rcp_n<NS, NQ>(v0, iv0);
-    if (!free_iv) md_rcp_n<NS, NQ>(v1, iv1);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const double root = x[q] * y[q];
-        const double beta = vc.sqrt_minus1 ? (root - vc.alpha1 * v1[q]) : (vc.alpha1 * v1[q] - root);
-        const double aq = vc.d_air * iv0[q], gq = vc.d_glass * iv1[q];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            r2[q][i] = (NZ && i < 2) ? vc.alpha1 * r1[q][i] : vc.alpha1 * r1[q][i] + beta * (NZ ? 1.0 : n[i]);
-            P1[q][i] = aq * r0[q][i] + gq * r1[q][i];      // exit point on the outer glass face (vision.cpp:546-552)
+        for (int q = 0; q < NQ; ++q) {
+            const double c2 = a01 * s0[q], cp = vc.d_air + ga * s0[q] * y1[q];
+            r2[q][0] = c2 * xx[q]; r2[q][1] = c2 * yy[q]; r2[q][2] = x2[q] * y2[q];
+            P1[q][0] = cp * xx[q]; P1[q][1] = cp * yy[q]; P1[q][2] = zP;
+        }
+    } else {
+        const double* n = vc.nrm;
+        double r0[NQ][3], r1[NQ][3], v0[NQ], v1[NQ], x[NQ], y[NQ], iv0[NQ], iv1[NQ];
+    #pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const T* p = (q & 1) ? yr : yl;
+            r0[q][0] = (double)p[2 * (q >> 1)]; r0[q][1] = (double)p[2 * (q >> 1) + 1]; r0[q][2] = 1.0;
+            x[q] = r0[q][0] * r0[q][0] + r0[q][1] * r0[q][1] + 1.0;
+        }
+        md_rsq_n<NS, NQ>(x, y);
+        // NZ: v0 = r0_z = 1 / |(x, y, 1)|, so 1 / v0 = |.|^2 / |.| costs one product; and where the refracted ray keeps the normal's side
+        // (sqrt_minus: the lower index first, as in air -> glass) v1 = alpha0 v0 + beta IS the root below, whose reciprocal is the
+        // reciprocal square root already taken -- no division for the two path lengths d_air / v0, d_glass / v1
+        const bool free_iv = NZ && vc.sqrt_minus0;           // wave-uniform
+        if constexpr (NZ) {
+    #pragma unroll
+            for (int q = 0; q < NQ; ++q) iv0[q] = x[q] * y[q];
+        }
+    #pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+    #pragma unroll
+            for (int i = 0; i < 3; ++i) r0[q][i] *= y[q];
+            v0[q] = NZ ? r0[q][2] : r0[q][0] * n[0] + r0[q][1] * n[1] + r0[q][2] * n[2];
+            x[q] = 1.0 - vc.alpha0 * vc.alpha0 * (1.0 - v0[q] * v0[q]);
+        }
+        md_rsq_n<NS, NQ>(x, y);                              // air -> glass   (vision.cpp:505-522)
+    #pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double root = x[q] * y[q];
+            const double beta = vc.sqrt_minus0 ? (root - vc.alpha0 * v0[q]) : (vc.alpha0 * v0[q] - root);
+    #pragma unroll
+            for (int i = 0; i < 3; ++i) r1[q][i] = (NZ && i < 2) ? vc.alpha0 * r0[q][i] : vc.alpha0 * r0[q][i] + beta * (NZ ? 1.0 : n[i]);
+            v1[q] = NZ ? r1[q][2] : r1[q][0] * n[0] + r1[q][1] * n[1] + r1[q][2] * n[2];
+            iv1[q] = y[q];                                   // (= 1 / v1 if free_iv)
+            x[q] = 1.0 - vc.alpha1 * vc.alpha1 * (1.0 - v1[q] * v1[q]);
+        }
+        md_rsq_n<NS, NQ>(x, y);                              // glass -> water (vision.cpp:524-543)
+        if constexpr (!NZ) md_rcp_n<NS, NQ>(v0, iv0);
+        if (!free_iv) md_rcp_n<NS, NQ>(v1, iv1);
+    #pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double root = x[q] * y[q];
+            const double beta = vc.sqrt_minus1 ? (root - vc.alpha1 * v1[q]) : (vc.alpha1 * v1[q] - root);
+            const double aq = vc.d_air * iv0[q], gq = vc.d_glass * iv1[q];
+    #pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                r2[q][i] = (NZ && i < 2) ? vc.alpha1 * r1[q][i] : vc.alpha1 * r1[q][i] + beta * (NZ ? 1.0 : n[i]);
+                P1[q][i] = aq * r0[q][i] + gq * r1[q][i];      // exit point on the outer glass face (vision.cpp:546-552)
+            }
         }
     }
     // the right ray in the left frame (vision.cpp:555-556), mid-point of the two rays by Cramer (vision.cpp:559-595)
@@ -631,7 +661,7 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
 #pragma unroll
         for (int i = 0; i < 3; ++i) dP[i] = PR[k][i] - PL[k][i];
         cross3(rL[k], rR[k], cr);
-        d3[k] = det3cols(cr, rL[k], rR[k]);
+        d3[k] = cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2];       // det(cr, rL, rR) = cr . (rL x rR) = |cr|^2
         t1[k] = det3cols(cr, dP, rR[k]);
         t2[k] = -det3cols(cr, rL[k], dP);
     }
