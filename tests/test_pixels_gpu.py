@@ -86,6 +86,52 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo):
             assert np.linalg.eigvalsh(Ps / (dg[:, :, None] * dg[:, None, :])).min() > 0
 
 
+def test_the_fifteen_state_filter_takes_the_same_updates():
+    """north_star's literal filter has 15 error states (per-corner 2 x 15 Jacobians): N = 18 without the gravity block.  The reprojection-row
+    update (left, stereo) and the corner-row update through the N = 15 kernels against the N = 15 oracle, standard gates."""
+    B, M, dialect, n = 192, 4, 0, 15
+    prm = capi.default_params(dialect)
+    prm.marker_size = SIZE
+    nom0, _, P, prev = synth.initial_state(0, B, list(prm.p0_diag), n, mixed_cov=True)
+    truth, _, ids, left, right = pixel_scene(B, M, prm, SIZE, seed=31, noise=5e-4, nominal=nom0)
+    rng = np.random.default_rng(32)
+    nom = truth.copy()
+    nom[:, 0:3] += rng.normal(0, 0.004, (B, 3))
+    nom = r32(nom)
+    rot, P, left, right = r32(synth.q2R(nom[:, 6:10]).reshape(B, 9)), r32(P), r32(left), r32(right)
+    assert P.shape[1:] == (n, n)
+    vp = oc.vision_params()
+    corners = np.zeros((B, M, 4, 3))
+    for b in range(B):
+        for m in range(M):
+            if ids[b, m] >= 0:
+                corners[b, m] = oc.refraction_triangulate(vp, left[b, m], right[b, m])
+    for what in ("pixels left", "pixels stereo", "corners"):
+        eng = OracleEngine(B, dialect, n)
+        eng.set_state(nom, rot, P, prev)
+        if what == "corners":
+            ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids, corners, SIZE, capi.MODE_STACKED)
+        else:
+            ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, right if "stereo" in what else None, SIZE, prm.r_pix)
+        assert ok.all()
+        for dtype in (64, 32):
+            with BatchedFilter(B, prm, dtype=dtype, nstate=n) as flt:
+                flt.set_state(nom, rot, P, prev)
+                if what == "corners":
+                    flt.correct_corners(ids, left, right, capi.VIS_REFRACTIVE, capi.MODE_STACKED)
+                else:
+                    flt.correct_pixels(ids, left, right if "stereo" in what else None)
+                got = flt.get_state()
+                assert (flt.applied() == ok).all()
+            e = parity_errors(got, eng.get_state())
+            print(f"[parity] N = 15, {what} fp{dtype}: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} cov block-wise {e['cov_block']:.2e}")
+            if dtype == 64:
+                assert e["literal"] < 1e-6 and e["sigma"] < 1e-6 and e["cov_block"] < 1e-6 and e["asym"] == 0
+            else:
+                assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL
+                assert e["cov"] <= COV_TOL and e["cov_block"] <= COV_BLOCK_TOL and e["asym"] == 0
+
+
 def test_tilted_port_takes_the_general_normal_path():
     """The reference's configuration has the port square to the camera (normal_vector 0 0 1: paramconfig.yml:39-42, refractinfo.yml:10-13)
     and the kernels have a form specialised for it; a port tilted by two degrees goes through the general form: reprojection rows (left,
