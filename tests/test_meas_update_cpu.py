@@ -127,3 +127,54 @@ def test_float32_records_keep_the_posterior_where_the_textbook_form_loses_it():
     print(f"[update] float32 records, 118 rows: one-shot form {worst_direct:.2e} block-wise, P - K H P in float32 {worst_textbook:.2e}")
     assert worst_direct < 2e-6
     assert worst_textbook > 50 * worst_direct
+
+
+def test_constant_row_matrix_sums_expand_to_the_per_corner_sums():
+    """csrc/ekf_meas.hpp::PixAcc::add_corner_const / expand_const: when every corner's rows share one N' (the corner-position update:
+    N' = R_IL' R_IL), S_aa, S_ac and S_cc are linear in the count, sum r and sum r r'.  The formulas of expand_const transcribed,
+    against the per-corner accumulation (add_corner: S_ac += N' [r]x, S_cc += [r]x' N' [r]x)."""
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(3, 3))
+    Nm = A @ A.T
+
+    def cross_mat(r):
+        return np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+
+    rs, W, cnt = np.zeros(3), np.zeros((3, 3)), 0
+    Saa, Sac, Scc = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros((3, 3))
+    for _ in range(11):
+        r = rng.normal(size=3)
+        B = cross_mat(r)
+        Saa += Nm; Sac += Nm @ B; Scc += B.T @ Nm @ B
+        rs += r; W += np.outer(r, r); cnt += 1
+    n00, n01, n02, n11, n12, n22 = Nm[0, 0], Nm[0, 1], Nm[0, 2], Nm[1, 1], Nm[1, 2], Nm[2, 2]
+    w00, w01, w02, w11, w12, w22 = W[0, 0], W[0, 1], W[0, 2], W[1, 1], W[1, 2], W[2, 2]
+    Scc_x = np.array([[n11 * w22 - 2 * n12 * w12 + n22 * w11, -n01 * w22 + n12 * w02 + n02 * w12 - n22 * w01, n01 * w12 - n11 * w02 - n02 * w11 + n12 * w01],
+                      [0, n00 * w22 - 2 * n02 * w02 + n22 * w00, -n00 * w12 + n01 * w02 + n02 * w01 - n12 * w00],
+                      [0, 0, n00 * w11 - 2 * n01 * w01 + n11 * w00]])
+    Scc_x = Scc_x + np.triu(Scc_x, 1).T
+    assert np.abs(Scc_x - Scc).max() < 1e-12 * np.abs(Scc).max()
+    assert np.abs(Nm @ cross_mat(rs) - Sac).max() < 1e-12 * np.abs(Sac).max()
+    assert np.abs(cnt * Nm - Saa).max() < 1e-12 * np.abs(Saa).max()
+
+
+def test_square_port_row_is_the_general_row():
+    """csrc/ekf_meas.hpp::pixel_fold_marker, NZ: with the port normal (0, 0, 1) the reprojection row
+    a_r = alpha e'M + beta n'M + k (M_r - uv_r M_z),  alpha = c1 g_e, beta = -(c2 g_e + k g_n), g = (unit_r - uv_r unit_z) / D_z,
+    loses its two k uv_r M_z terms:  a_r = c1 e_r (e'M) + k M_r - c2 e_r M_z  (D_z = 1, e_z = 0)."""
+    rng = np.random.default_rng(5)
+    M = rng.normal(size=(3, 3))
+    n = np.array([0.0, 0.0, 1.0])
+    for _ in range(50):
+        lat = np.array([rng.normal(), rng.normal(), 0.0])
+        rho = np.linalg.norm(lat)
+        kk, c1, c2 = rng.uniform(0.3, 1.5), rng.normal(), rng.normal()
+        e = lat / rho
+        Dz = n[2] + kk * lat[2]
+        uv = (n[:2] + kk * lat[:2]) / Dz
+        eM, nM = e @ M, n @ M
+        for r in range(2):
+            ge, gn = (e[r] - uv[r] * e[2]) / Dz, (n[r] - uv[r] * n[2]) / Dz
+            general = ge * c1 * eM - (c2 * ge + kk * gn) * nM + kk / Dz * (M[r] - uv[r] * M[2])
+            square = c1 * e[r] * eM + kk * M[r] - c2 * e[r] * M[2]
+            assert np.abs(general - square).max() < 1e-13 * max(1.0, np.abs(general).max())
