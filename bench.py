@@ -486,6 +486,7 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
         pixels_m4      4 marker slots, left camera: 32 reprojection rows per filter and frame
         pixels_m16     16 marker slots (BASELINE config 5's shape): 128 rows, and the stereo form (256 rows) as one launch time
         corners_m4     fbus_ekf_correct_corners_dev (stereo corners triangulated through the port on the device, 12 rows per marker)
+        pixels_m4_n15  as pixels_m4 with north_star's literal 15-state filter (N = 18 without the gravity block: 608-byte records)
     Scene: a wall of 16 markers 1.2 - 1.8 m in front of the port, image points = flat-port projections of the true corners +
     noise (synth.pixel_wall_scene), filters at rest.  Reported per case: EKF steps/s, ms per bench step, launch time of the update
     (HIP events on the handle's stream), its algorithmic bytes (2 x 796 + 68 M) and their fraction of 8 TB/s, and --
@@ -496,7 +497,8 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
     out = {}
     prof = _pixels_sq_profile()
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-    for name, slots, kind in (("pixels_m4", 4, "pixels"), ("pixels_m16", 16, "pixels"), ("corners_m4", 4, "corners")):
+    for name, slots, kind, nstate in (("pixels_m4", 4, "pixels", 18), ("pixels_m16", 16, "pixels", 18), ("corners_m4", 4, "corners", 18),
+                                      ("pixels_m4_n15", 4, "pixels", 15)):
         prm = capi.default_params(capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP)
         size = 0.15
         prm.marker_size = size
@@ -507,7 +509,7 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
         d_ids, d_left, d_right = torch.from_numpy(ids).to(dev), f32(left), f32(right)
         nvis = float((ids >= 0).sum(axis=1).mean())
         prev0 = np.zeros(B, np.int32)
-        with BatchedFilter(B, prm, device=local_rank, order_streams=False) as flt:
+        with BatchedFilter(B, prm, device=local_rank, order_streams=False, nstate=nstate) as flt:
             flt.set_state(nom, rot, None, prev0)
             flt.reset_cov()
             torch.cuda.synchronize()
@@ -537,9 +539,9 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
             finite = bool(np.isfinite(flt.get_state()[0]).all())
             us = u_ms / max(u_n, 1) * 1e3
             rows = nvis * (8 if kind == "pixels" else 12)
-            bytes_api = 2 * 796 + 68 * slots
+            bytes_api = 2 * 4 * (27 + nstate * (nstate + 1) // 2 + 1) + 68 * slots      # record round trip + the slot's image points
             blk = {"value": B * STEPS_PER_BENCH_STEP * steps / el, "unit": "EKF steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-                   "batch": B, "marker_slots": slots, "markers_in_view_mean": nvis, "rows_per_filter_and_frame": rows,
+                   "batch": B, "nstate": nstate, "marker_slots": slots, "markers_in_view_mean": nvis, "rows_per_filter_and_frame": rows,
                    "update": "fbus_ekf_correct_pixels_dev (left camera)" if kind == "pixels" else "fbus_ekf_correct_corners_dev (refractive, stacked)",
                    "update_avg_launch_us": us, "update_launches": u_n, "predict_avg_launch_us": p_ms / max(p_n, 1) * 1e3,
                    "update_bytes_per_filter_api": bytes_api, "update_algorithmic_GBs": bytes_api * B / (us * 1e-6) / 1e9,
