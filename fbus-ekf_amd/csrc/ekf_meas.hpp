@@ -99,47 +99,34 @@ __device__ __forceinline__ void md_rcp_n(const double (&x)[NQ], double (&y)[NQ])
         for (int q = 0; q < NQ; ++q) y[q] = __builtin_fma(y[q], h[q], y[q]);
     }
 }
-template <int NS, int NQ> __device__ __forceinline__ void pe_rsq_n(const double (&x)[NQ], double (&y)[NQ]) { md_rsq_n<NS, NQ>(x, y); }
-template <int NS, int NQ> __device__ __forceinline__ void pe_rcp_n(const double (&x)[NQ], double (&y)[NQ]) { md_rcp_n<NS, NQ>(x, y); }
-template <int NS, int NQ> __device__ __forceinline__ void pe_rsq_n(const float (&x)[NQ], float (&y)[NQ])
-{
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) y[q] = __builtin_amdgcn_rsqf(x[q]);
-}
-template <int NS, int NQ> __device__ __forceinline__ void pe_rcp_n(const float (&x)[NQ], float (&y)[NQ])
-{
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) y[q] = __builtin_amdgcn_rcpf(x[q]);
-}
 
 // the port equation  rho = L(t) = d_air t + d_glass tan(theta_glass) + zw tan(theta_water),  t = tan(theta_air)   (vision_device.hpp)
 // with s = sin(theta_air) = t r, r = (1 + t^2)^-1/2, icg = 1 / cos(theta_glass) = (1 - a0^2 s^2)^-1/2, icw likewise, G = d_glass a0,
 // W = zw a1:   L = d_air t + s (G icg + W icw),   L' = d_air + r^3 (G icg^3 + W icw^3),
 //              L'' = 3 r^5 ( -t (G icg^3 + W icw^3) + s r (G a0^2 icg^5 + W a1^2 icw^5) )   (< 0: L is concave)
-// dt: HALLEY's step  -2 f L' / (2 L'^2 - f L''),  f = L - rho  (cubic convergence: from the measured ray, a few 1e-3 .. 1e-2 off,
-// one step in fp32 leaves ~1e-6 and one more in double the rounding error; tools/emul_meas_fold.py halley).  The denominator is
+// dt: HALLEY's step  -2 f L' / (2 L'^2 - f L''),  f = L - rho  (cubic convergence; tests/test_port_solver_cpu.py).  The denominator is
 // kept >= L'^2 (far below the root f L'' > 0 could eat it: the step then is at most twice Newton's).
 // Lzt, Ltt: d L_z / dt, d L_t / dt (to carry L_z, L_t along the step to first order).
 template <typename S, int NQ> struct PortEvalN { S Lt[NQ], Lz[NQ], dt[NQ], Ltt[NQ], Lzt[NQ]; };
 template <int NS, typename S, int NQ>
 __device__ __forceinline__ void port_eval_n(S a0, S a1, S d_air, S G, const S (&W)[NQ], const S (&rho)[NQ], const S (&t)[NQ],
-                                            PortEvalN<S, NQ>& o)
+                                            PortEvalN<S, NQ>& o)          // (S = double; the round's fp32 first step is gone)
 {
     const S a02 = a0 * a0, a12 = a1 * a1;
     S x[NQ], r[NQ], s_[NQ], s2[NQ], icg[NQ], icw[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) x[q] = S(1) + t[q] * t[q];
-    pe_rsq_n<NS, NQ>(x, r);
+    md_rsq_n<NS, NQ>(x, r);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) s_[q] = t[q] * r[q];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) s2[q] = s_[q] * s_[q];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) x[q] = S(1) - a02 * s2[q];
-    pe_rsq_n<NS, NQ>(x, icg);
+    md_rsq_n<NS, NQ>(x, icg);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) x[q] = S(1) - a12 * s2[q];
-    pe_rsq_n<NS, NQ>(x, icw);
+    md_rsq_n<NS, NQ>(x, icw);
     S icg2[NQ], icw2[NQ], g1[NQ], w1[NQ], g3[NQ], w3[NQ], q3[NQ], r2[NQ], r3[NQ], L[NQ], f[NQ], Lt2[NQ], den[NQ], h[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { icg2[q] = icg[q] * icg[q]; icw2[q] = icw[q] * icw[q]; g1[q] = G * icg[q]; w1[q] = W[q] * icw[q]; r2[q] = r[q] * r[q]; }
@@ -155,7 +142,7 @@ __device__ __forceinline__ void port_eval_n(S a0, S a1, S d_air, S G, const S (&
     for (int q = 0; q < NQ; ++q) o.Ltt[q] = S(3) * r3[q] * r2[q] * h[q];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) den[q] = fmax(S(2) * Lt2[q] - f[q] * o.Ltt[q], Lt2[q]);
-    pe_rcp_n<NS, NQ>(den, h);
+    md_rcp_n<NS, NQ>(den, h);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) o.dt[q] = -S(2) * f[q] * o.Lt[q] * h[q];
 }
