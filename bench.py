@@ -51,6 +51,8 @@ STEPS_PER_PATTERN = sum(PATTERN) + len(PATTERN)         # 23 EKF steps per filte
 PATTERNS_PER_STEP = 10              # one bench step = 1 s of sensor time = 30 camera frames
 STEPS_PER_BENCH_STEP = STEPS_PER_PATTERN * PATTERNS_PER_STEP      # 230 EKF steps per filter
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PIXELS_SQ = "r05_pixels_sq.json"
+PROFILE_ROUND = 5                   # only profiles/r05_* digests are quoted as `traffic` (collected on this round's kernels)
 # packed record round trip + inputs (what the per-call API implies)
 PREDICT_BYTES_API = 2 * 796 + 28
 CORRECT_BYTES_API = lambda M: 2 * 796 + 32 * M
@@ -132,14 +134,14 @@ def launch_ranks(args):
 # helpers
 # ------------------------------------------------------------------------------------------------
 def pmc_traffic(batch, args, world, kernel="predict"):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r02_digest*.json, written
-    by tools/profile_digest.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE doubled on gfx950 as
-    MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself.  The digest is only quoted when
-    it was taken on THIS configuration (batch, dialect, markers, mode, eager launches, one GPU); otherwise None."""
+    """HBM-side bytes per launch of a kernel from THIS round's committed rocprofv3 PMC passes (profiles/r05_digest_b<batch>.json,
+    written by tools/profile_digest.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE doubled on gfx950 as
+    MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself.  The digest is only quoted when it was taken
+    on THIS configuration (batch, dialect, markers, mode, eager launches, one GPU) and in THIS round (PROFILE_ROUND: a digest of an
+    earlier round's kernels is never quoted -- `traffic` is null then and `legs_skipped` says so)."""
     if world != 1 or args.graphs:
         return None, None
-    # this round's digest, else round 3's (same per-call predict / correct kernels: unchanged since); never round 2's kernels
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_digest_b{batch}.json") for r in (4, 3)) if os.path.exists(q)), "")
+    path = os.path.join(ROOT, "profiles", f"r{PROFILE_ROUND:02d}_digest_b{batch}.json")
     try:
         d = json.load(open(path))
         cfg = d.get("_config", {})
@@ -235,10 +237,10 @@ def cpu_baseline(args, seconds):
     m = capi.MODE_STACKED if args.mode == "stacked" else capi.MODE_NEAREST
     same_v, same_1, same_s = leg(d, m, seconds * 0.5)
     flags = "-march=native" if native else "generic x86-64"
-    # "if Eigen3 is found on the box, additionally build an Eigen-typed twin" -- say whether it was
-    eigen_dirs = [d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/rocm/include/eigen3") if os.path.isdir(os.path.join(d, "Eigen"))]
-    eigen = (f"Eigen headers at {eigen_dirs[0]}, but no Eigen-typed twin is built: the dense C port stands in for the reference's "
-             "Eigen path") if eigen_dirs else "Eigen3 not found on this box (the reference's own build needs it): no Eigen-typed twin, the dense C port stands in"
+    # SURVEY.md 8(d) allowed an optional Eigen-typed twin "if Eigen3 is found on the box".  There is none and none is promised: Eigen is
+    # in neither image (dev container, GPU box), so a twin could be neither compiled nor checked anywhere this repository runs; the
+    # dense C port (same operations, same order, plain loops instead of Eigen's expression templates) is the CPU baseline.
+    eigen = "no Eigen-typed twin (Eigen3 is not in the image; nothing here could compile or check one): the dense C port is the baseline"
     return {"value": ref_v, "unit": "EKF steps/s", "cores": cores, "kind": "port", "eigen": eigen,
             "path": "reference CPU path restated: C++ dialect, UpdateCovariance+UpdateNominalState (filter.cpp:533-616) per "
                     "IMU sample, ObservationUpdate (filter.cpp:622-741) per frame = nearest marker with hysteresis, 7 rows, LDLT",
@@ -429,7 +431,7 @@ def fp64_leg(torch, dev, local_rank, args, capi):
     pn_ms, pn_n = w.flt.timing_read(capi.KERNEL_PREDICT_N)
     c_ms, c_n = w.flt.timing_read(capi.KERNEL_CORRECT)
     w.flt.timing_enable(False)
-    tr, src = pmc_traffic_named(f"r04_digest_f64_b{w.B}.json", w.B, args, "predict_kernel<double, 18")
+    tr, src = pmc_traffic_named(f"r{PROFILE_ROUND:02d}_digest_f64_b{w.B}.json", w.B, args, "predict_kernel<double, 18")
     roof, corr = roofline_block(w, p_ms, p_n, c_ms, c_n, tr, src)
     roof.pop("note")
     # (round 4) the same frames as ONE launch each: frame2_kernel<double> -- the parked K-step predict loop + the row-split passes
@@ -457,7 +459,7 @@ def fp64_leg(torch, dev, local_rank, args, capi):
         p_ms, p_n = w2.flt.timing_read(capi.KERNEL_PREDICT)
         c_ms, c_n = w2.flt.timing_read(capi.KERNEL_CORRECT)
         w2.flt.timing_enable(False)
-        tr2, src2 = pmc_traffic_named(f"r04_digest_f64_b{w2.B}.json", w2.B, args, "predict_kernel<double, 18")
+        tr2, src2 = pmc_traffic_named(f"r{PROFILE_ROUND:02d}_digest_f64_b{w2.B}.json", w2.B, args, "predict_kernel<double, 18")
         roof2, corr2 = roofline_block(w2, p_ms, p_n, c_ms, c_n, tr2, src2)
         roof2.pop("note")
         roof2.update({"batch": w2.B, "records_MB": w2.B * 1600 / 1e6, "input_patterns": 2, "steps": steps2,
@@ -471,9 +473,9 @@ def fp64_leg(torch, dev, local_rank, args, capi):
 
 
 def _pixels_sq_profile():
-    """the committed SQ-counter digest of the pixel-row kernel (tools/r4_pixels_prof.sh -> profiles/r04_pixels_sq.json)"""
+    """this round's committed SQ-counter digest of the pixel-row kernel (tools/r5_pixels_prof.sh -> profiles/r05_pixels_sq.json)"""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r04_pixels_sq.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", PIXELS_SQ)))
     except Exception:
         return None
 
@@ -491,7 +493,7 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
     noise (synth.pixel_wall_scene), filters at rest.  Reported per case: EKF steps/s, ms per bench step, launch time of the update
     (HIP events on the handle's stream), its algorithmic bytes (2 x 796 + 68 M) and their fraction of 8 TB/s, and --
     these kernels are VALU-bound, that fraction is not what limits them -- the VALU issue fraction = wave-level VALU instructions of
-    one launch (SQ_INSTS_VALU, committed rocprofv3 pass profiles/r04_pixels_sq.json) / (launch time x SIMDs x clock / 4)."""
+    one launch (SQ_INSTS_VALU, committed rocprofv3 pass profiles/r05_pixels_sq.json) / (launch time x SIMDs x clock / 4)."""
     from fbus_ekf import BatchedFilter, synth
     torch.cuda.empty_cache()
     out = {}
@@ -559,7 +561,7 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
                 if prof and int(prof.get("batch", 0)) == B and int(prof.get("marker_slots", 0)) == slots:
                     insts, mhz = float(prof["counters_per_launch"]["SQ_INSTS_VALU"]), float(prof.get("clock_MHz") or 2400.0)
                     simds = int(prof.get("simds", 1024))
-                    blk.update({"valu_insts_per_launch": insts, "clock_MHz": mhz, "source": "profiles/r04_pixels_sq.json",
+                    blk.update({"valu_insts_per_launch": insts, "clock_MHz": mhz, "source": "profiles/" + PIXELS_SQ,
                                 "valu_issue_frac": insts / (us * 1e-6 * simds * mhz * 1e6 / 4.0),
                                 "valu_issue_frac_profiled_run": prof.get("valu_issue_frac_kernel_trace"),
                                 "sq_active_inst_valu_over_wave_cycles": prof.get("SQ_ACTIVE_INST_VALU_over_SQ_WAVE_CYCLES")})

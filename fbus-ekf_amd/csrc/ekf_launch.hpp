@@ -18,6 +18,10 @@ struct LaunchPolicy {
     int simds = 1024;               // SIMDs of the device (CUs x 4): one wave per SIMD = `simds` 64-filter tiles
     int two_wave_min_b = 1024 * 64 + 1;   // from this many filters on a launch has more waves than SIMDs: the <= 256-register forms
     bool meas_vec = true;           // measurement inputs of correct as 16-byte loads where legal
+    int policy_b = 0;               // fbus_ekf_set_policy_batch: the batch the kernel-FORM choice is keyed on (0 = the launch's own B)
+    // the <= 256-register forms (row-split correct, parked predict_n, frame2_kernel): chosen by the JOB's size, not the shard's, so
+    // that every shard layout of one job runs the same instruction streams (the forms agree to 1 ulp only)
+    bool two_wave(int B) const { return (policy_b > 0 ? policy_b : B) >= two_wave_min_b; }
 };
 
 // K == 1: the streamed per-call kernel (`policy`: 0 = nt loads and stores, 1 = default-policy loads, 2 = default loads

@@ -7,7 +7,7 @@
 //                             the marker origin:  X_k = R_IL R'(P_m + R_m c_k - p - R P_IL),  H = (d pi/d X)[ -R_IL R' | R_IL [R'(c_w - p)]x ]
 //   the update                matlab/MeasureUpdate.m:84-102 ; filter.cpp:709-739   K = P H'(H P H' + R)^-1, dx = K r, P = (I - K H) P
 //
-// What round 3 had (ekf_kernels.hpp::correct_pixels_kernel, kept for the fp64 / Joseph verification paths) and why it is replaced:
+// What round 3 had (ekf_kernels.hpp::correct_pixels_kernel; deleted in round 4, commit fdeea42) and why it was replaced:
 //   * fp32 throughout.  128-256 rows at sigma_pix = 1e-3 shrink the pose variances by 4-5 decades in ONE update; P - k (P h')(P h')'
 //     then cancels to 1e-5 of its terms, the 6 x 6 information matrix accumulated in fp32 is perturbed by eps * cond(Lam), and a
 //     predicted image point known to 6e-8 moves a weakly observed block (gravity, sigma 10) by 5e-5 of itself:

@@ -119,7 +119,7 @@ struct fbus_ekf {
     LaunchPolicy lp;                  // SIMD count, two-wave threshold, vector measurement loads (handed to the launchers)
     int cus = 256;                    // hipDeviceProp::multiProcessorCount (FBUS_FAKE_SIMDS / 4 overrides it)
     size_t l2_bytes = (size_t)4 << 20;        // hipDeviceProp::l2CacheSize (one XCD's L2)
-    size_t mall_bytes = (size_t)256 << 20;    // memory-side Infinity Cache: not exposed by the runtime; 256 MiB per 1024 SIMDs, FBUS_MALL_MB
+    size_t mall_bytes = (size_t)256 << 20;    // memory-side Infinity Cache: not exposed by the runtime; 256 MiB (MI300X / MI355X), FBUS_MALL_MB
     int policy_batch = 0;             // fbus_ekf_set_policy_batch: the batch the kernel-FAMILY choice is keyed on (0 = this handle's)
     bool records_warm = false;        // the last kernel stored the records with the default cache policy (they sit in L2)
     int big_records_mb = 56;          // records larger than this run the predict with default-policy loads and stores (FBUS_BIG_RECORDS_MB)
@@ -631,6 +631,10 @@ template <typename T, int N, int D>
 int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, int geometry,
                              int mode, const uint8_t* skip)
 {
+    // the kernel fetches a slot's image points with 16-byte loads (a slot is 32 / 48 contiguous bytes): the arrays must start on a
+    // 16-byte boundary -- any allocation does; a view offset by one to three elements does not and is refused, not read unaligned
+    if (((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right)) & 15) != 0)
+        return fail(h, FBUS_ERR_INVALID, "fbus_ekf_correct_corners: left / right must be 16-byte aligned device pointers");
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
     // triangulation and fold in double, non-cancelling update (ekf_meas.hpp); records written through (sc1) as correct_kernel's
     h->records_warm = h->warm_after_correct;
@@ -646,6 +650,8 @@ int launch_correct_corners_t(fbus_ekf_t h, int M, const int32_t* ids, const void
 template <typename T, int N, int D>
 int launch_correct_pixels_t(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, const uint8_t* skip)
 {
+    if (((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right)) & 15) != 0)      // 16-byte loads, see correct_corners
+        return fail(h, FBUS_ERR_INVALID, "fbus_ekf_correct_pixels: left / right must be 16-byte aligned device pointers");
     const int ev = timing_begin(h, FBUS_KERNEL_CORRECT_CORNERS);
     // double-precision fold + non-cancelling update (ekf_meas.hpp), both record types, either covariance form (the form is
     // symmetric by construction and subtracts nothing on the rows the measurement shrinks: what Joseph's form is chosen for)
@@ -825,22 +831,27 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (!h) return FBUS_ERR_NOMEM;
     h->B = batch;
     h->Bs = (batch + 63) / 64 * 64;
-    {   // launch policy from the device: CU count -> SIMDs, L2 size; the memory-side cache is not exposed (256 MiB per 1024 SIMDs)
+    {   // launch policy from the device: CU count -> SIMDs, L2 size; the memory-side cache is not exposed (256 MiB assumed)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
             if (prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
             if (prop.l2CacheSize > 0) h->l2_bytes = (size_t)prop.l2CacheSize;
         }
         int simds = h->cus * 4;
-        if (const char* e = std::getenv("FBUS_FAKE_SIMDS")) { const int v = std::atoi(e); if (v >= 4) { simds = v / 4 * 4; h->cus = simds / 4; } }
+        bool fake = false;
+        if (const char* e = std::getenv("FBUS_FAKE_SIMDS")) { const int v = std::atoi(e); if (v >= 4) { simds = v / 4 * 4; h->cus = simds / 4; fake = true; } }
         h->lp.simds = simds;
         h->lp.two_wave_min_b = simds * 64 + 1;
         if (const char* e = std::getenv("FBUS_TWO_WAVE_MIN_B")) h->lp.two_wave_min_b = std::atoi(e);
         h->lp.meas_vec = std::getenv("FBUS_NO_MEAS_VEC") == nullptr;
-        h->mall_bytes = ((size_t)256 << 20) / 1024 * (size_t)simds;
+        // 256 MiB is MI355X's (and MI300X's) Infinity Cache whatever the CU count of the SKU: not scaled with the device; only the
+        // test knob FBUS_FAKE_SIMDS (a pretended smaller chip) scales it down with the SIMD count, FBUS_MALL_MB sets it outright
+        h->mall_bytes = (size_t)256 << 20;
+        if (fake && simds < 1024) h->mall_bytes = ((size_t)256 << 20) / 1024 * (size_t)simds;
         if (const char* e = std::getenv("FBUS_MALL_MB")) { const long v = std::atol(e); if (v > 0) h->mall_bytes = (size_t)v << 20; }
         // records larger than this leave the one-round, cache-resident regime (measured crossover 52-60 MB on 1024 SIMDs, 4.1)
-        h->big_records_mb = (int)(56L * simds / 1024);
+        // (a cache-capacity effect: the same 56 MB on any part with a 256 MiB Infinity Cache; scaled only for a pretended chip)
+        h->big_records_mb = (fake && simds < 1024) ? (int)(56L * simds / 1024) : 56;
     }
     if (const char* e = std::getenv("FBUS_BIG_RECORDS_MB")) h->big_records_mb = std::atoi(e);
     if (const char* e = std::getenv("FBUS_WARM_AFTER_CORRECT")) h->warm_after_correct = std::atoi(e) != 0;
@@ -919,6 +930,7 @@ int fbus_ekf_set_policy_batch(fbus_ekf_t h, int total_filters)
 {
     if (!h || total_filters < 0) return FBUS_ERR_INVALID;
     h->policy_batch = total_filters;
+    h->lp.policy_b = total_filters;      // the two-wave (<= 256-register) kernel forms follow the job's size too (ekf_launch.hpp)
     return FBUS_OK;
 }
 
@@ -1150,6 +1162,20 @@ int fbus_ekf_gather_group(fbus_ekf_t* handles, int n, void* const* out_dev, cons
 {
     // the gather of ALL ranks of one process in one RCCL group (a single thread may not issue the ranks' collectives one by one)
     if (!handles || !out_dev || n < 1) return FBUS_ERR_INVALID;
+    // everything fbus_ekf_gather would refuse is refused HERE, before the group is opened: a rank that fails inside an open group
+    // leaves the ranks in front of it with an incomplete collective enqueued, and ncclGroupEnd would then hang their streams
+    for (int k = 0; k < n; ++k) {
+        fbus_ekf_t h = handles[k];
+        if (!h) return FBUS_ERR_INVALID;
+        if (!out_dev[k]) return fail(h, FBUS_ERR_INVALID, "fbus_ekf_gather_group: out_dev[k] is NULL");
+        if (!h->comm) return fail(h, FBUS_ERR_INVALID, "fbus_ekf_gather_group: a handle without communicator (fbus_ekf_comm_init_all first)");
+        if (h->comm_world != n || h->comm_rank != k)
+            return fail(h, FBUS_ERR_INVALID, "fbus_ekf_gather_group: handles[k] is not rank k of an n-rank communicator");
+        if (bytes_of_rank && bytes_of_rank[k] != h->rec_bytes)
+            return fail(h, FBUS_ERR_INVALID, "fbus_ekf_gather_group: bytes_of_rank[k] is not handles[k]'s record size");
+        if (!bytes_of_rank && h->rec_bytes != handles[0]->rec_bytes)
+            return fail(h, FBUS_ERR_INVALID, "fbus_ekf_gather_group: ragged shards need bytes_of_rank");
+    }
     Rccl& r = rccl();
     if (!r.ok) return fail(handles[0], FBUS_ERR_UNSUPPORTED, r.err);
     int rc = r.GroupStart();

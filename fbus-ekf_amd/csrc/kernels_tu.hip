@@ -51,7 +51,7 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
         // kernel -- the resident loop spilled 580 bytes per lane; the parked form spills 68 (N = 18) / 0 (N = 15).
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
                            K, accel, gyro, dt, dt_stride, dc);
-    } else if (B >= lp.two_wave_min_b) {
+    } else if (lp.two_wave(B)) {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
                            K, accel, gyro, dt, dt_stride, dc);
     } else {
@@ -80,7 +80,7 @@ void launch_correct_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
                        mode, skip, applied, dc)
     // fp32, stacked, simple form: from 1025 waves on (two on some SIMDs) the row-split instantiation (194 registers) is the
     // faster one -- see the LEAN comment in correct_kernel
-    if (sizeof(T) == 4 && joint && !joseph && B >= lp.two_wave_min_b) {
+    if (sizeof(T) == 4 && joint && !joseph && lp.two_wave(B)) {
         hipLaunchKernelGGL((correct_kernel<T, N, D, COV_SIMPLE, true, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, M, ids,
                            pos, quat, mode, skip, applied, dc);
         return;
@@ -116,7 +116,7 @@ void launch_frame_k(hipStream_t s, T* recs, int B, int K, const T* accel, const 
     // (Joseph form, nearest marker) is not built as a fused kernel (7 Joseph rank-2 passes with the record resident
     // spilled 280 bytes per lane): fbus_ekf.hip runs that combination as predict_n + correct
     // stacked mode, simple form, > 1024 waves: the two-waves-per-SIMD kernel (see frame2_kernel)
-    if (joint && !joseph && B >= lp.two_wave_min_b) {
+    if (joint && !joseph && lp.two_wave(B)) {
         hipLaunchKernelGGL((frame2_kernel<T, N, D>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, dt_stride, M, ids,
                            pos, quat, skip, applied, dc);
         return;

@@ -362,9 +362,14 @@ int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* la
  * camera (right == NULL: 2 rows per corner, 128 rows at 16 markers) or in both cameras (4 rows per corner).
  * h = pi(X_k(x)): X_k = R_IL R'(P_m + R_m c_k - p - R P_IL) the corner in the left camera frame (the geometry of
  * MeasureUpdate.m:67,72-73 with the corner in place of the marker origin), pi = the flat-port forward projection
- * (air -> glass -> water, the inverse of the ray construction of vision.cpp:505-552, solved by Newton in the plane of the port
- * normal and the point).  Per-corner Jacobian rows (2 x N) = d pi/dX (closed form) x [ -R_IL R' | R_IL [R'(c_w - p)]x ];
- * all rows of all visible markers at one linearisation point, folded into the 6x6 information matrix.
+ * (air -> glass -> water, the inverse of the ray construction of vision.cpp:505-552, in the plane of the port normal and the
+ * point: a closed-form thin-port start taken twice, then ONE Halley step in double -- two for fp64 records --; no iteration).
+ * Per-corner Jacobian rows (2 x N) = d pi/dX (closed form) x [ -R_IL R' | R_IL [R'(c_w - p)]x ];
+ * all rows of all visible markers at one linearisation point, folded into the 6x6 information matrix; the update is the one-shot
+ * form  P(J,:) <- G P(J,:),  P_rr -= x_a' S^-1 x_c  (symmetric by construction, nothing cancels on the rows the measurement
+ * shrinks).  fbus_params::cov_form DOES NOT APPLY to this entry point nor to fbus_ekf_correct_corners: FBUS_COV_JOSEPH selects
+ * nothing here (the one-shot form already has what Joseph's form is chosen for); it governs fbus_ekf_correct only.
+ * left / right must be 16-byte aligned (any allocation is): the slots are fetched with 16-byte loads, FBUS_ERR_INVALID otherwise.
  * ids (B, M), left / right (B, M, 8) = x0 y0 .. x3 y3 (the column layout of corners.txt, vision.cpp:111-119). */
 int fbus_ekf_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right /* may be NULL */,
                             const uint8_t* skip);

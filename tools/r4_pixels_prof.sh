@@ -1,7 +1,8 @@
 #!/bin/bash
 # round 4: the reprojection-row update at 65 536 filters x 16 marker slots -- launch times (the round-3 kernel it replaced: profiles/r04_pixels_times.txt),
 # kernel trace and SQ counters (own passes: --pmc never together with other trace domains).  TAG=$1 names the output directory.
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}" || exit 1
 TAG=${1:-a}
 export OUT=gpurun_out/r04/pix_$TAG
 mkdir -p $OUT
@@ -27,6 +28,7 @@ for sub in ("p1", "p2"):
         grid = int(r["Grid_Size"]) // 64
 per = {k: v[0] / v[1] for k, v in acc.items()}
 us = None
+name = None
 fs = sorted(glob.glob(f"{out}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 for r in csv.DictReader(open(fs[-1])) if fs else []:
     if "correct_pixels" in r["Name"]:
@@ -34,6 +36,8 @@ for r in csv.DictReader(open(fs[-1])) if fs else []:
 import shutil
 if fs: shutil.copy(fs[-1], f"{out}/kernel_stats.csv")
 mhz = (per.get("GRBM_GUI_ACTIVE", 0) / 8 / us) if us else None      # GRBM_GUI_ACTIVE sums the 8 XCDs
+if name is None:
+    raise SystemExit("no correct_pixels row in the kernel trace: nothing to summarise")
 d = {"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "batch": 65536, "marker_slots": 16, "camera": "left", "waves": grid, "simds": 1024,
      "avg_launch_us_kernel_trace": us, "clock_MHz": mhz,
      "SQ_INSTS_VALU_per_wave": per.get("SQ_INSTS_VALU", 0) / max(grid, 1), "counters_per_launch": per}
