@@ -485,10 +485,11 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
     Jacobians (fbus_ekf_correct_pixels_dev, csrc/ekf_meas.hpp) -- in the headline's mixed workload: the same 200 Hz + 30 Hz
     schedule (7 / 7 / 6 per-call predicts, then a camera frame; one bench step = 1 s of sensor time = 230 EKF steps per filter)
     with the correct launch replaced by
-        pixels_m4      4 marker slots, left camera: 32 reprojection rows per filter and frame
-        pixels_m16     16 marker slots (BASELINE config 5's shape): 128 rows, and the stereo form (256 rows) as one launch time
+        pixels_m4 / pixels_m4_stereo      4 marker slots, left camera (32 reprojection rows per filter and frame) / both cameras (64)
+        pixels_m16 / pixels_m16_stereo    16 marker slots (BASELINE config 5's shape): 128 / 256 rows
         corners_m4     fbus_ekf_correct_corners_dev (stereo corners triangulated through the port on the device, 12 rows per marker)
         pixels_m4_n15  as pixels_m4 with north_star's literal 15-state filter (N = 18 without the gravity block: 608-byte records)
+        fused_frame_*  the same frames through fbus_ekf_frame_meas_fused_dev: ONE launch per camera frame (K predicts + the update)
     Scene: a wall of 16 markers 1.2 - 1.8 m in front of the port, image points = flat-port projections of the true corners +
     noise (synth.pixel_wall_scene), filters at rest.  Reported per case: EKF steps/s, ms per bench step, launch time of the update
     (HIP events on the handle's stream), its algorithmic bytes (2 x 796 + 68 M) and their fraction of 8 TB/s, and --
@@ -499,15 +500,22 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
     out = {}
     prof = _pixels_sq_profile()
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-    for name, slots, kind, nstate in (("pixels_m4", 4, "pixels", 18), ("pixels_m16", 16, "pixels", 18), ("corners_m4", 4, "corners", 18),
-                                      ("pixels_m4_n15", 4, "pixels", 15)):
+    cases = (("pixels_m4", 4, "pixels", 18, False, False), ("pixels_m4_stereo", 4, "pixels", 18, True, False),
+             ("pixels_m16", 16, "pixels", 18, False, False), ("pixels_m16_stereo", 16, "pixels", 18, True, False),
+             ("corners_m4", 4, "corners", 18, True, False), ("pixels_m4_n15", 4, "pixels", 15, False, False),
+             ("fused_frame_pixels_m4", 4, "pixels", 18, False, True), ("fused_frame_pixels_m4_stereo", 4, "pixels", 18, True, True),
+             ("fused_frame_pixels_m16_stereo", 16, "pixels", 18, True, True), ("fused_frame_corners_m4", 4, "corners", 18, True, True))
+    scenes = {}
+    for name, slots, kind, nstate, stereo, fused in cases:
         prm = capi.default_params(capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP)
         size = 0.15
         prm.marker_size = size
-        nom, rot, ids, left, right = synth.pixel_wall_scene(B, slots, prm, size, seed=9, stereo=True)
+        if slots not in scenes:
+            scenes[slots] = synth.pixel_wall_scene(B, slots, prm, size, seed=9, stereo=True)
+        nom, rot, ids, left, right = scenes[slots]
         acc, gyr = synth.imu_samples(0, B, 0, sum(PATTERN), nom)
         d_acc, d_gyr = f32(acc), f32(gyr)
-        d_dt = torch.full((1,), 0.005, dtype=torch.float32, device=dev)
+        d_dt = torch.full((max(PATTERN),), 0.005, dtype=torch.float32, device=dev)
         d_ids, d_left, d_right = torch.from_numpy(ids).to(dev), f32(left), f32(right)
         nvis = float((ids >= 0).sum(axis=1).mean())
         prev0 = np.zeros(B, np.int32)
@@ -516,7 +524,7 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
             flt.reset_cov()
             torch.cuda.synchronize()
 
-            def update(stereo=False):
+            def update():
                 if kind == "pixels":
                     flt.correct_pixels(d_ids, d_left, d_right if stereo else None)
                 else:
@@ -526,49 +534,59 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
                 for r in range(PATTERNS_PER_STEP):
                     k = 0
                     for K in PATTERN:
-                        for j in range(K):
-                            flt.predict(d_acc[k + j], d_gyr[k + j], d_dt)
+                        if fused:                                    # one launch per camera frame: K predicts + the update, record resident
+                            flt.frame_meas(d_acc[k:k + K], d_gyr[k:k + K], d_dt[:K], d_ids, d_left, d_right if stereo else None,
+                                           capi.MEAS_PIXELS if kind == "pixels" else capi.MEAS_CORNERS, capi.VIS_REFRACTIVE, capi.MODE_STACKED)
+                        else:
+                            for j in range(K):
+                                flt.predict(d_acc[k + j], d_gyr[k + j], d_dt[:1])
+                            update()
                         k += K
-                        update()
-            el = timed(torch, bench_step, steps, warmup)          # throughput: no event brackets inside the timed region
+            el = timed(torch, bench_step, steps, warmup, before_timing=lambda: flt._keep.clear())   # throughput: no event brackets inside the timed region
             flt.timing_enable(True, stride=1)                     # launch times: one more step with a bracket around every launch
             flt.timing_reset()
             bench_step(0)
             flt.sync()
-            u_ms, u_n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
+            u_ms, u_n = flt.timing_read(capi.KERNEL_FRAME if fused else capi.KERNEL_CORRECT_CORNERS)
             p_ms, p_n = flt.timing_read(capi.KERNEL_PREDICT)
             applied = float(flt.applied().mean())
             finite = bool(np.isfinite(flt.get_state()[0]).all())
             us = u_ms / max(u_n, 1) * 1e3
-            rows = nvis * (8 if kind == "pixels" else 12)
-            bytes_api = 2 * 4 * (27 + nstate * (nstate + 1) // 2 + 1) + 68 * slots      # record round trip + the slot's image points
+            rows = nvis * ((16 if stereo else 8) if kind == "pixels" else 12)
+            rec_b = 4 * (27 + nstate * (nstate + 1) // 2 + 1)
+            bytes_api = 2 * rec_b + 68 * slots      # record round trip + the slot's image points
             blk = {"value": B * STEPS_PER_BENCH_STEP * steps / el, "unit": "EKF steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
                    "batch": B, "nstate": nstate, "marker_slots": slots, "markers_in_view_mean": nvis, "rows_per_filter_and_frame": rows,
-                   "update": "fbus_ekf_correct_pixels_dev (left camera)" if kind == "pixels" else "fbus_ekf_correct_corners_dev (refractive, stacked)",
-                   "update_avg_launch_us": us, "update_launches": u_n, "predict_avg_launch_us": p_ms / max(p_n, 1) * 1e3,
-                   "update_bytes_per_filter_api": bytes_api, "update_algorithmic_GBs": bytes_api * B / (us * 1e-6) / 1e9,
-                   "update_frac_of_hbm_peak": bytes_api * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                   "camera": ("stereo" if stereo else "left") if kind == "pixels" else "stereo (triangulated)",
                    "filters_updated_frac": applied, "state_finite": finite}
-            if kind == "pixels":
-                blk["reprojection_rows_per_s"] = rows * B / (us * 1e-6)
-                if slots == 16:
-                    # the stereo form of the same update (256 rows), launch time only
-                    flt.timing_reset()
-                    for _ in range(6):
-                        update(stereo=True)
-                    s_ms, s_n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
-                    blk["stereo_256_rows_avg_launch_us"] = s_ms / max(s_n, 1) * 1e3
-                if prof and int(prof.get("batch", 0)) == B and int(prof.get("marker_slots", 0)) == slots:
-                    insts, mhz = float(prof["counters_per_launch"]["SQ_INSTS_VALU"]), float(prof.get("clock_MHz") or 2400.0)
-                    simds = int(prof.get("simds", 1024))
-                    blk.update({"valu_insts_per_launch": insts, "clock_MHz": mhz, "source": "profiles/" + PIXELS_SQ,
-                                "valu_issue_frac": insts / (us * 1e-6 * simds * mhz * 1e6 / 4.0),
-                                "valu_issue_frac_profiled_run": prof.get("valu_issue_frac_kernel_trace"),
-                                "sq_active_inst_valu_over_wave_cycles": prof.get("SQ_ACTIVE_INST_VALU_over_SQ_WAVE_CYCLES")})
+            if fused:
+                kavg = sum(PATTERN) / len(PATTERN)
+                blk.update({"launch": "fbus_ekf_frame_meas_fused_dev: K = 7 / 7 / 6 ImuUpdates + the update in ONE launch per camera frame "
+                                      "(frame_meas_kernel: record resident, covariance parked in LDS across the fold)",
+                            "frame_avg_launch_us": us, "frame_launches": u_n, "us_per_ekf_step": us / (kavg + 1),
+                            "frame_bytes_per_filter_actual": 2 * rec_b + 68 * slots + 28 * kavg,
+                            "note": "extra to the metric: one record round trip per FRAME; priced per step by SURVEY 8(d) it would read > 1 of the roofline"})
+            else:
+                blk.update({"update": ("fbus_ekf_correct_pixels_dev (" + ("stereo" if stereo else "left camera") + ")") if kind == "pixels"
+                                      else "fbus_ekf_correct_corners_dev (refractive, stacked)",
+                            "update_avg_launch_us": us, "update_launches": u_n, "predict_avg_launch_us": p_ms / max(p_n, 1) * 1e3,
+                            "update_bytes_per_filter_api": bytes_api, "update_algorithmic_GBs": bytes_api * B / (us * 1e-6) / 1e9,
+                            "update_frac_of_hbm_peak": bytes_api * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                if kind == "pixels":
+                    blk["reprojection_rows_per_s"] = rows * B / (us * 1e-6)
+                    if prof and int(prof.get("batch", 0)) == B and int(prof.get("marker_slots", 0)) == slots and \
+                            prof.get("camera", "left") == ("stereo" if stereo else "left"):
+                        insts, mhz = float(prof["counters_per_launch"]["SQ_INSTS_VALU"]), float(prof.get("clock_MHz") or 2400.0)
+                        simds = int(prof.get("simds", 1024))
+                        blk.update({"valu_insts_per_launch": insts, "clock_MHz": mhz, "source": "profiles/" + PIXELS_SQ,
+                                    "valu_issue_frac": insts / (us * 1e-6 * simds * mhz * 1e6 / 4.0),
+                                    "valu_issue_frac_profiled_run": prof.get("valu_issue_frac_kernel_trace"),
+                                    "sq_active_inst_valu_over_wave_cycles": prof.get("SQ_ACTIVE_INST_VALU_over_SQ_WAVE_CYCLES")})
             flt.timing_enable(False)
         out[name] = blk
-    out["note"] = ("same 200 Hz + 30 Hz per-call schedule as `value`, the camera frame applied as reprojection rows (pixels_*) or as "
-                   "triangulated corner rows (corners_m4) instead of marker poses; VALU-bound updates: read valu_issue_frac, not the byte fraction")
+    out["note"] = ("same 200 Hz + 30 Hz schedule as `value`, the camera frame applied as reprojection rows (pixels_*: left camera 2 rows per corner, "
+                   "*_stereo 4 rows per corner) or as triangulated corner rows (corners_m4) instead of marker poses; per call (one launch per EKF "
+                   "step) or fused_frame_* (one launch per camera frame); VALU-bound updates: read valu_issue_frac, not the byte fraction")
     return out
 
 

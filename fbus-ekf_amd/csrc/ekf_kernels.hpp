@@ -1098,21 +1098,26 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
 // sequential rank-1 passes -- were removed in round 4.)
 
 // One marker per lane: corners (stereo pairs or 3-D) -> marker pose in the left camera frame.
+// The arithmetic runs in DOUBLE whatever the array type T (round 5; the reference computes in double, vision.cpp:472-759):
+// fp32 triangulation left the corner positions ~2e-6 m off, which the pose update behind it amplified to 10x the parity
+// gate (tests/test_vision_gpu.py); the kernel is a front-door step (one launch per camera frame, 64 B in / 28 B out per
+// marker) and fp64 FMAs cost what fp32 ones cost on this part.  Outputs are rounded to T once.
 template <typename T>
 __global__ void __launch_bounds__(256)
 marker_pose_kernel(int n, int geometry, const T* __restrict__ left, const T* __restrict__ right,
-                   T* __restrict__ pos, T* __restrict__ quat, T* __restrict__ corners3d, VisConst<T> vc)
+                   T* __restrict__ pos, T* __restrict__ quat, T* __restrict__ corners3d, VisConst<double> vc)
 {
+    using S = double;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    T C[12];
+    S C[12];
     if (geometry == VIS_CORNERS3D) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) C[k] = left[(size_t)i * 12 + k];
+        for (int k = 0; k < 12; ++k) C[k] = (S)left[(size_t)i * 12 + k];
     } else {
-        T l[8], r[8];
+        S l[8], r[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { l[k] = left[(size_t)i * 8 + k]; r[k] = right[(size_t)i * 8 + k]; }
+        for (int k = 0; k < 8; ++k) { l[k] = (S)left[(size_t)i * 8 + k]; r[k] = (S)right[(size_t)i * 8 + k]; }
         if (geometry == VIS_REFRACTIVE) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) refraction_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], C + 3 * c);
@@ -1121,15 +1126,15 @@ marker_pose_kernel(int n, int geometry, const T* __restrict__ left, const T* __r
             for (int c = 0; c < 4; ++c) pinhole_corner(vc, l[2 * c], l[2 * c + 1], r[2 * c], r[2 * c + 1], C + 3 * c);
         }
     }
-    T p[3], q[4];
+    S p[3], q[4];
     marker_pose(C, p, q);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pos[(size_t)i * 3 + k] = p[k];
+    for (int k = 0; k < 3; ++k) pos[(size_t)i * 3 + k] = (T)p[k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) quat[(size_t)i * 4 + k] = q[k];
+    for (int k = 0; k < 4; ++k) quat[(size_t)i * 4 + k] = (T)q[k];
     if (corners3d) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) corners3d[(size_t)i * 12 + k] = C[k];
+        for (int k = 0; k < 12; ++k) corners3d[(size_t)i * 12 + k] = (T)C[k];
     }
 }
 

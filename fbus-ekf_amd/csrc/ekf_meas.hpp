@@ -904,7 +904,28 @@ __device__ __forceinline__ void direct_update(T* P, T* dx, const COEF& cf)
 #undef PS
 }
 
-// the tail both measurement kernels share: the sums -> information matrix -> 6 x 6 stage -> update -> injection -> stores
+// the sums -> information matrix -> 6 x 6 stage (double) -> one-shot update of the resident covariance; dx = the error state
+// (the resident kernels; meas_update_tail below holds the same statements in place)
+template <typename T, int N>
+__device__ __forceinline__ void meas_solve_update(T* P, const PixAcc& acc, const double* Rd, double w, T* dx)
+{
+    double Lam[21], bv[6];
+    acc.finish(Rd, w, Lam, bv);
+    T G[36], Sinv[21], m[6];
+    {
+        double PJJ[36];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
+        info_solve<T>(Lam, bv, PJJ, G, Sinv, m);
+    }
+    RegCoef<T> cf;
+    cf.set(G, Sinv, m);
+    direct_update<T, N>(P, dx, cf);
+}
+
+// the tail both per-call measurement kernels share: the sums -> information matrix -> 6 x 6 stage -> update -> injection -> stores
 template <typename T, int N>
 __device__ __forceinline__ void meas_update_tail(const __amdgpu_buffer_rsrc_t rs, unsigned lane, const PixAcc& acc, const double* Rd, double w,
                                                  int new_prev)
@@ -917,7 +938,7 @@ __device__ __forceinline__ void meas_update_tail(const __amdgpu_buffer_rsrc_t rs
     double Lam[21], bv[6];
     acc.finish(Rd, w, Lam, bv);
     T dx[N];
-    {
+    {   // (meas_solve_update's body, kept in place: calling it here changed the register allocation of the tuned per-call kernels)
         T G[36], Sinv[21], m[6];
         {
             double PJJ[36];
@@ -1238,5 +1259,255 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
     meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pos, new_prev);
     applied[b] = 1;
 }
+
+// =================================================================================
+// One camera frame in ONE launch with the north star's own MeasureUpdate (round 5): K ImuUpdates with the record resident in
+// registers (predict_steps: the arithmetic of K fbus_ekf_predict calls), then correct() from corner pixels (KIND = MEAS_PIXELS:
+// correct_pixels2_kernel's fold) or from stereo corners (MEAS_CORNERS: correct_corners2_kernel's), then the one-shot update --
+// the reference's BatchImuProcessing + ObservationUpdate (filter.cpp:232-235) with the measurement model of BASELINE.json's
+// north_star in place of the pose rows.  Same device functions in the same order per filter as K predict launches + one
+// correct_pixels / correct_corners launch with one wave per tile: bit-equal to that sequence (tests/test_frame_meas_gpu.py).
+//
+// Registers: the predict loop holds the whole record (28 + 172 values) beside its coefficients; the double-precision fold needs
+// ~390 registers WITHOUT the covariance.  So between the last ImuUpdate and the update the covariance waits outside the register
+// file: the chunks ImuUpdate can change (N = 18: 33 of 43; N = 15: all 31) in LDS -- 33 KiB per wave, lane-consecutive 16-byte
+// slots, conflict-free; with the 4.5 KiB marker table 37.5 KiB per one-wave workgroup, four of which fit a CU's 160 KiB: one wave
+// per SIMD, the occupancy the 400-register fold allows anyway -- and the predict-invariant tail (N = 18: ba / bg / g block, 10
+// chunks) is not kept at all: it is in the record as it was, and comes back from L2 under the 6 x 6 stage.  The nominal state
+// stays in registers (the fold reads p, R from it; 12 values more than the per-call kernel's pqr).
+// What the fusion saves against predict_n + correct_pixels: one launch, the record's way out and in again between them (the
+// per-call update waits ~8 us for p, q, R and again for the covariance), and 2 x 800 B of traffic per filter and frame.
+// =================================================================================
+template <typename T> struct QDiag { T qd[4]; };      // (MEAS_PIXELS / MEAS_CORNERS: ekf_launch.hpp)
+
+template <typename T, int N, int DIALECT, int KIND, bool NZ>
+__global__ void __launch_bounds__(64)
+frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
+                  const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ left,
+                  const T* __restrict__ right, int geometry, int mode, double size, double r_meas, double switch_thres,
+                  const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied, const short* __restrict__ id2slot,
+                  MeasConst mc, VisConst<double> vc, VisConst<T> vct, QDiag<T> qd)
+{
+    using L = Lay<N>;
+    using RC = Rec<T, N>;
+    constexpr int EPC = RC::EPC, CN = RC::CH_NOM;
+    constexpr int PCH = RC::CH_VAR_END - CN;             // covariance chunks parked in LDS across the fold
+    constexpr int NT = 64;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned tile = blockIdx.x;
+    const int b = (int)(tile * 64u + lane);
+    const int bc = b < B ? b : (int)(tile * 64u);
+    const bool live = b < B && M > 0 && !(skip && skip[bc]);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    __shared__ MeasLDS tbl;
+    __shared__ u32x4 park_mem[PCH * 64];
+    u32x4* park = park_mem + lane;
+    const bool stereo = right != nullptr;
+    const bool c3d = KIND == MEAS_CORNERS && geometry == VIS_CORNERS3D;
+    const int lw = c3d ? 12 : 8;
+    struct Meas { int id; T l[KIND == MEAS_CORNERS ? 12 : 8], r[8]; };
+    // the id and the image coordinates of marker slot i (16-byte loads; the layouts of correct_pixels2 / correct_corners2_kernel)
+    auto fetch = [&](int i, Meas& mm) __attribute__((always_inline)) {
+        const size_t o = (size_t)bc * M + i;
+        constexpr int EP = 16 / (int)sizeof(T);
+        mm.id = ids[o];
+        const u32x4* pl = reinterpret_cast<const u32x4*>(left + o * lw);
+        const u32x4* pr = reinterpret_cast<const u32x4*>(((KIND == MEAS_CORNERS ? c3d : !stereo) ? left : right) + o * 8);
+        if constexpr (KIND == MEAS_PIXELS) {
+#pragma unroll
+            for (int c = 0; c < 8 / EP; ++c) {
+                const u32x4 vl = pl[c], vr = pr[c];
+                const T* el = reinterpret_cast<const T*>(&vl);
+                const T* er = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+                for (int k = 0; k < EP; ++k) { mm.l[c * EP + k] = el[k]; mm.r[c * EP + k] = er[k]; }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 12 / EP; ++c) {
+                const u32x4 vl = pl[(c < 8 / EP || c3d) ? c : 0];
+                const T* el = reinterpret_cast<const T*>(&vl);
+#pragma unroll
+                for (int k = 0; k < EP; ++k) mm.l[c * EP + k] = el[k];
+            }
+#pragma unroll
+            for (int c = 0; c < 8 / EP; ++c) {
+                const u32x4 vr = pr[c];
+                const T* er = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+                for (int k = 0; k < EP; ++k) mm.r[c * EP + k] = er[k];
+            }
+        }
+    };
+    // the four corners of a measured marker in the left camera frame (MEAS_CORNERS)
+    auto corners = [&](const Meas& mm, double (&C)[4][3]) __attribute__((always_inline)) {
+        if (geometry == VIS_REFRACTIVE) { tri_corners_refractive<T, NZ>(vc, mm.l, mm.r, C); return; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (geometry == VIS_CORNERS3D) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) C[k][i] = (double)mm.l[(3 * k + i) % (KIND == MEAS_CORNERS ? 12 : 8)];
+            } else {
+                T o3[3];
+                pinhole_corner(vct, mm.l[2 * k], mm.l[2 * k + 1], mm.r[2 * k], mm.r[2 * k + 1], o3);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) C[k][i] = (double)o3[i];
+            }
+        }
+    };
+    T nom[L::NNOM];
+    Meas cur, nxt;
+    T prev_raw = T(0);
+    {
+        T P[RC::NCOVP];
+        {
+            // the marker map -> LDS, the record behind it (lanes past B load their existing tile too: no branch in front of the loads)
+            constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(double) * FBUS_MAX_MARKERS * MKC_STRIDE / 16;
+            constexpr int PI = (NI + NT - 1) / NT, PM = (NM + NT - 1) / NT;
+            const u32x4* si = reinterpret_cast<const u32x4*>(id2slot);
+            const u32x4* sm = reinterpret_cast<const u32x4*>(mc.mkc);
+            u32x4* di = reinterpret_cast<u32x4*>(tbl.id2slot);
+            u32x4* dm = reinterpret_cast<u32x4*>(tbl.mkc);
+            u32x4 vi[PI], vm[PM];
+#pragma unroll
+            for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; vi[q] = si[i < NI ? i : 0]; }
+#pragma unroll
+            for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; vm[q] = sm[i < NM ? i : 0]; }
+            order_fence();
+            load_chunks<T, N, 0, CN, AUX_NT>(rs, lane, nom);
+            load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, lane, P);
+            order_fence();
+#pragma unroll
+            for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; if (i < NI) di[i] = vi[q]; }
+#pragma unroll
+            for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; if (i < NM) dm[i] = vm[q]; }
+            order_fence();
+        }
+        if (b >= B) return;
+        // K ImuUpdates; under the covariance stages of the last one the first marker's image points are requested
+        auto first_marker = [&]() __attribute__((always_inline)) { if (M > 0) fetch(0, cur); };
+        predict_steps<T, N, DIALECT>(nom, P, K, accel, gyro, dt, dt_stride, B, b, qd.qd, first_marker);
+        order_fence();
+        if (KIND == MEAS_CORNERS && mode == MODE_NEAREST && DIALECT == DIALECT_CPP) prev_raw = P[L::OFF_PREV - L::OFF_COV];
+        // the covariance as predicted -> LDS (what ImuUpdate can change; the rest is in the record as it was)
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) {
+            u32x4 v;
+            T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+            for (int k = 0; k < EPC; ++k) e[k] = P[c * EPC + k];
+            park[c * 64] = v;
+        }
+        order_fence();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double pd[3], Rd[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pd[i] = (double)nom[L::OFF_P3 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rd[i] = (double)nom[L::OFF_R + i];
+    double pil[3];
+    filter_pil(Rd, mc.P_IL, pil);
+    PixAcc acc;
+    acc.clear();
+    double nfold = 0.0;
+    int new_prev = -1;
+    if constexpr (KIND == MEAS_PIXELS) {
+        const int last = live ? M : 0;
+#pragma unroll 1
+        for (int i = 0; i < last; ++i) {
+            fetch(i + 1 < M ? i + 1 : M - 1, nxt);
+            const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
+            const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
+            if (slot >= 0) {
+                double mk[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
+                if (stereo) pixel_fold_marker<2, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+                else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
+                nfold += 1.0;
+            }
+            cur = nxt;
+        }
+    } else {
+        auto fold_marker = [&](const Meas& mm) __attribute__((always_inline)) {
+            const bool ok = mm.id >= 0 && mm.id <= FBUS_MAX_MARKER_ID;
+            const int slot = ok ? (int)tbl.id2slot[ok ? mm.id : 0] : -1;
+            if (slot < 0) return false;
+            double mk[9], C[4][3];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
+            corners(mm, C);
+            corner_fold_marker(acc, pd, Rd, pil, mc, mk, C, size);
+            return true;
+        };
+        if (mode == MODE_NEAREST) {
+            if (live) {
+                const int prev_id = (int)prev_raw;
+                int min_i = -1, prev_i = -1;
+                double min_d = 10.0, prev_d = 0.0;
+#pragma unroll 1
+                for (int i = 0; i < M; ++i) {
+                    fetch(i + 1 < M ? i + 1 : M - 1, nxt);
+                    if (cur.id >= 0) {
+                        double C[4][3];
+                        corners(cur, C);
+                        const double dist = sqrt(C[0][0] * C[0][0] + C[0][1] * C[0][1] + C[0][2] * C[0][2]);
+                        if (dist < min_d) { min_d = dist; min_i = i; }
+                        if (DIALECT == DIALECT_CPP && cur.id == prev_id) { prev_d = dist; prev_i = i; }
+                    }
+                    cur = nxt;
+                }
+                if (min_i >= 0) {
+                    if (DIALECT == DIALECT_CPP && prev_i >= 0 && fabs(prev_d - min_d) < switch_thres && prev_d != 0.0) min_i = prev_i;
+                    fetch(min_i, cur);
+                    if (fold_marker(cur)) { nfold = 1.0; if (DIALECT == DIALECT_CPP) new_prev = cur.id; }
+                }
+            }
+        } else {
+            const int last = live ? M : 0;
+#pragma unroll 1
+            for (int i = 0; i < last; ++i) {
+                fetch(i + 1 < M ? i + 1 : M - 1, nxt);
+                if (fold_marker(cur)) nfold += 1.0;
+                cur = nxt;
+            }
+        }
+    }
+    order_fence();
+    T P[RC::NCOVP];
+    if (!live || nfold == 0.0) {
+        // no update for this filter (skipped, no usable marker, M = 0): the record as predicted -- what ImuUpdate writes
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) {
+            const u32x4 v = park[c * 64];
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int k = 0; k < EPC; ++k) P[c * EPC + k] = e[k];
+        }
+        store_chunks<T, N, 0, RC::CH_KIN, FBUS_X_FRAME_ST>(rs, lane, nom);
+        store_chunks<T, N, CN, RC::CH_VAR_END, FBUS_X_FRAME_ST>(rs, lane, P);
+        if (M > 0) applied[b] = 0;
+        return;
+    }
+    // the predict-invariant tail from the record (L2-hot: this wave read it at the top), the rest back from LDS
+    if constexpr (RC::CH_VAR_END < RC::NCH) load_chunks<T, N, RC::CH_VAR_END, RC::NCH>(rs, lane, P + PCH * EPC);
+#pragma unroll
+    for (int c = 0; c < PCH; ++c) {
+        const u32x4 v = park[c * 64];
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) P[c * EPC + k] = e[k];
+    }
+    if constexpr (KIND == MEAS_CORNERS) acc.expand_const(mc.NI);
+    T dx[N];
+    meas_solve_update<T, N>(P, acc, Rd, 1.0 / r_meas, dx);
+    inject<T, N>(nom, dx);
+    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+    store_chunks<T, N, 0, CN, FBUS_X_FRAME_ST>(rs, lane, nom);
+    store_chunks<T, N, CN, RC::NCH, FBUS_X_FRAME_ST>(rs, lane, P);
+    applied[b] = 1;
+}
+
 
 }  // namespace

@@ -135,6 +135,7 @@ struct fbus_ekf {
     // 2..4 = always with that many roles (fbus_ekf_set_team, FBUS_TEAM_PREDICT / FBUS_TEAM_CORRECT at create)
     int team_predict = 0, team_correct = 0;
     int team_frame = 0;               // FBUS_TEAM_FRAME: 0 = follows team_predict, 1 = never, 2 = always
+    bool no_frame_meas = false;       // FBUS_NO_FRAME_MEAS=1 (A/B runs): fbus_ekf_frame_meas_fused_dev always as predict_n + the per-call update
     fbus_params prm{};
     HostConst hc;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -595,7 +596,7 @@ int launch_marker_pose_t(fbus_ekf_t h, int n, int geometry, const void* left, co
     const int grid = (n + 255) / 256;
     const int ev = timing_begin(h, FBUS_KERNEL_MARKER_POSE);
     hipLaunchKernelGGL((marker_pose_kernel<T>), dim3(grid), dim3(256), 0, h->stream, n, geometry, (const T*)left,
-                       (const T*)right, (T*)pos, (T*)quat, (T*)corners3d, make_vc<T>(h));
+                       (const T*)right, (T*)pos, (T*)quat, (T*)corners3d, make_vc<double>(h));
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -667,6 +668,46 @@ int launch_correct_pixels_t(fbus_ekf_t h, int M, const int32_t* ids, const void*
 int launch_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, const uint8_t* skip)
 {
     DISPATCH(h, launch_correct_pixels_t, h, M, ids, left, right, skip);
+}
+
+// One camera frame with the north star's MeasureUpdate: K predicts + correct_pixels (kind 0) / correct_corners (kind 1).
+// ONE launch (frame_meas_kernel: record resident, covariance parked in LDS across the fold) where the per-call update would run one wave
+// per tile anyway -- fp32 records, more than half a chip of tiles (or fbus_ekf_set_team(., 1)) -- and bit-equal to the per-call
+// sequence there; otherwise predict_n + the per-call update (whose team forms fill a small launch better than one resident wave
+// per tile could; fp64 records: the resident fold + covariance do not fit 512 registers).
+template <typename T, int N, int D>
+int launch_frame_meas_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter, int kind, int M,
+                        const int32_t* ids, const void* left, const void* right, int geometry, int mode, const uint8_t* skip)
+{
+    const int roles = (kind == MEAS_CORNERS && mode != MODE_STACKED) ? 1 : team_roles_pixels(h, M);
+    const bool fused = sizeof(T) == 4 && K > 0 && M > 0 && roles == 1 && !h->no_frame_meas;
+    if (!fused) {
+        int rc = FBUS_OK;
+        if (K > 0) rc = launch_predict_t<T, N, D>(h, K, accel, gyro, dt, dt_per_filter);
+        if (rc == FBUS_OK && M > 0)
+            rc = kind == MEAS_PIXELS ? launch_correct_pixels_t<T, N, D>(h, M, ids, left, right, skip)
+                                     : launch_correct_corners_t<T, N, D>(h, M, ids, left, right, geometry, mode, skip);
+        return rc;
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right)) & 15) != 0)
+            return fail(h, FBUS_ERR_INVALID, "fbus_ekf_frame_meas_fused_dev: left / right must be 16-byte aligned device pointers");
+        const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
+        h->records_warm = true;
+        const DevConst<T> dc = make_dc<T>(h);
+        launch_frame_meas_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0,
+                                     kind, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode, h->prm.marker_size,
+                                     kind == MEAS_PIXELS ? h->prm.r_pix : h->prm.r_pos, h->prm.switch_thres, (const unsigned char*)skip,
+                                     h->d_applied, h->d_id2slot, make_mc(h), make_vc<double>(h), make_vc<T>(h), dc.qd);
+        timing_end(h, ev);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return FBUS_OK;
+}
+int launch_frame_meas(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int per, int kind, int M,
+                      const int32_t* ids, const void* left, const void* right, int geometry, int mode, const uint8_t* skip)
+{
+    DISPATCH(h, launch_frame_meas_t, h, K, accel, gyro, dt, per, kind, M, ids, left, right, geometry, mode, skip);
 }
 
 int launch_correct_corners(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, int geometry,
@@ -858,6 +899,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (const char* e = std::getenv("FBUS_PREDICT_POLICY")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->predict_policy_force = v; }
     if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
     if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
+    if (const char* e = std::getenv("FBUS_NO_FRAME_MEAS")) h->no_frame_meas = std::atoi(e) != 0;
     if (const char* e = std::getenv("FBUS_TEAM_FRAME")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->team_frame = v; }
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
@@ -1413,6 +1455,27 @@ int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void*
     if (M > 0 && (!ids || !pos || !quat)) return FBUS_ERR_INVALID;
     if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     return launch_frame(h, K, accel, gyro, dt, dt_per_filter, M, ids, pos, quat, mode, skip);
+}
+
+int fbus_ekf_frame_meas_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
+                                  int kind, int M, const int32_t* ids, const void* left, const void* right, int geometry, int mode,
+                                  const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    // everything is validated before the first launch: a rejected call must not leave the state advanced by the K predicts
+    if (!h || K < 0 || M < 0 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (kind != FBUS_MEAS_PIXELS && kind != FBUS_MEAS_CORNERS) return FBUS_ERR_UNSUPPORTED;
+    if (K > 0 && (!accel || !gyro || !dt)) return FBUS_ERR_INVALID;
+    if (M > 0 && (!ids || !left)) return FBUS_ERR_INVALID;
+    if (kind == FBUS_MEAS_PIXELS) {
+        if (!(h->prm.r_pix > 0)) return fail(h, FBUS_ERR_INVALID, "r_pix must be positive");
+        geometry = FBUS_VIS_REFRACTIVE; mode = FBUS_MODE_STACKED;          // (not used by the pixel rows)
+    } else {
+        if (geometry != FBUS_VIS_REFRACTIVE && geometry != FBUS_VIS_PINHOLE && geometry != FBUS_VIS_CORNERS3D) return FBUS_ERR_UNSUPPORTED;
+        if (M > 0 && geometry != FBUS_VIS_CORNERS3D && !right) return FBUS_ERR_INVALID;
+        if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    }
+    return launch_frame_meas(h, K, accel, gyro, dt, dt_per_filter, kind, M, ids, left, right, geometry, mode, skip);
 }
 
 int fbus_ekf_frames_fused_dev(fbus_ekf_t h, int nframes, const int32_t* kcount, const void* accel, const void* gyro,

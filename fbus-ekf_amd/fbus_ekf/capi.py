@@ -13,6 +13,7 @@ COV_SIMPLE, COV_JOSEPH = 0, 1
 KERNEL_PREDICT, KERNEL_CORRECT, KERNEL_PREDICT_N, KERNEL_MARKER_POSE, KERNEL_FRAME = 0, 1, 2, 3, 4
 KERNEL_CORRECT_CORNERS = 5
 VIS_REFRACTIVE, VIS_PINHOLE, VIS_CORNERS3D = 0, 1, 2
+MEAS_PIXELS, MEAS_CORNERS = 0, 1   # fbus_ekf_frame_meas_fused_dev
 POSE_INIT, POSE_RESET = 0, 1
 L0_QUAT_MUL, L0_QUAT_TO_ROTMAT_M, L0_QUAT_TO_ROTMAT_E, L0_QUAT_NORMALIZE, L0_EXPM_SO3_NEG, L0_DTHETA_TO_QUAT, L0_SINCOS_HALF = range(7)
 MAX_MARKERS, MAX_VISIBLE = 32, 16
@@ -21,7 +22,7 @@ STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
 # fbus_ekf_launch_info (include/fbus_ekf.h)
 (INFO_SIMDS, INFO_ONE_ROUND_FILTERS, INFO_TWO_WAVE_MIN_B, INFO_BIG_RECORDS_MB, INFO_MALL_MB, INFO_L2_KB, INFO_POLICY_BATCH,
  INFO_ROLES_PREDICT, INFO_ROLES_MEAS, INFO_TEAM_FRAMES) = range(10)
-ABI_VERSION = 4                    # FBUS_ABI_VERSION of the header this mirror was written against
+ABI_VERSION = 5                    # FBUS_ABI_VERSION of the header this mirror was written against
 ERR_ABI = 6
 
 
@@ -126,6 +127,7 @@ def load_library():
         "fbus_ekf_get_applied": ([H, u8p], C.c_int),
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_frame_meas_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
         "fbus_ekf_frames_fused_dev": ([H, C.c_int, ip, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_init_gravity_bias": ([H, C.c_int, vp, vp], C.c_int),
         "fbus_ekf_init_gravity_bias_dev": ([H, C.c_int, vp, vp], C.c_int),

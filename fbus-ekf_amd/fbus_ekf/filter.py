@@ -356,6 +356,35 @@ class BatchedFilter:
         self._check(rc, "frame_dev")
         self._order_out(cur)
 
+    def frame_meas(self, accel, gyro, dt, ids, left, right=None, kind=capi.MEAS_PIXELS, geometry=capi.VIS_REFRACTIVE,
+                   mode=capi.MODE_STACKED, skip=None):
+        """One camera frame with the north star's MeasureUpdate in ONE launch (fbus_ekf_frame_meas_fused_dev; device arrays):
+        K predicts, then correct_pixels (kind = MEAS_PIXELS; right=None: left camera) or correct_corners (MEAS_CORNERS, with its
+        geometry / mode).  accel, gyro: (K, B, 3); dt: (K,) or (K, B); ids: (B, M); left / right: (B, M, 8) [(B, M, 12) corner
+        positions for VIS_CORNERS3D]."""
+        B = self.B
+        K = accel.numel() // (3 * B) if accel is not None else 0
+        M = ids.numel() // B if ids is not None else 0
+        per = 0
+        if K > 0:
+            per = 1 if (dt.numel() == K * B and B > 1) else 0
+            if not per and dt.numel() < K:
+                raise ValueError("dt must have K or K*B elements")
+            self._dev_checked(accel, K * B * 3, "accel"); self._dev_checked(gyro, K * B * 3, "gyro")
+            self._dev_checked(dt, dt.numel(), "dt")
+        if M > 0:
+            lw = 12 if (kind == capi.MEAS_CORNERS and geometry == capi.VIS_CORNERS3D) else 8
+            self._dev_checked(ids, B * M, "ids"); self._dev_checked(left, B * M * lw, "left")
+            if right is not None:
+                self._dev_checked(right, B * M * 8, "right")
+        if skip is not None:
+            self._dev_checked(skip, B, "skip")
+        cur = self._order_in(accel, gyro, dt, ids, left, right, skip)
+        rc = self._lib.fbus_ekf_frame_meas_fused_dev(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per, kind, M,
+                                                     self._p(ids), self._p(left), self._p(right), geometry, mode, self._p(skip))
+        self._check(rc, "frame_meas_fused_dev")
+        self._order_out(cur)
+
     def frames(self, kcount, accel, gyro, dt, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
         """A window of camera frames in ONE launch (device arrays): len(kcount) times { kcount[f] predicts, one correct }
         with the records resident in registers in between -- the frame loop of FBUS_EKF.m:151-210 over a recorded stretch.

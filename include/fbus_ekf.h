@@ -105,11 +105,12 @@ int fbus_params_validate(const fbus_params* prm, char* msg, size_t msg_len);
  * the caller's compile-time sizeof(fbus_params) and FBUS_ABI_VERSION to fbus_ekf_create_checked, which refuses a
  * mismatch with FBUS_ERR_ABI.  (Bindings that cannot use the macro -- ctypes, loadlibrary -- call
  * fbus_ekf_abi_version() / fbus_params_size() once after loading and compare; the Python mirror does.)
+ *   5  round 5: fbus_ekf_frame_meas_fused_dev (struct unchanged)
  *   4  round 4: fbus_ekf_set_policy_batch, fbus_ekf_launch_info (struct unchanged)
  *   3  round 3: FBUS_ERR_ABI, create_checked, team kernels (fbus_ekf_set_team), fbus_ekf_gather
  *   2  round 2: r_pix in fbus_params, set_stream(NULL) = legacy default stream
  *   1  round 1 */
-#define FBUS_ABI_VERSION 4
+#define FBUS_ABI_VERSION 5
 int fbus_ekf_abi_version(void);
 size_t fbus_params_size(void);
 
@@ -270,6 +271,19 @@ int fbus_ekf_frame_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro,
  * fbus_ekf_frame_dev.  M = 0: predicts only. */
 int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                              int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
+
+/* (round 5) The same frame with the NORTH STAR's MeasureUpdate -- correct() from corner pixels (FBUS_MEAS_PIXELS: the rows of
+ * fbus_ekf_correct_pixels_dev; right may be NULL = left camera; geometry and mode are ignored) or from stereo corners
+ * (FBUS_MEAS_CORNERS: fbus_ekf_correct_corners_dev with its geometry and mode) -- in place of the pose rows: K predicts
+ * (matlab/ImuUpdate.m:36-82 ; filter.cpp:505-516) and the update (matlab/MeasureUpdate.m:84-102 with the reprojection rows of the
+ * flat-port model, vision.cpp:496-599 run forward) in ONE launch, the record resident in registers / LDS in between.  Same
+ * arithmetic and results as K fbus_ekf_predict_dev calls + one fbus_ekf_correct_pixels_dev / _corners_dev call (bit-equal where
+ * that update runs one wave per tile: more than half a chip of tiles, or fbus_ekf_set_team(h, ., 1)); smaller launches and fp64
+ * records run as fbus_ekf_predict_n_dev + the per-call update.  M = 0: predicts only.  left / right: 16-byte aligned. */
+enum { FBUS_MEAS_PIXELS = 0, FBUS_MEAS_CORNERS = 1 };
+int fbus_ekf_frame_meas_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
+                                  int kind, int M, const int32_t* ids, const void* left, const void* right, int geometry, int mode,
+                                  const uint8_t* skip);
 
 /* A WINDOW of camera frames in ONE launch (offline replay of a recorded stretch: the frame loop of
  * matlab/FBUS_EKF.m:151-210 / FilterThreadFunction, filter.cpp:229-235): nframes times { kcount[f] predicts, one

@@ -164,9 +164,8 @@ def test_config3_correct_from_refracted_stereo_corners(mode):
             ap = flt.applied()
         assert (ap[sub] == ok).all() and ok.all()
         _properties(g, f"config 3 corners mode {mode} fp{dtype}", psd_stride=7)
-        mult = 10.0
-        assert_parity([x[sub] for x in g], eng.get_state(), dtype, f"config 3 refractive corners, mode {mode}, fp{dtype}",
-                      state_tol=mult * STATE_TOL, plain_tol=mult * PLAIN_TOL, cov_block_tol=mult * COV_BLOCK_TOL)
+        # the standard gate (round 4's kernel triangulates in double; the 10x multiplier of rounds 2-3 is gone)
+        assert_parity([x[sub] for x in g], eng.get_state(), dtype, f"config 3 refractive corners, mode {mode}, fp{dtype}")
 
 
 # ------------------------------------------------------------------------------------------- config 5

@@ -1,0 +1,197 @@
+"""GPU suite: one camera frame with the NORTH STAR's MeasureUpdate in one launch (`fbus_ekf_frame_meas_fused_dev`,
+csrc/ekf_meas.hpp::frame_meas_kernel): K ImuUpdates (matlab/ImuUpdate.m:36-82) + correct() from corner pixels / from stereo
+corners (the rows of MeasureUpdate.m:67,72-73 with a corner in place of the marker origin, through the flat-port model of
+vision.cpp:496-599) with the record resident in registers / LDS in between.
+
+What is asserted:
+  * fused == the per-call sequence (K fbus_ekf_predict_dev + one fbus_ekf_correct_pixels_dev / _corners_dev) BIT FOR BIT --
+    nominal state, carried rotation, covariance, previous marker id, applied flags -- N = 18 and N = 15, left camera and stereo,
+    corner rows stacked and nearest (C++ dialect: hysteresis), with filters that see nothing, only unknown ids, or are skipped;
+  * fused against the fp64 oracle through the standard gate (tests/util.py::assert_parity), no widened bound;
+  * the routes behind the same entry point that do NOT take the fused kernel (fp64 records, the team forms of small launches,
+    M = 0) give the per-call results too;
+  * at the bench's size (65 536 filters): size-independent properties -- fused == per-call on a strided subset, symmetric positive
+    definite posterior."""
+import numpy as np
+import pytest
+
+import oracle_capi as oc
+from fbus_ekf import BatchedFilter, capi, synth
+from replay_ref import OracleEngine
+from util import PLAIN_WINDOW_TOL, assert_parity, pixel_scene
+
+pytestmark = pytest.mark.gpu
+r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+SIZE = 0.28
+DT = np.array([0.005])
+
+
+def _scene(B, M, dialect, n, seed):
+    prm = capi.default_params(dialect)
+    prm.marker_size = SIZE
+    nom0, _, P, prev = synth.initial_state(0, B, list(prm.p0_diag), n, mixed_cov=True)
+    truth, _, ids, left, right = pixel_scene(B, M, prm, SIZE, seed=seed, noise=5e-4, nominal=nom0)
+    rng = np.random.default_rng(seed + 1)
+    nom = truth.copy()
+    nom[:, 0:3] += rng.normal(0, 0.004, (B, 3))
+    nom[:, 3:6] = rng.normal(0, 0.02, (B, 3))                        # slow: K predicts must not carry the markers out of view
+    nom = r32(nom)
+    rot = r32(synth.q2R(nom[:, 6:10]).reshape(B, 9))
+    prev = np.where(ids[:, 0] >= 0, ids[:, 0], 0).astype(np.int32)   # C++ dialect: the previously used marker is one in view
+    return prm, nom, rot, r32(P), prev, ids, r32(left), r32(right)
+
+
+def _dev(torch, dtype):
+    dev = torch.device("cuda:0")
+    tt = torch.float32 if dtype == 32 else torch.float64
+    return lambda a: (torch.from_numpy(np.ascontiguousarray(a)).to(dev) if np.asarray(a).dtype.kind in "iu"
+                      else torch.from_numpy(np.ascontiguousarray(a, np.float64)).to(dev).to(tt))
+
+
+CASES = [("pixels", False, capi.MODE_STACKED), ("pixels", True, capi.MODE_STACKED),
+         ("corners", True, capi.MODE_STACKED), ("corners", True, capi.MODE_NEAREST)]
+
+
+def _run(flt, fused, d, K, what, stereo, mode):
+    """one frame through the fused entry point, or as K per-call predicts + one per-call update"""
+    kind = capi.MEAS_PIXELS if what == "pixels" else capi.MEAS_CORNERS
+    rgt = d["right"] if stereo else None
+    if fused:
+        flt.frame_meas(d["acc"][:K], d["gyr"][:K], d["dt"][:K], d["ids"], d["left"], rgt, kind, capi.VIS_REFRACTIVE, mode, skip=d["skip"])
+    else:
+        for k in range(K):
+            flt.predict(d["acc"][k], d["gyr"][k], d["dt"][:1])
+        if what == "pixels":
+            flt.correct_pixels(d["ids"], d["left"], rgt, d["skip"])
+        else:
+            flt.correct_corners(d["ids"], d["left"], rgt, capi.VIS_REFRACTIVE, mode, d["skip"])
+    flt.sync()
+    return flt.get_state(), flt.applied()
+
+
+@pytest.mark.parametrize("n", [18, 15])
+@pytest.mark.parametrize("dialect", [0, 1])
+def test_fused_frame_equals_the_per_call_sequence_bit_for_bit_and_the_oracle(dialect, n):
+    import torch
+    B, M, K = 448 - 5, 4, 3                                           # ragged last tile
+    prm, nom, rot, P, prev, ids, left, right = _scene(B, M, dialect, n, seed=41 + dialect)
+    ids[0] = -1                                                       # nothing visible: the predicted record
+    ids[1, :] = 9                                                     # only ids outside the map
+    skip = (np.arange(B) % 13 == 7).astype(np.uint8)
+    acc, gyr = synth.imu_samples(0, B, 0, K, nom)
+    acc, gyr = r32(acc), r32(gyr)
+    dd = _dev(torch, 32)
+    d = {"acc": dd(acc), "gyr": dd(gyr), "dt": dd(np.full(K, DT[0])), "ids": dd(ids), "left": dd(left), "right": dd(right),
+         "skip": dd(skip)}
+    vp = oc.vision_params()
+    corners = np.zeros((B, M, 4, 3))
+    for b in range(B):
+        for m in range(M):
+            if ids[b, m] >= 0:
+                corners[b, m] = oc.refraction_triangulate(vp, left[b, m], right[b, m])
+    for what, stereo, mode in CASES:
+        with BatchedFilter(B, prm, nstate=n) as fa, BatchedFilter(B, prm, nstate=n) as fb:
+            for f in (fa, fb):
+                f.set_team(1, 1)                                      # one wave per tile: the forms a full-chip launch runs
+                f.set_state(nom, rot, P, prev)
+            sa, oka = _run(fa, True, d, K, what, stereo, mode)
+            sb, okb = _run(fb, False, d, K, what, stereo, mode)
+        assert (oka == okb).all()
+        for x, y, name in zip(sa, sb, ("nominal", "rot", "P", "prev")):
+            assert np.array_equal(x, y), f"{what} stereo={stereo} mode={mode}: fused != per-call in {name}: {np.abs(x.astype(np.float64) - y).max():.3g}"
+        # ... and the oracle: K ImuUpdates + the update on the fp64 side, the standard gate (a chain of K + 1 steps without
+        # re-seeding: the plain per-block figure gets its free-running bound, as in smoke(); every other figure the single-step one)
+        eng = OracleEngine(B, dialect, n)
+        eng.set_state(nom, rot, P, prev)
+        for k in range(K):
+            eng.predict(acc[k], gyr[k], DT)
+        keep = eng.get_state()
+        if what == "pixels":
+            ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, right if stereo else None, SIZE, prm.r_pix)
+        else:
+            ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids, corners, SIZE, mode)
+        now = eng.get_state()
+        for x, y in zip(now, keep):
+            x[skip == 1] = y[skip == 1]
+        eng.set_state(*now)
+        ok[skip == 1] = 0
+        assert (oka == ok).all() and ok[2:][skip[2:] == 0].all() and not ok[0] and not ok[1]
+        assert_parity(sa, eng.get_state(), 32, f"fused frame N={n} dialect {dialect} {what} {'stereo' if stereo else 'left'} mode {mode}",
+                      plain_tol=PLAIN_WINDOW_TOL)
+
+
+def test_routes_that_do_not_take_the_fused_kernel():
+    """fp64 records, the automatic team forms of a small launch (roles > 1) and M = 0 behind the same entry point: the per-call
+    results (fp64 / M = 0: bit for bit; team forms: the same launches as the per-call route, so bit for bit as well)"""
+    import torch
+    B, M, K = 256, 4, 4
+    prm, nom, rot, P, prev, ids, left, right = _scene(B, M, 0, 18, seed=77)
+    acc, gyr = synth.imu_samples(0, B, 0, K, nom)
+    for dtype in (64, 32):
+        dd = _dev(torch, dtype)
+        d = {"acc": dd(acc), "gyr": dd(gyr), "dt": dd(np.full(K, DT[0])), "ids": dd(ids), "left": dd(left), "right": dd(right), "skip": None}
+        with BatchedFilter(B, prm, dtype=dtype) as fa, BatchedFilter(B, prm, dtype=dtype) as fb:
+            fa.set_state(nom, rot, P, prev); fb.set_state(nom, rot, P, prev)
+            # the per-call side of this comparison is predict_n + the update: what the entry point documents for these routes
+            fa.frame_meas(d["acc"], d["gyr"], d["dt"], d["ids"], d["left"], d["right"], capi.MEAS_PIXELS)
+            fb.predict_n(d["acc"], d["gyr"], d["dt"])
+            fb.correct_pixels(d["ids"], d["left"], d["right"])
+            sa, sb = fa.get_state(), fb.get_state()
+            for x, y in zip(sa, sb):
+                assert np.array_equal(x, y)
+            # M = 0: predicts only
+            fa.frame_meas(d["acc"], d["gyr"], d["dt"], None, None, None, capi.MEAS_PIXELS)
+            fb.predict_n(d["acc"], d["gyr"], d["dt"])
+            for x, y in zip(fa.get_state(), fb.get_state()):
+                assert np.array_equal(x, y)
+
+
+def test_rejected_calls_leave_the_state_alone():
+    import torch
+    B, M, K = 128, 2, 2
+    prm, nom, rot, P, prev, ids, left, right = _scene(B, M, 0, 18, seed=5)
+    acc, gyr = synth.imu_samples(0, B, 0, K, nom)
+    dd = _dev(torch, 32)
+    with BatchedFilter(B, prm) as flt:
+        flt.set_team(1, 1)
+        flt.set_state(nom, rot, P, prev)
+        before = flt.get_state()
+        lib, h = flt._lib, flt._h
+        a, g, t, i, l = dd(acc), dd(gyr), dd(np.full(K, DT[0])), dd(ids), dd(left)
+        p = lambda x: x.data_ptr()
+        assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, 7, M, p(i), p(l), None, 0, 1, None) == 4      # kind
+        assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, capi.MEAS_CORNERS, M, p(i), p(l), None, 0, 1, None) == 1   # no right
+        assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, capi.MEAS_PIXELS, M, p(i), p(l) + 4, None, 0, 1, None) == 1   # alignment
+        assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), None, p(t), 0, capi.MEAS_PIXELS, M, p(i), p(l), None, 0, 1, None) == 1
+        flt.sync()
+        for x, y in zip(flt.get_state(), before):
+            assert np.array_equal(x, y)
+
+
+def test_fused_frame_at_the_bench_size():
+    """65 536 filters x 4 marker slots (the `fused_frame_pixels_m4` row of bench.py): the automatic policy takes the fused kernel
+    here; fused == per-call bit for bit on every filter, posterior symmetric positive definite, everything finite"""
+    import torch
+    B, M, K = 65536, 4, 7
+    prm = capi.default_params(0)
+    prm.marker_size = 0.15
+    nom, rot, ids, left, right = synth.pixel_wall_scene(B, M, prm, 0.15, seed=9, stereo=True)
+    acc, gyr = synth.imu_samples(0, B, 0, K, nom)
+    dd = _dev(torch, 32)
+    d = {"acc": dd(acc), "gyr": dd(gyr), "dt": dd(np.full(K, DT[0])), "ids": dd(ids), "left": dd(left), "right": dd(right), "skip": None}
+    out = {}
+    for stereo in (False, True):
+        with BatchedFilter(B, prm) as fa, BatchedFilter(B, prm) as fb:
+            for f in (fa, fb):
+                f.set_state(nom, rot, None, np.zeros(B, np.int32))
+                f.reset_cov()
+            assert fa.launch_info(capi.INFO_ROLES_MEAS, M) == 1
+            sa, oka = _run(fa, True, d, K, "pixels", stereo, capi.MODE_STACKED)
+            sb, okb = _run(fb, False, d, K, "pixels", stereo, capi.MODE_STACKED)
+        assert oka.all() and okb.all()
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y)
+        Ps = sa[2][::97].astype(np.float64)
+        assert np.isfinite(sa[0]).all() and np.isfinite(Ps).all() and np.array_equal(Ps, np.swapaxes(Ps, 1, 2))
+        dg = np.sqrt(np.einsum("bii->bi", Ps))
+        assert np.linalg.eigvalsh(Ps / (dg[:, :, None] * dg[:, None, :])).min() > 0

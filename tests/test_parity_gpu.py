@@ -13,7 +13,7 @@ import pytest
 import oracle_capi as oc
 from fbus_ekf import BatchedFilter, capi, replay, synth
 from replay_ref import OracleEngine
-from util import (COV_BLOCK_TOL, COV_TOL, PLAIN_TOL, PLAIN_WINDOW_TOL, STATE_TOL, WINDOW_TOL, assert_parity, cov_rel_err,
+from util import (COV_BLOCK_TOL, COV_TOL, PLAIN_TOL, PLAIN_WINDOW_TOL, STATE_TOL, WINDOW_TOL, assert_parity, assert_window_parity, cov_rel_err,
                   cov_rel_err_blockwise, parity_errors, rot_rel_err, state_rel_err, state_rel_err_literal,
                   state_rel_err_plain)
 
@@ -556,8 +556,10 @@ def test_frame_window_equals_a_sequence_of_fused_frames(dialect, mode):
             if dtype == 64:
                 assert max(e["literal"], e["sigma"], e["plain"], e["cov"]) <= 1e-9 and e["cov_block"] <= 1e-11
             else:
-                assert e["literal"] <= 5e-5 and e["sigma"] <= WINDOW_TOL and e["plain"] <= PLAIN_WINDOW_TOL
-                assert e["cov"] <= COV_TOL and e["cov_block"] <= COV_BLOCK_TOL
+                # tests/util.py's window gate: literal 1e-5 (C++ dialect, N = 18: the stated 5e-5 -- util.py); here the block-wise
+                # covariance even meets its single-step bound
+                assert_window_parity(sa, eng.get_state(), f"frame window d{dialect} mode {mode} fp32 (gate)", dialect, 18, verbose=False)
+                assert e["cov_block"] <= COV_BLOCK_TOL
             assert e["asym"] == 0 and e["prev_equal"]
     prm.cov_form = capi.COV_SIMPLE
 

@@ -12,7 +12,7 @@ import pytest
 
 from fbus_ekf import BatchedFilter, capi, synth
 from replay_ref import OracleEngine
-from util import assert_parity, parity_errors
+from util import assert_parity, assert_window_parity, parity_errors
 
 pytestmark = pytest.mark.gpu
 DT = np.array([np.float64(np.float32(0.005))])
@@ -242,17 +242,12 @@ def test_team_frame_window_equals_one_wave_window(dialect, mode, n):
         k0 += K
         ids_f = ids[f].copy(); ids_f[skip[f] == 1] = -1
         eng.correct(ids_f, pos[f], quat[f], mode)
+    # the window gate of tests/util.py (literal 1e-5; C++ dialect with N = 18: the stated 5e-5, see util.py / profiles/r05_window_quantisation.txt)
     for what in ("one-wave", "team"):
-        e = parity_errors(out[what], eng.get_state())
-        print(f"[parity] {what} frame window d{dialect} mode {mode} N {n}: literal {e['literal']:.2e} sigma {e['sigma']:.2e} "
-              f"plain {e['plain']:.2e} cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
-        assert e["literal"] <= 5e-5 and e["sigma"] <= 5e-5 and e["plain"] <= 2e-2, (what, e)
-        assert e["cov"] <= 2e-5 and e["cov_block"] <= 2e-4 and e["asym"] == 0 and e["prev_equal"], (what, e)
-    # team against one-wave: contraction differences of single steps (1 ulp), carried through 16 ImuUpdates and 4 MeasureUpdates
-    e = parity_errors(out["team"], out["one-wave"])
-    print(f"[team vs one-wave] literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} cov {e['cov']:.2e} "
-          f"cov block-wise {e['cov_block']:.2e}")
-    assert e["literal"] <= 5e-5 and e["sigma"] <= 5e-5 and e["cov"] <= 1e-5 and e["cov_block"] <= 1e-4 and e["prev_equal"], e
+        assert_window_parity(out[what], eng.get_state(), f"{what} frame window d{dialect} mode {mode} N {n}", dialect, n)
+    # team against one-wave: contraction differences of single steps (1 ulp), carried through 16 ImuUpdates and 4 MeasureUpdates --
+    # two fp32 runs differ by what the window gate allows either of them against the oracle
+    assert_window_parity(out["team"], out["one-wave"], f"team vs one-wave frame window d{dialect} mode {mode} N {n}", dialect, n)
 
 
 def test_team_frame_is_the_default_for_small_batches_and_long_windows():
@@ -294,10 +289,7 @@ def test_team_frame_is_the_default_for_small_batches_and_long_windows():
             eng.predict(acc[k0 + k][sub], gyr[k0 + k][sub], dtb[k0 + k][sub])
         k0 += K
         eng.correct(ids[f][sub], pos[f][sub], quat[f][sub], capi.MODE_STACKED)
-    e = parity_errors(tuple(x[sub] for x in out["team"]), eng.get_state())
-    print(f"[parity] team frame window, 64 frames / {Kt} steps: literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} "
-          f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
-    assert e["literal"] <= 2e-4 and e["sigma"] <= 2e-4 and e["cov"] <= 5e-5 and e["asym"] == 0 and e["prev_equal"], e
+    assert_window_parity(tuple(x[sub] for x in out["team"]), eng.get_state(), f"team frame window, 64 frames / {Kt} steps", dialect, n)
     # the long run: the one-shot form P - W W' of the divided MeasureUpdate, 256 times in a row between ~1300 fp32 predicts, must
     # stay with the oracle and keep every covariance symmetric positive definite
     for _ in range(3):
@@ -307,14 +299,14 @@ def test_team_frame_is_the_default_for_small_batches_and_long_windows():
                 eng.predict(acc[k0 + k][sub], gyr[k0 + k][sub], dtb[k0 + k][sub])
             k0 += K
             eng.correct(ids[f][sub], pos[f][sub], quat[f][sub], capi.MODE_STACKED)
-    e = parity_errors(tuple(x[sub] for x in long_run), eng.get_state())
     Pl = np.asarray(long_run[2], np.float64)
     min_eig = np.linalg.eigvalsh(Pl[::16]).min(axis=1)
     dmin = np.einsum("bii->bi", Pl[::16]).min(axis=1)
-    print(f"[parity] team frame window, 256 frames / {4 * Kt} steps: literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} "
-          f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}; min eigenvalue / min diagonal over 1024 filters {np.min(min_eig / dmin):.2e}")
-    assert np.isfinite(Pl).all() and (min_eig > 0).all() and e["asym"] == 0
-    assert e["literal"] <= 5e-4 and e["sigma"] <= 5e-4 and e["cov"] <= 2e-4, e
+    print(f"[parity] team frame window, 256 frames: min eigenvalue / min diagonal over 1024 filters {np.min(min_eig / dmin):.2e}")
+    assert np.isfinite(Pl).all() and (min_eig > 0).all()
+    # 256 frames are beyond the 100-frame window the gate is stated for; the run meets it all the same (measured: literal 1e-6,
+    # sigma-aware 1.3e-5, covariance 5e-6)
+    assert_window_parity(tuple(x[sub] for x in long_run), eng.get_state(), f"team frame window, 256 frames / {4 * Kt} steps", dialect, n)
 
 
 def test_team_frame_window_at_512_tiles_two_workgroups_per_cu():
@@ -350,7 +342,4 @@ def test_team_frame_window_at_512_tiles_two_workgroups_per_cu():
                 eng.predict(acc[k0 + k][sub], gyr[k0 + k][sub], DT)
             k0 += K
             eng.correct(ids[f][sub], pos[f][sub], quat[f][sub], mode)
-    e = parity_errors(tuple(x[sub] for x in runs[0]), eng.get_state())
-    print(f"[parity] team frame windows at 32 768 filters: literal {e['literal']:.2e} sigma {e['sigma']:.2e} plain {e['plain']:.2e} "
-          f"cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
-    assert e["literal"] <= 1e-4 and e["sigma"] <= 1e-4 and e["cov"] <= 2e-5 and e["asym"] == 0 and e["prev_equal"], e
+    assert_window_parity(tuple(x[sub] for x in runs[0]), eng.get_state(), "team frame windows at 32 768 filters", dialect, n)

@@ -126,10 +126,14 @@ def test_corners_to_correct_chain_on_device():
     eng = OracleEngine(B, 1, 18)
     eng.set_state(nom, rot, P, prev)
     eng.correct(np.zeros((B, 1), np.int32), o_pos[:, None, :], o_quat[:, None, :], 0)
-    # the measurement itself carries fp32 triangulation error (~2e-6 m): compare at that scale
-    assert state_rel_err(g[0], eng.nominal, eng.P)[0] <= 10 * STATE_TOL
-    assert cov_rel_err(g[2], eng.P) <= COV_TOL
-    assert cov_rel_err_blockwise(g[2], eng.P) <= 10 * COV_BLOCK_TOL
+    # (round 5) marker_pose_kernel<float> triangulates and fits the pose in double (rounds 1-4: in fp32, ~2e-6 m off in the corner
+    # positions, 10x gates here): the measurement reaches correct() rounded to fp32 once, the standard single-step gates apply
+    es, where = state_rel_err(g[0], eng.nominal, eng.P)
+    ec, eb = cov_rel_err(g[2], eng.P), cov_rel_err_blockwise(g[2], eng.P)
+    print(f"[parity] marker_pose -> correct chain fp32: sigma-aware {es:.2e} ({where}) cov {ec:.2e} cov block-wise {eb:.2e}")
+    assert es <= STATE_TOL
+    assert ec <= COV_TOL
+    assert eb <= COV_BLOCK_TOL
 
 
 def test_large_batch_properties():

@@ -128,6 +128,45 @@ COV_BLOCK_TOL_F64 = 1e-11
 F64_TOL = 1e-9
 
 
+# Free-running WINDOWS (no re-seeding from the oracle; <= 100 frames): assert_window_parity below.
+#   literal   <= STATE_TOL (1e-5), the north star's figure -- with ONE stated exception, WINDOW_LITERAL_TOL_CPP18:
+#             the C++ dialect's constants (P0_v = 1e-2, P0_g = 100, R = 1e-3: paramconfig.yml:46-54, filter.hpp:29-34) with N = 18.
+#             The first camera frames resolve gravity from sigma = 10 m/s^2 through the velocity block; every step's output is
+#             rounded to an fp32 record (the north star's record type), and this start-up transient amplifies that rounding:
+#             tools/emul_window_quantisation.py runs the fp64 ORACLE on the window tests' own inputs with the record rounded to
+#             fp32 after every step -- EXACT arithmetic, fp32 records -- and reads, after 4 frames, literal 7.0e-6 against the fp64
+#             run, and 2.4e-5 between two such runs whose roundings differ by half an ulp (profiles/r05_window_quantisation.txt;
+#             measured on the device: kernel vs oracle 2.4e-5, team kernel vs one-wave kernel 2.45e-5).  No fp32-record filter
+#             can meet 1e-5 there; the Matlab dialect (7e-6 measured) and every N = 15 case (3e-7) do.  Single steps re-seeded
+#             from the oracle meet 1e-5 in every dialect (assert_parity).
+#   sigma     <= WINDOW_TOL (1e-4), plain <= PLAIN_WINDOW_TOL, cov <= COV_TOL (1e-4), cov-block <= 10 x COV_BLOCK_TOL
+WINDOW_LITERAL_TOL_CPP18 = 5e-5
+WINDOW_COV_BLOCK_TOL = 10 * COV_BLOCK_TOL
+
+
+def window_literal_tol(dialect, nstate):
+    """the literal state gate of a free-running window: 1e-5, except the C++ dialect with N = 18 (see above)"""
+    return WINDOW_LITERAL_TOL_CPP18 if (dialect == 1 and nstate == 18) else STATE_TOL
+
+
+def assert_window_parity(got, ref, what, dialect, nstate, verbose=True, prev=True):
+    """THE gate of free-running windows (fp32 kernels against the fp64 oracle, or two fp32 kernel forms against each other)."""
+    e = parity_errors(got, ref)
+    if verbose:
+        print(f"[parity] {what}: literal {e['literal']:.2e}  sigma-aware {e['sigma']:.2e} ({e['sigma_block']})  "
+              f"plain per-block {e['plain']:.2e} ({e['plain_block']})  cov {e['cov']:.2e}  cov block-wise {e['cov_block']:.2e}")
+    lit = window_literal_tol(dialect, nstate)
+    assert e["literal"] <= lit, f"{what}: literal state rel err {e['literal']:.3g} > {lit:g}"
+    assert e["sigma"] <= WINDOW_TOL, f"{what}: state rel err {e['sigma']:.3g} in block {e['sigma_block']}"
+    assert e["plain"] <= PLAIN_WINDOW_TOL, f"{what}: plain per-block state rel err {e['plain']:.3g} in block {e['plain_block']}"
+    assert e["cov"] <= COV_TOL, f"{what}: covariance rel err {e['cov']:.3g}"
+    assert e["cov_block"] <= WINDOW_COV_BLOCK_TOL, f"{what}: block-wise covariance rel err {e['cov_block']:.3g}"
+    assert e["asym"] == 0, f"{what}: covariance not exactly symmetric"
+    if prev:
+        assert e["prev_equal"], f"{what}: prev marker id"
+    return e
+
+
 def parity_errors(got, ref):
     """got / ref = (nominal, rot, P, prev) -> dict of every error figure the gates use"""
     g_nom, g_rot, g_P = (np.asarray(x, np.float64) for x in got[:3])
