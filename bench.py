@@ -507,12 +507,13 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
              ("fused_frame_pixels_m16_stereo", 16, "pixels", 18, True, True), ("fused_frame_corners_m4", 4, "corners", 18, True, True))
     scenes = {}
     for name, slots, kind, nstate, stereo, fused in cases:
-        prm = capi.default_params(capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP)
         size = 0.15
-        prm.marker_size = size
         if slots not in scenes:
-            scenes[slots] = synth.pixel_wall_scene(B, slots, prm, size, seed=9, stereo=True)
-        nom, rot, ids, left, right = scenes[slots]
+            # (pixel_wall_scene REPLACES the marker map inside the parameter set by its wall of 16 markers: the parameters belong to the scene)
+            prm = capi.default_params(capi.DIALECT_MATLAB if args.dialect == "matlab" else capi.DIALECT_CPP)
+            prm.marker_size = size
+            scenes[slots] = (prm,) + tuple(synth.pixel_wall_scene(B, slots, prm, size, seed=9, stereo=True))
+        prm, nom, rot, ids, left, right = scenes[slots]
         acc, gyr = synth.imu_samples(0, B, 0, sum(PATTERN), nom)
         d_acc, d_gyr = f32(acc), f32(gyr)
         d_dt = torch.full((max(PATTERN),), 0.005, dtype=torch.float32, device=dev)

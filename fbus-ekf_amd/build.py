@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Builds fbus-ekf_amd/lib/libfbus_ekf.so (HIP, gfx950) in-tree with hipcc.
 
-The library is 23 translation units compiled in parallel and linked into one shared object:
+The library is 25 translation units compiled in parallel and linked into one shared object:
   fbus_ekf.hip                          handle, C ABI, the small kernels (pack/unpack, init, EMA, marker pose)
-  kernels_tu.hip x 22                   one kernel family for one (float|double, N = 18|15), both dialects (-DFBUS_TU_T/N/FAMILY):
-                                        float: predict / correct / frame / frames / team / meas / fmeas (7 x 2 = 14),
-                                        double: predict / correct / frame / meas (4 x 2 = 8; len(units()) == 23 with fbus_ekf.hip)
+  kernels_tu.hip x 24                   one kernel family for one (float|double, N = 18|15), both dialects (-DFBUS_TU_T/N/FAMILY):
+                                        float: predict / correct / frame / frames / team / meas / fmeas / msplit (8 x 2 = 16),
+                                        double: predict / correct / frame / meas (4 x 2 = 8; len(units()) == 25 with fbus_ekf.hip)
 Objects live in fbus-ekf_amd/lib/obj/ (git-ignored) and are rebuilt when a source they include is newer.
   python build.py [--force] [--only f32_18_correct,...] [--jobs N]
 FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds (A/B of differently built kernels via FBUS_EKF_LIB).
@@ -17,12 +17,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HEADERS = [os.path.join(CSRC, h) for h in ("ekf_kernels.hpp", "ekf_device.hpp", "vision_device.hpp", "ekf_launch.hpp", "ekf_team.hpp", "ekf_meas.hpp")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("ekf_kernels.hpp", "ekf_device.hpp", "vision_device.hpp", "ekf_launch.hpp", "ekf_team.hpp", "ekf_meas.hpp", "ekf_meas_split.hpp")] + \
           [os.path.join(HERE, "..", "include", "fbus_ekf.h")]
 OUT = os.environ.get("FBUS_OUT") or os.path.join(HERE, "lib", "libfbus_ekf.so")   # FBUS_OUT / FBUS_EXTRA_FLAGS: experiment builds
 OBJDIR = os.environ.get("FBUS_OBJDIR") or os.path.join(os.path.dirname(OUT), "obj" if not os.environ.get("FBUS_OUT") else
                                                        "obj_" + os.path.splitext(os.path.basename(OUT))[0])
-FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "frames": 5, "team": 6, "meas": 7, "fmeas": 8}
+FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "frames": 5, "team": 6, "meas": 7, "fmeas": 8, "msplit": 9}
 # Per-family scheduler choice (measured in one run, B = 65 536, tools/ab_bench.sh, profiles/logs/r02_ab2.log): the
 # max-ILP strategy of the AMDGPU machine scheduler shortens the per-call kernels, where one wave per SIMD has nothing
 # but its own independent instructions to cover dependent-issue stalls (predict 13.4 -> 13.05 us, stacked correct
@@ -32,7 +32,7 @@ FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "correct": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "frame": [], "frames": [],
                 "team": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "meas": os.environ.get("FBUS_MEAS_FLAGS", "").split(),
-                "fmeas": os.environ.get("FBUS_FMEAS_FLAGS", "").split()}
+                "fmeas": os.environ.get("FBUS_FMEAS_FLAGS", "").split(), "msplit": os.environ.get("FBUS_MSPLIT_FLAGS", "").split()}
 TYPES = {"f32": "float", "f64": "double"}
 
 
@@ -49,7 +49,7 @@ def units():
     for tn, t in TYPES.items():
         for n in (18, 15):
             for fam, code in FAMILIES.items():
-                if fam in ("frames", "team", "fmeas") and tn == "f64":
+                if fam in ("frames", "team", "fmeas", "msplit") and tn == "f64":
                     continue                    # fp64: one fused frame kernel (family "frame": frame2_kernel), windows frame by frame
                 out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
                             [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"] +

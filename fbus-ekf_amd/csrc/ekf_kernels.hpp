@@ -5,6 +5,7 @@
 #include "../../include/fbus_ekf.h"
 #include "ekf_device.hpp"
 #include "vision_device.hpp"
+#include "ekf_launch.hpp"      // TileMap, LaunchPolicy
 
 #include <hip/hip_runtime.h>
 
@@ -460,13 +461,21 @@ template <typename T> constexpr int park_nom_chunks() { return sizeof(T) == 8 ? 
 template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST, bool PARK = false>
 __global__ void __launch_bounds__(BLOCK, (PARK && sizeof(T) == 4) ? 2 : 1)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
-               const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
+               const T* __restrict__ dt, int dt_stride, DevConst<T> dc, TileMap tm)
 {
-    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    // (MULTI: always the plain mapping.)  K = 1: the tiles behind tm.full as sub-tile waves -- see TileMap (ekf_launch.hpp)
+    unsigned tile_ = blockIdx.x;
+    if (!MULTI && tile_ >= tm.full) {
+        const unsigned w = tile_ - tm.full;
+        tile_ = tm.full + (w >> tm.shift);
+        if ((threadIdx.x >> (6u - tm.shift)) != (w & ((1u << tm.shift) - 1u))) return;
+    }
+    const unsigned tile = __builtin_amdgcn_readfirstlane(tile_);
+    const int b = (int)(tile * BLOCK + threadIdx.x);
     if (b >= B) return;
     using RC = Rec<T, N>;
     constexpr int EPC = RC::EPC, CN = RC::CH_NOM;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
     T nom[Lay<N>::NNOM], P[RC::NCOVP];
     if (MULTI) {
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);

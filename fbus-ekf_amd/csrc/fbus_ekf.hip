@@ -135,6 +135,7 @@ struct fbus_ekf {
     // 2..4 = always with that many roles (fbus_ekf_set_team, FBUS_TEAM_PREDICT / FBUS_TEAM_CORRECT at create)
     int team_predict = 0, team_correct = 0;
     int team_frame = 0;               // FBUS_TEAM_FRAME: 0 = follows team_predict, 1 = never, 2 = always
+    int meas_split = -1;              // FBUS_MEAS_SPLIT: -1 auto, 0 never, 2 / 4: always the divided-update pixel kernel with that many waves per tile
     bool no_frame_meas = false;       // FBUS_NO_FRAME_MEAS=1 (A/B runs): fbus_ekf_frame_meas_fused_dev always as predict_n + the per-call update
     fbus_params prm{};
     HostConst hc;
@@ -289,6 +290,20 @@ int team_roles_pixels(const fbus_ekf* h, int M)
     if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
     const int tiles = policy_tiles(h);
     return tiles <= quarter_chip(h) ? 4 : (tiles <= half_chip(h) ? 2 : 1);
+}
+// (round 5) correct_pixels with the UPDATE divided between the waves of a tile as well (ekf_meas_split.hpp: a solver and an updater wave,
+// every wave below 256 registers): 0 = not this launch (the one-wave-tail kernel with team_roles_pixels' fold roles), 2 = two waves per
+// tile (from a quarter of the chip on, full-chip launches included: two waves per SIMD there), 4 = four (small launches).  fp32
+// records and the port square to the camera only; fbus_ekf_set_team's correct_roles = 1 keeps the one-wave kernel.
+int meas_split_roles(const fbus_ekf* h, int M)
+{
+    const double* n = h->prm.port_normal;
+    if (h->dtype != 32 || M < 2 || h->team_correct == 1 || h->meas_split == 0) return 0;
+    if (!(n[0] == 0.0 && n[1] == 0.0 && n[2] == 1.0)) return 0;
+    if (h->meas_split > 0) return h->meas_split;
+    if (h->team_correct >= 2) return h->team_correct >= 3 ? 4 : 2;
+    const int tiles = policy_tiles(h);
+    return tiles <= quarter_chip(h) ? 4 : (tiles <= half_chip(h) ? 2 : 0);
 }
 // fused frame / frame window (frames_team_kernel: the predict_n pipeline + the one-shot correct divided over the four roles).  Follows the predict
 // setting (fbus_ekf_set_team: 1 = never, 2..4 = always); FBUS_TEAM_FRAME=1|2 overrides.  Two workgroups of four waves fit a CU
@@ -657,9 +672,17 @@ int launch_correct_pixels_t(fbus_ekf_t h, int M, const int32_t* ids, const void*
     // double-precision fold + non-cancelling update (ekf_meas.hpp), both record types, either covariance form (the form is
     // symmetric by construction and subtracts nothing on the rows the measurement shrinks: what Joseph's form is chosen for)
     h->records_warm = h->warm_after_correct;          // written through (sc1), as correct_kernel's records
-    const int roles = team_roles_pixels(h, M);
-    launch_pixels2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, roles,
-                              h->prm.marker_size, h->prm.r_pix, (const unsigned char*)skip, h->d_applied, h->d_id2slot, make_mc(h));
+    const int split = meas_split_roles(h, M);
+    if constexpr (sizeof(T) == 4) {
+        if (split > 0)
+            launch_pixels_split_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, split,
+                                           h->prm.marker_size, h->prm.r_pix, (const unsigned char*)skip, h->d_applied, h->d_id2slot, make_mc(h));
+    }
+    if (split == 0 || sizeof(T) != 4) {
+        const int roles = team_roles_pixels(h, M);
+        launch_pixels2_k<T, N, D>(h->stream, (T*)h->recs, h->B, M, (const int*)ids, (const T*)left, (const T*)right, roles,
+                                  h->prm.marker_size, h->prm.r_pix, (const unsigned char*)skip, h->d_applied, h->d_id2slot, make_mc(h));
+    }
     timing_end(h, ev);
     HIP_TRY(h, hipGetLastError());
     return FBUS_OK;
@@ -680,7 +703,7 @@ int launch_frame_meas_t(fbus_ekf_t h, int K, const void* accel, const void* gyro
                         const int32_t* ids, const void* left, const void* right, int geometry, int mode, const uint8_t* skip)
 {
     const int roles = (kind == MEAS_CORNERS && mode != MODE_STACKED) ? 1 : team_roles_pixels(h, M);
-    const bool fused = sizeof(T) == 4 && K > 0 && M > 0 && roles == 1 && !h->no_frame_meas;
+    const bool fused = sizeof(T) == 4 && M > 0 && roles == 1 && !h->no_frame_meas;
     if (!fused) {
         int rc = FBUS_OK;
         if (K > 0) rc = launch_predict_t<T, N, D>(h, K, accel, gyro, dt, dt_per_filter);
@@ -885,6 +908,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
         h->lp.two_wave_min_b = simds * 64 + 1;
         if (const char* e = std::getenv("FBUS_TWO_WAVE_MIN_B")) h->lp.two_wave_min_b = std::atoi(e);
         h->lp.meas_vec = std::getenv("FBUS_NO_MEAS_VEC") == nullptr;
+        h->lp.tail_split = std::getenv("FBUS_NO_TAIL_SPLIT") == nullptr;
         // 256 MiB is MI355X's (and MI300X's) Infinity Cache whatever the CU count of the SKU: not scaled with the device; only the
         // test knob FBUS_FAKE_SIMDS (a pretended smaller chip) scales it down with the SIMD count, FBUS_MALL_MB sets it outright
         h->mall_bytes = (size_t)256 << 20;
@@ -900,6 +924,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
     if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
     if (const char* e = std::getenv("FBUS_NO_FRAME_MEAS")) h->no_frame_meas = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FBUS_MEAS_SPLIT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 4 || v == 12) h->meas_split = v; }
     if (const char* e = std::getenv("FBUS_TEAM_FRAME")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->team_frame = v; }
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);
@@ -990,6 +1015,7 @@ int fbus_ekf_launch_info(fbus_ekf_t h, int what, int arg, int* value)
         case FBUS_INFO_ROLES_PREDICT: *value = team_roles_predict(h, arg > 1 ? arg : 1); break;
         case FBUS_INFO_ROLES_MEAS: *value = team_roles_pixels(h, arg > 0 ? arg : 4); break;
         case FBUS_INFO_TEAM_FRAMES: *value = team_frames(h, MODE_STACKED) ? 1 : 0; break;
+        case FBUS_INFO_MEAS_SPLIT: *value = meas_split_roles(h, arg > 0 ? arg : 4); break;
         default: return FBUS_ERR_INVALID;
     }
     return FBUS_OK;

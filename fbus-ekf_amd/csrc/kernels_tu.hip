@@ -7,12 +7,16 @@
 //   5 frame window (F frames per launch)
 //   6 team kernels (several waves per tile: predict, predict_n, frame window; fp32 only)
 //   7 correct from corner pixels / from stereo corners (ekf_meas.hpp: double-precision fold, non-cancelling update)
+//   9 correct from corner pixels with the update divided between the waves of a tile (ekf_meas_split.hpp; fp32 only)
 //   8 fused frame with that update (K predicts + correct_pixels / correct_corners in one launch; fp32 only)
 // gfx950 only.
 #include <cstdlib>
 #include "ekf_kernels.hpp"
 #include "ekf_team.hpp"
 #include "ekf_meas.hpp"
+#if FBUS_TU_FAMILY == 9
+#include "ekf_meas_split.hpp"
+#endif
 #include <atomic>
 #include "ekf_launch.hpp"
 
@@ -36,12 +40,16 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
                       int dt_stride, const DevConst<T>& dc, const LaunchPolicy& lp)
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
+    TileMap plain;
+    plain.full = (unsigned)grid;
     // policy 0: nt loads and stores; 1: default-policy loads (first predict behind a kernel that stored the records with
     // the default policy); 2: default loads and stores (records do not fit the Infinity Cache) -- see predict_kernel
     if (K == 1) {
+        // more than one round of waves: the tiles beyond the last whole round as sub-tile waves, spread over all CUs (TileMap)
+        const TileMap tm = lp.tail_split ? TileMap::balanced((unsigned)grid, (unsigned)lp.simds) : plain;
 #define FBUS_LAUNCH_PREDICT(LD, ST)                                                                                     \
-    hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD, ST>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, \
-                       dt_stride, dc)
+    hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD, ST>), dim3(tm.grid((unsigned)grid)), dim3(BLOCK), 0, s, recs, B, K, accel, \
+                       gyro, dt, dt_stride, dc, tm)
         if (policy == 2) FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD_BIG, FBUS_X_PREDICT_ST_BIG);      // records larger than the Infinity Cache
         else if (policy == 1) FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD_WARM, AUX_NT);      // first predict behind a default-policy writer
         else FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD, FBUS_X_PREDICT_ST);
@@ -51,13 +59,13 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
         // LDS between their uses (StepPark; 512 registers, one wave per SIMD).  Rounds 1-3 ran predict_n as K launches of the per-call
         // kernel -- the resident loop spilled 580 bytes per lane; the parked form spills 68 (N = 18) / 0 (N = 15).
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
-                           K, accel, gyro, dt, dt_stride, dc);
+                           K, accel, gyro, dt, dt_stride, dc, plain);
     } else if (lp.two_wave(B)) {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
-                           K, accel, gyro, dt, dt_stride, dc);
+                           K, accel, gyro, dt, dt_stride, dc, plain);
     } else {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt,
-                           dt_stride, dc);
+                           dt_stride, dc, plain);
     }
 }
 #define FBUS_INST(D)                                                                                                  \
@@ -294,8 +302,28 @@ void launch_frame_meas_k(hipStream_t s, T* recs, int B, int K, const T* accel, c
                                                                double, const unsigned char*, unsigned char*, const short*, \
                                                                const MeasConst&, const VisConst<double>&,               \
                                                                const VisConst<FBUS_TU_T>&, const FBUS_TU_T*);
+#elif FBUS_TU_FAMILY == 9
+template <typename T, int N, int D>
+void launch_pixels_split_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, double size,
+                           double r_pix, const unsigned char* skip, unsigned char* applied, const short* id2slot, const MeasConst& mc)
+{
+    const int tiles = (B + 63) / 64;
+    if (roles >= 3)
+        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 4, false>), dim3(tiles), dim3(256), 0, s, recs, B, M, ids, left, right, size,
+                           r_pix, skip, applied, id2slot, mc);
+    else if (roles == 12)       // experiment (FBUS_MEAS_SPLIT=12): two waves per tile with the 256-register corner-by-corner fold
+        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 2, true>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right, size,
+                           r_pix, skip, applied, id2slot, mc);
+    else
+        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 2, false>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right, size,
+                           r_pix, skip, applied, id2slot, mc);
+}
+#define FBUS_INST(D)                                                                                                   \
+    template void launch_pixels_split_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const int*, const FBUS_TU_T*, \
+                                                                 const FBUS_TU_T*, int, double, double, const unsigned char*, \
+                                                                 unsigned char*, const short*, const MeasConst&);
 #else
-#error "FBUS_TU_FAMILY must be 1, 2, 3, 5, 6, 7 or 8"
+#error "FBUS_TU_FAMILY must be 1, 2, 3, 5, 6, 7, 8 or 9"
 #endif
 
 FBUS_INST(DIALECT_MATLAB)

@@ -21,7 +21,7 @@ MAX_WINDOW_FRAMES = 64           # fbus_ekf_frames_fused_dev
 STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
 # fbus_ekf_launch_info (include/fbus_ekf.h)
 (INFO_SIMDS, INFO_ONE_ROUND_FILTERS, INFO_TWO_WAVE_MIN_B, INFO_BIG_RECORDS_MB, INFO_MALL_MB, INFO_L2_KB, INFO_POLICY_BATCH,
- INFO_ROLES_PREDICT, INFO_ROLES_MEAS, INFO_TEAM_FRAMES) = range(10)
+ INFO_ROLES_PREDICT, INFO_ROLES_MEAS, INFO_TEAM_FRAMES, INFO_MEAS_SPLIT) = range(11)
 ABI_VERSION = 5                    # FBUS_ABI_VERSION of the header this mirror was written against
 ERR_ABI = 6
 

@@ -108,7 +108,7 @@ class BatchedFilter:
                 "mall_MB": self.launch_info(c.INFO_MALL_MB), "l2_KB": self.launch_info(c.INFO_L2_KB),
                 "policy_batch": self.launch_info(c.INFO_POLICY_BATCH), "roles_predict": self.launch_info(c.INFO_ROLES_PREDICT, 1),
                 "roles_predict_n": self.launch_info(c.INFO_ROLES_PREDICT, K), "roles_meas": self.launch_info(c.INFO_ROLES_MEAS, M),
-                "team_frames": bool(self.launch_info(c.INFO_TEAM_FRAMES))}
+                "team_frames": bool(self.launch_info(c.INFO_TEAM_FRAMES)), "meas_split": self.launch_info(c.INFO_MEAS_SPLIT, M)}
 
     def wait_stream(self, stream):
         """work submitted to this filter from now on starts after everything already queued on `stream`"""

@@ -163,7 +163,9 @@ enum { FBUS_INFO_SIMDS = 0,            /* SIMDs of the device = CUs x 4 (FBUS_FA
        FBUS_INFO_POLICY_BATCH = 6,     /* see fbus_ekf_set_policy_batch                                                    */
        FBUS_INFO_ROLES_PREDICT = 7,    /* waves per tile the next predict (arg = 1) / predict_n (arg = K) would use       */
        FBUS_INFO_ROLES_MEAS = 8,       /* ... correct_corners (stacked) / correct_pixels with arg = M marker slots          */
-       FBUS_INFO_TEAM_FRAMES = 9 };    /* 1: the fused frame / frame window entry points use the team kernel              */
+       FBUS_INFO_TEAM_FRAMES = 9,      /* 1: the fused frame / frame window entry points use the team kernel              */
+       FBUS_INFO_MEAS_SPLIT = 10 };    /* (round 5) correct_pixels with arg = M: 0 = one wave applies the update, 2 / 4 = the update divided
+                                          between a solver and an updater wave, that many waves per tile (fp32, square port) */
 int fbus_ekf_launch_info(fbus_ekf_t h, int what, int arg, int* value);
 /* Cross-stream ordering without a host sync (hipEventRecord + hipStreamWaitEvent):
  * wait_stream   -- work submitted to the handle's stream after this call starts

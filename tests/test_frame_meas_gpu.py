@@ -4,9 +4,10 @@ corners (the rows of MeasureUpdate.m:67,72-73 with a corner in place of the mark
 vision.cpp:496-599) with the record resident in registers / LDS in between.
 
 What is asserted:
-  * fused == the per-call sequence (K fbus_ekf_predict_dev + one fbus_ekf_correct_pixels_dev / _corners_dev) BIT FOR BIT --
-    nominal state, carried rotation, covariance, previous marker id, applied flags -- N = 18 and N = 15, left camera and stereo,
-    corner rows stacked and nearest (C++ dialect: hysteresis), with filters that see nothing, only unknown ids, or are skipped;
+  * fused == one fbus_ekf_predict_n_dev + one fbus_ekf_correct_pixels_dev / _corners_dev launch BIT FOR BIT -- nominal state,
+    carried rotation, covariance, previous marker id, applied flags -- N = 18 and N = 15, left camera and stereo, corner rows
+    stacked and nearest (C++ dialect: hysteresis), with filters that see nothing, only unknown ids, or are skipped; against K
+    launches of the streamed per-call predict + the update: to fp32 rounding (the single-step gate);
   * fused against the fp64 oracle through the standard gate (tests/util.py::assert_parity), no widened bound;
   * the routes behind the same entry point that do NOT take the fused kernel (fp64 records, the team forms of small launches,
     M = 0) give the per-call results too;
@@ -53,14 +54,18 @@ CASES = [("pixels", False, capi.MODE_STACKED), ("pixels", True, capi.MODE_STACKE
 
 
 def _run(flt, fused, d, K, what, stereo, mode):
-    """one frame through the fused entry point, or as K per-call predicts + one per-call update"""
+    """one frame through the fused entry point ("fused"), as ONE predict_n launch + one per-call update ("n"), or as K per-call
+    predicts + one per-call update ("k")"""
     kind = capi.MEAS_PIXELS if what == "pixels" else capi.MEAS_CORNERS
     rgt = d["right"] if stereo else None
-    if fused:
+    if fused is True or fused == "fused":
         flt.frame_meas(d["acc"][:K], d["gyr"][:K], d["dt"][:K], d["ids"], d["left"], rgt, kind, capi.VIS_REFRACTIVE, mode, skip=d["skip"])
     else:
-        for k in range(K):
-            flt.predict(d["acc"][k], d["gyr"][k], d["dt"][:1])
+        if fused == "n":
+            flt.predict_n(d["acc"][:K], d["gyr"][:K], d["dt"][:K])
+        else:
+            for k in range(K):
+                flt.predict(d["acc"][k], d["gyr"][k], d["dt"][:1])
         if what == "pixels":
             flt.correct_pixels(d["ids"], d["left"], rgt, d["skip"])
         else:
@@ -90,15 +95,23 @@ def test_fused_frame_equals_the_per_call_sequence_bit_for_bit_and_the_oracle(dia
             if ids[b, m] >= 0:
                 corners[b, m] = oc.refraction_triangulate(vp, left[b, m], right[b, m])
     for what, stereo, mode in CASES:
-        with BatchedFilter(B, prm, nstate=n) as fa, BatchedFilter(B, prm, nstate=n) as fb:
-            for f in (fa, fb):
+        with BatchedFilter(B, prm, nstate=n) as fa, BatchedFilter(B, prm, nstate=n) as fb, BatchedFilter(B, prm, nstate=n) as fc:
+            for f in (fa, fb, fc):
                 f.set_team(1, 1)                                      # one wave per tile: the forms a full-chip launch runs
                 f.set_state(nom, rot, P, prev)
-            sa, oka = _run(fa, True, d, K, what, stereo, mode)
-            sb, okb = _run(fb, False, d, K, what, stereo, mode)
-        assert (oka == okb).all()
+            sa, oka = _run(fa, "fused", d, K, what, stereo, mode)
+            sb, okb = _run(fb, "n", d, K, what, stereo, mode)
+            sc, okc = _run(fc, "k", d, K, what, stereo, mode)
+        assert (oka == okb).all() and (oka == okc).all()
+        # bit for bit against predict_n + the per-call update: the resident K-step loop (predict_steps) and the fold / update functions
+        # are the ones those two kernels run, on the same values
         for x, y, name in zip(sa, sb, ("nominal", "rot", "P", "prev")):
-            assert np.array_equal(x, y), f"{what} stereo={stereo} mode={mode}: fused != per-call in {name}: {np.abs(x.astype(np.float64) - y).max():.3g}"
+            assert np.array_equal(x, y), f"{what} stereo={stereo} mode={mode}: fused != predict_n + update in {name}: {np.abs(x.astype(np.float64) - y).max():.3g}"
+        # against K launches of the streamed per-call predict + the update: the same device functions compiled into a different kernel --
+        # which product of an a b + c d the compiler fuses differs (the fused pose frame shows the same, tests/test_parity_gpu.py): a few
+        # ulp on velocities near zero and on small covariance elements.  Two fp32 runs of the same K + 1 steps: the single-step gate.
+        assert_parity(sa, sc, 32, f"fused frame vs K per-call predicts + update, N={n} dialect {dialect} {what} {'stereo' if stereo else 'left'} mode {mode}",
+                      plain_tol=PLAIN_WINDOW_TOL)
         # ... and the oracle: K ImuUpdates + the update on the fp64 side, the standard gate (a chain of K + 1 steps without
         # re-seeding: the plain per-block figure gets its free-running bound, as in smoke(); every other figure the single-step one)
         eng = OracleEngine(B, dialect, n)
@@ -170,7 +183,7 @@ def test_rejected_calls_leave_the_state_alone():
 
 def test_fused_frame_at_the_bench_size():
     """65 536 filters x 4 marker slots (the `fused_frame_pixels_m4` row of bench.py): the automatic policy takes the fused kernel
-    here; fused == per-call bit for bit on every filter, posterior symmetric positive definite, everything finite"""
+    here; fused == predict_n + the per-call update bit for bit on every filter, posterior symmetric positive definite, everything finite"""
     import torch
     B, M, K = 65536, 4, 7
     prm = capi.default_params(0)
@@ -185,9 +198,9 @@ def test_fused_frame_at_the_bench_size():
             for f in (fa, fb):
                 f.set_state(nom, rot, None, np.zeros(B, np.int32))
                 f.reset_cov()
-            assert fa.launch_info(capi.INFO_ROLES_MEAS, M) == 1
-            sa, oka = _run(fa, True, d, K, "pixels", stereo, capi.MODE_STACKED)
-            sb, okb = _run(fb, False, d, K, "pixels", stereo, capi.MODE_STACKED)
+            assert fa.launch_info(capi.INFO_ROLES_MEAS, M) == 1 and fa.launch_info(capi.INFO_MEAS_SPLIT, M) == 0
+            sa, oka = _run(fa, "fused", d, K, "pixels", stereo, capi.MODE_STACKED)
+            sb, okb = _run(fb, "n", d, K, "pixels", stereo, capi.MODE_STACKED)
         assert oka.all() and okb.all()
         for x, y in zip(sa, sb):
             assert np.array_equal(x, y)
