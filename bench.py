@@ -480,7 +480,7 @@ def _pixels_sq_profile():
         return None
 
 
-def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, warmup=1):
+def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, warmup=1, hbm_resident=False):
     """The north star's OWN MeasureUpdate -- flat-port refractive stereo reprojection of the ArUco corners, per-corner 2 x N
     Jacobians (fbus_ekf_correct_pixels_dev, csrc/ekf_meas.hpp) -- in the headline's mixed workload: the same 200 Hz + 30 Hz
     schedule (7 / 7 / 6 per-call predicts, then a camera frame; one bench step = 1 s of sensor time = 230 EKF steps per filter)
@@ -500,11 +500,17 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
     out = {}
     prof = _pixels_sq_profile()
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    if hbm_resident:
+        # past the Infinity Cache: 524 288 filters = 419 MB of records (+ 67 MB of image points per camera); what a VALU-bound update and
+        # the memory-bound predicts between the frames do when nothing stays cache-resident from launch to launch
+        B, steps = 524288, 1
     cases = (("pixels_m4", 4, "pixels", 18, False, False), ("pixels_m4_stereo", 4, "pixels", 18, True, False),
              ("pixels_m16", 16, "pixels", 18, False, False), ("pixels_m16_stereo", 16, "pixels", 18, True, False),
              ("corners_m4", 4, "corners", 18, True, False), ("pixels_m4_n15", 4, "pixels", 15, False, False),
              ("fused_frame_pixels_m4", 4, "pixels", 18, False, True), ("fused_frame_pixels_m4_stereo", 4, "pixels", 18, True, True),
              ("fused_frame_pixels_m16_stereo", 16, "pixels", 18, True, True), ("fused_frame_corners_m4", 4, "corners", 18, True, True))
+    if hbm_resident:
+        cases = (("pixels_m4", 4, "pixels", 18, False, False), ("fused_frame_pixels_m4", 4, "pixels", 18, False, True))
     scenes = {}
     for name, slots, kind, nstate, stereo, fused in cases:
         size = 0.15
@@ -585,6 +591,8 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
                                     "sq_active_inst_valu_over_wave_cycles": prof.get("SQ_ACTIVE_INST_VALU_over_SQ_WAVE_CYCLES")})
             flt.timing_enable(False)
         out[name] = blk
+    if hbm_resident:
+        out["records_MB"] = B * 800 / 1e6
     out["note"] = ("same 200 Hz + 30 Hz schedule as `value`, the camera frame applied as reprojection rows (pixels_*: left camera 2 rows per corner, "
                    "*_stereo 4 rows per corner) or as triangulated corner rows (corners_m4) instead of marker poses; per call (one launch per EKF "
                    "step) or fused_frame_* (one launch per camera frame); VALU-bound updates: read valu_issue_frac, not the byte fraction")
@@ -658,7 +666,8 @@ def main():
             dist.barrier()
 
     if args.only_pixels:
-        emit(json.dumps({"north_star_rows": north_star_rows_leg(torch, dev, local_rank, args, capi)}))
+        emit(json.dumps({"north_star_rows": north_star_rows_leg(torch, dev, local_rank, args, capi),
+                         "north_star_rows_hbm_resident": None if args.no_hbm_leg else north_star_rows_leg(torch, dev, local_rank, args, capi, hbm_resident=True)}))
         return
     w = Workload(torch, dev, local_rank, lo, hi, args, POOL if args.tile == 1 else 2, with_cov=(hi - lo) <= 131072 and args.tile == 1,
                  tile=args.tile, dtype=args.dtype)
@@ -821,6 +830,8 @@ def main():
                 skipped += ["fp64: --no-extra-legs", "north_star_rows: --no-extra-legs"]
             if args.no_cpu_baseline:
                 skipped += ["cpu_baseline: --no-cpu-baseline"]
+        if world == 1 and not strong and out["roofline"].get("traffic") is None:
+            skipped += [f"roofline.traffic: no profiles/r{PROFILE_ROUND:02d}_digest_b{args.batch}.json taken on this configuration (digests of earlier rounds' kernels are not quoted)"]
         out["legs_skipped"] = skipped
         if world == 1 and not args.no_hbm_leg and not strong and args.batch < MID_LEG_BATCH:
             out["roofline_hbm_resident"] = batch_leg(
@@ -836,6 +847,8 @@ def main():
         if world == 1 and not args.no_extra_legs and not strong:
             out["fp64"] = fp64_leg(torch, dev, local_rank, args, capi)
             out["north_star_rows"] = north_star_rows_leg(torch, dev, local_rank, args, capi)
+            if not args.no_hbm_leg:
+                out["north_star_rows_hbm_resident"] = north_star_rows_leg(torch, dev, local_rank, args, capi, hbm_resident=True)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:

@@ -5,7 +5,6 @@
 #include "../../include/fbus_ekf.h"
 #include "ekf_device.hpp"
 #include "vision_device.hpp"
-#include "ekf_launch.hpp"      // TileMap, LaunchPolicy
 
 #include <hip/hip_runtime.h>
 
@@ -19,6 +18,35 @@ namespace {
 constexpr int BLOCK = FBUS_BLOCK;       // 64 = one wave per workgroup: B/64 workgroups over 256 CUs x 4 SIMDs
 __device__ __forceinline__ unsigned my_tile() { return __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6); }
 __device__ __forceinline__ unsigned my_lane() { return threadIdx.x & 63u; }
+
+// Stagger of the four SIMDs of a CU (round 5).  A launch of one wave per SIMD runs every wave through the same phases at the same time:
+// all four waves of a CU request their records together (and store them together at the end), sharing the CU's one path to memory
+// (~12.8 B/clk per CU: 4 x 51 KB take ~6.7 us, one wave alone ~1.7 us) while its VALUs idle; then all four compute while that path idles.
+// In the VALU-bound resident kernels (fused frames, the pixel / corner updates) a wave on SIMD k therefore sleeps k x FBUS_X_SIMD_STAGGER
+// x 64 clocks before it asks for its record: the four load (and store) phases of a CU fall one behind the other, under the other SIMDs'
+// arithmetic.  (Round 2 staggered alternate WORKGROUPS of the memory-bound correct and found nothing: neighbouring workgroups sit on
+// different CUs, the four waves of one CU stayed in phase -- and a memory-bound kernel has no arithmetic to hide a load under.)
+// HW_ID (hwreg 4): SIMD_ID = bits 5:4.
+// Measured (65 536 filters, same box, profiles/r05_stagger.txt; units of 64 clocks per SIMD id, fused / per-call):
+//   0 / 0      fused pose frame 1.446e10 steps/s, fused pixel frame (M = 4) 9.36e9, correct_pixels M = 4 31.8 us, stereo 41.4 us
+//   48 / 24    1.545e10, 9.82e9, 30.9 / 41.3 us          64 / 32   1.564e10 (+8 %), 9.82e9 (+5 %), 30.6 / 39.6 us
+//   96 / 16    1.501e10, 9.38e9, 30.3 / 41.0 us          127 / 48  1.398e10, 9.40e9, 31.2 / 40.6 us
+// (the frame window, the per-call predict and the pose-form correct do not change: one is all arithmetic, the others all memory)
+#ifndef FBUS_X_STAGGER_FRAME
+#define FBUS_X_STAGGER_FRAME 64     // the fused frames (frame_kernel, frame_meas_kernel): 64 x 64 clocks = 1.7 us per SIMD id
+#endif
+#ifndef FBUS_X_STAGGER_MEAS
+#define FBUS_X_STAGGER_MEAS 32      // the per-call pixel / corner updates with one wave per tile
+#endif
+template <int UNITS>
+__device__ __forceinline__ void simd_stagger()
+{
+    if constexpr (UNITS > 0) {
+        const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);      // 2 bits at offset 4 of HW_ID
+        for (unsigned i = 0; i < simd; ++i) __builtin_amdgcn_s_sleep(UNITS);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // ---------------------------------------------------------------------------------
 // record <-> registers
@@ -461,21 +489,15 @@ template <typename T> constexpr int park_nom_chunks() { return sizeof(T) == 8 ? 
 template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST, bool PARK = false>
 __global__ void __launch_bounds__(BLOCK, (PARK && sizeof(T) == 4) ? 2 : 1)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
-               const T* __restrict__ dt, int dt_stride, DevConst<T> dc, TileMap tm)
+               const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
 {
-    // (MULTI: always the plain mapping.)  K = 1: the tiles behind tm.full as sub-tile waves -- see TileMap (ekf_launch.hpp)
-    unsigned tile_ = blockIdx.x;
-    if (!MULTI && tile_ >= tm.full) {
-        const unsigned w = tile_ - tm.full;
-        tile_ = tm.full + (w >> tm.shift);
-        if ((threadIdx.x >> (6u - tm.shift)) != (w & ((1u << tm.shift) - 1u))) return;
-    }
-    const unsigned tile = __builtin_amdgcn_readfirstlane(tile_);
-    const int b = (int)(tile * BLOCK + threadIdx.x);
+    // (round 5, measured and NOT kept: the tiles beyond the last whole round of waves as sub-tile waves of 16 / 32 active lanes spread
+    // over all CUs -- no gain at any size, one extra tile costs +3.4 us however it is cut: profiles/r05_tail_split.txt, commit b55c4d4)
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
     if (b >= B) return;
     using RC = Rec<T, N>;
     constexpr int EPC = RC::EPC, CN = RC::CH_NOM;
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[Lay<N>::NNOM], P[RC::NCOVP];
     if (MULTI) {
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
@@ -780,6 +802,7 @@ frame_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, co
     __shared__ MarkerLDS<T> tbl;                      // the marker map, looked up from LDS (see MarkerLDS)
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
+    simd_stagger<FBUS_X_STAGGER_FRAME>();
     {
         // map pieces first, the record behind them, the LDS copy after both are on their way (lanes past B load
         // their existing tile too: no branch in front of the loads)

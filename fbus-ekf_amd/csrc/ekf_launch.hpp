@@ -22,36 +22,6 @@ struct LaunchPolicy {
     // the <= 256-register forms (row-split correct, parked predict_n, frame2_kernel): chosen by the JOB's size, not the shard's, so
     // that every shard layout of one job runs the same instruction streams (the forms agree to 1 ulp only)
     bool two_wave(int B) const { return (policy_b > 0 ? policy_b : B) >= two_wave_min_b; }
-    bool tail_split = true;         // the per-call predict's tiles beyond the last whole round as sub-tile waves (TileMap); FBUS_NO_TAIL_SPLIT
-};
-
-// Which 64-filter tile a workgroup (one wave) of the per-call predict works on.  Workgroups [0, full) take whole tiles; every tile
-// behind them is cut into 1 << shift SUB-TILE waves of 64 >> shift active lanes (the same 1 KiB pieces, a quarter / half of the
-// lanes enabled: the disabled lanes request nothing).  Why: a launch of more than one wave per SIMD is bound by each CU's own path
-// to memory (~12.8 B/clk whatever the number of waves on the CU, tools/exp_predict_timeline.hip): 1024 + 64 tiles load 64 CUs with
-// 5 waves' worth of bytes and the rest with 4, and the launch lasts 5/4; as 256 quarter-waves the same 64 tiles load EVERY CU with
-// 4.25 (round 5).  shift = 0 / full = all tiles: the plain mapping.
-struct TileMap {
-    unsigned full = 0, shift = 0;
-    unsigned grid(unsigned tiles) const { return full + ((tiles - full) << shift); }
-    // tiles beyond the last whole round of `simds` waves, spread as evenly over the cus = simds / 4 compute units as 1, 2 or 4 waves per tile allow
-    static TileMap balanced(unsigned tiles, unsigned simds)
-    {
-        TileMap tm;
-        tm.full = tiles;
-        const unsigned cus = simds / 4, tail = simds ? tiles % simds : 0;
-        if (tiles <= simds || tail == 0 || cus == 0) return tm;
-        unsigned best = 0;
-        double best_load = 1e30;
-        for (unsigned sh = 0; sh <= 2; ++sh) {
-            const unsigned waves = tail << sh;
-            const double load = (double)((waves + cus - 1) / cus) / (double)(1u << sh);      // tile-equivalents on the most loaded CU
-            if (load < best_load - 1e-9) { best_load = load; best = sh; }
-        }
-        tm.full = tiles - tail;
-        tm.shift = best;
-        return tm;
-    }
 };
 
 // K == 1: the streamed per-call kernel (`policy`: 0 = nt loads and stores, 1 = default-policy loads, 2 = default loads
@@ -106,8 +76,8 @@ struct MeasConst {
 template <typename T, int N, int D>
 void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, double size,
                       double r_pix, const unsigned char* skip, unsigned char* applied, const short* id2slot, const MeasConst& mc);
-// (round 5) the same update with the TAIL divided between the waves of a tile (ekf_meas_split.hpp): roles = 2 (256-register fold, two
-// waves per SIMD: full-chip launches) or 4 (small launches).  fp32 records, square port only -- the caller checks.
+// (round 5) the same update with the TAIL divided between the waves of a tile (ekf_meas_split.hpp): roles = 2 or 4 waves per tile
+// (launches below half / a quarter of the chip's SIMDs in tiles).  fp32 records, square port only -- the caller checks.
 template <typename T, int N, int D>
 void launch_pixels_split_k(hipStream_t s, T* recs, int B, int M, const int* ids, const T* left, const T* right, int roles, double size,
                            double r_pix, const unsigned char* skip, unsigned char* applied, const short* id2slot, const MeasConst& mc);

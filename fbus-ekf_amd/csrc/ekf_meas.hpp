@@ -35,6 +35,7 @@
 #pragma once
 #include "ekf_kernels.hpp"
 #include "ekf_launch.hpp"          // MeasConst
+#include "ekf_team.hpp"            // CovMap: storage index -> (row, column)
 
 
 namespace {
@@ -904,6 +905,160 @@ __device__ __forceinline__ void direct_update(T* P, T* dx, const COEF& cf)
 #undef PS
 }
 
+// ---- the update in two PARTS of the packed covariance (round 5) ----------------------------------------------------------------
+// EARLY part = storage [0, late_start): rows 0..8 and the collected diagonals -- every x_c = P(J, c) lives there; LATE part = the
+// chunks behind it, which hold only elements P(a, c) with a, c >= 9 (type "outside J": P(a, c) -= x_a' S^-1 x_c).  Used by the
+// divided-update kernel (ekf_meas_split.hpp: the two parts on two waves) and by the fp64 tail below (one wave, one part after the other:
+// 171 doubles + 63 coefficients do not fit 512 registers at once).
+// first storage index of the LATE part: a multiple of the chunk size behind which every element has row >= 9 (and so column >= 9:
+// no element of the J rows / columns, nothing the 6 x 6 stage reads)
+template <typename T, int N>
+constexpr int late_start()
+{
+    constexpr int EPC = Rec<T, N>::EPC, NP = Lay<N>::NP;
+    int e0 = NP;
+    for (int e = NP - 1; e >= 0 && cov_row<N>(e) >= 9; --e) e0 = e;
+    return (e0 + EPC - 1) / EPC * EPC;
+}
+constexpr bool in_J(int s) { return s < 3 || (s >= 6 && s < 9); }
+// what the SOLVER reads of the early part, by covariance chunk cc (0 = the first chunk behind the nominal state):
+//   SEL_JJ   a chunk that holds an element of P(J, J): the 6 x 6 stage's input, requested in front of the exchange
+//   SEL_XL   a chunk that holds an element P(J, c >= 9) = part of an x_c of the late columns (and no P(J, J) element: those it has
+//            already); requested behind the 6 x 6 stage, whose doubles leave no room for them
+enum { SEL_JJ = 1, SEL_XL = 2 };
+template <typename T, int N>
+constexpr int chunk_sel(int cc)
+{
+    constexpr int EPC = Rec<T, N>::EPC, NP = Lay<N>::NP;
+    bool jj = false, xl = false;
+    for (int k = 0; k < EPC; ++k) {
+        const int e = cc * EPC + k;
+        if (e >= NP) continue;
+        const int i = cov_row<N>(e), j = cov_col<N>(e);
+        jj = jj || (in_J(i) && in_J(j));
+        xl = xl || (in_J(i) && j >= 9);
+    }
+    return jj ? SEL_JJ : (xl ? SEL_XL : 0);
+}
+// chunks [C0, C1) of the covariance whose selector is SEL -> P (storage order; the others stay untouched)
+template <typename T, int N, int C0, int C1, int SEL, int AUX = AUX_DEFAULT>
+__device__ __forceinline__ void load_cov_chunks(__amdgpu_buffer_rsrc_t rs, unsigned lane, T* P)
+{
+    using RC = Rec<T, N>;
+    static_for<C0, C1>([&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        if constexpr (chunk_sel<T, N>(cc) == SEL)
+            load_chunks<T, N, RC::CH_NOM + cc, RC::CH_NOM + cc + 1, AUX>(rs, lane, P + cc * RC::EPC);
+    });
+}
+
+// which elements of the three groups of direct_update lie in the storage range [LO, HI)
+template <int N, int LO, int HI> constexpr bool in_part(int i, int j) { return pidx<N>(i, j) >= LO && pidx<N>(i, j) < HI; }
+template <int N, int LO, int HI> constexpr bool part_any_rr(int c) { bool a_ = false; for (int a = 0; a <= c; ++a) a_ = a_ || in_part<N, LO, HI>(rcol(a), rcol(c)); return a_; }
+template <int N, int LO, int HI> constexpr bool part_any_jj() { bool a_ = false; for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) a_ = a_ || in_part<N, LO, HI>(jcol(i), jcol(j)); return a_; }
+template <int N, int LO, int HI> constexpr bool part_all_jj() { bool a_ = true; for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) a_ = a_ && in_part<N, LO, HI>(jcol(i), jcol(j)); return a_; }
+template <int N, int LO, int HI> constexpr bool part_any_jr(int c) { bool a_ = false; for (int i = 0; i < 6; ++i) a_ = a_ || in_part<N, LO, HI>(jcol(i), rcol(c)); return a_; }
+template <int N, int LO, int HI> constexpr bool part_all_jr(int c) { bool a_ = true; for (int i = 0; i < 6; ++i) a_ = a_ && in_part<N, LO, HI>(jcol(i), rcol(c)); return a_; }
+
+// direct_update (ekf_meas.hpp) restricted to the covariance elements with storage index in [LO, HI): the same operations on every
+// element it touches, in the same order.  P is the full-size array; every element of the J rows / columns that the touched elements
+// need must be loaded (x_c = P(J, c)); WANT_DX: dx = P(:, J) m as well (needs all of the J rows).  PHASES: 1 = the block outside J
+// (reads S^-1), 2 = the J rows (reads G), 3 = both -- the fp64 tail runs them one after the other with only that phase's coefficients live.
+template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES = 3>
+__device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
+{
+#define PS(i, j) P[pidx<N>((i), (j))]
+#define INR(i, j) (in_part<N, LO, HI>((i), (j)))
+    constexpr int NR_ = N - 6;
+    if constexpr (WANT_DX) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T s = PS(i, jcol(0)) * cf.m(0);
+#pragma unroll
+            for (int k = 1; k < 6; ++k) s += PS(i, jcol(k)) * cf.m(k);
+            dx[i] = s;
+        }
+    }
+    // the block outside J, column by column: t = Sinv x_c, then P(a, c) -= x_a . t for the columns a <= c (the x are still the old ones)
+    static_for<0, NR_>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        if constexpr (part_any_rr<N, LO, HI>(c) && (PHASES & 1)) {
+            T t[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                T s = cf.S(0, i) * PS(jcol(0), rcol(c));
+#pragma unroll
+                for (int j = 1; j < 6; ++j) s += cf.S(j, i) * PS(jcol(j), rcol(c));
+                t[i] = s;
+            }
+            static_for<0, c + 1>([&](auto a_) {
+                constexpr int a = decltype(a_)::value;
+                if constexpr (INR(rcol(a), rcol(c))) {
+                    T s = PS(jcol(0), rcol(a)) * t[0];
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) s += PS(jcol(k), rcol(a)) * t[k];
+                    PS(rcol(a), rcol(c)) -= s;
+                }
+            });
+        }
+    });
+    // the J x J block from the old values (upper triangle of G P_JJ), then the J x r columns in place
+    if constexpr (part_any_jj<N, LO, HI>() && (PHASES & 2)) {
+        // (the J x J block lies in ONE part: the early one)
+        T nj[21];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                T s = cf.G(i, 0) * PS(jcol(0), jcol(j));
+#pragma unroll
+                for (int k = 1; k < 6; ++k) s += cf.G(i, k) * PS(jcol(k), jcol(j));
+                nj[lidx(i, j)] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) PS(jcol(i), jcol(j)) = nj[lidx(i, j)];
+        static_assert(part_all_jj<N, LO, HI>(), "the J x J block must lie in one part");
+    }
+    static_for<0, NR_>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        if constexpr (part_any_jr<N, LO, HI>(c) && (PHASES & 2)) {
+            static_assert(part_all_jr<N, LO, HI>(c), "a column of the J rows must lie in one part");
+            T x[6], y[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) x[j] = PS(jcol(j), rcol(c));
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                T s = cf.G(i, 0) * x[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) s += cf.G(i, j) * x[j];
+                y[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) PS(jcol(i), rcol(c)) = y[i];
+        }
+    });
+#undef INR
+#undef PS
+}
+
+// coefficient views of the phased fp64 tail: S^-1 and m in registers while the block outside J is updated, G back from LDS for the J rows
+template <typename T>
+struct CoefSm {
+    T s[21], m_[6];
+    __device__ __forceinline__ T G(int, int) const { return T(0); }
+    __device__ __forceinline__ T S(int i, int j) const { return s[i <= j ? lidx(i, j) : lidx(j, i)]; }
+    __device__ __forceinline__ T m(int k) const { return m_[k]; }
+};
+template <typename T>
+struct CoefG {
+    T g[36];
+    __device__ __forceinline__ T G(int i, int j) const { return g[6 * i + j]; }
+    __device__ __forceinline__ T S(int, int) const { return T(0); }
+    __device__ __forceinline__ T m(int) const { return T(0); }
+};
+
 // the sums -> information matrix -> 6 x 6 stage (double) -> one-shot update of the resident covariance; dx = the error state
 // (the resident kernels; meas_update_tail below holds the same statements in place)
 template <typename T, int N>
@@ -928,10 +1083,66 @@ __device__ __forceinline__ void meas_solve_update(T* P, const PixAcc& acc, const
 // the tail both per-call measurement kernels share: the sums -> information matrix -> 6 x 6 stage -> update -> injection -> stores
 template <typename T, int N>
 __device__ __forceinline__ void meas_update_tail(const __amdgpu_buffer_rsrc_t rs, unsigned lane, const PixAcc& acc, const double* Rd, double w,
-                                                 int new_prev)
+                                                 int new_prev, T* gpark /* fp64 records: this lane's column of 36 x 64 values in LDS */)
 {
     using L = Lay<N>;
     using RC = Rec<T, N>;
+    if constexpr (sizeof(T) == 8) {
+        // fp64 records (round 5): 171 covariance doubles are 342 registers, the 6 x 6 stage wants ~220 and the update 63 coefficients
+        // (126 registers) beside the covariance: held all at once the kernels spilled 650-790 bytes per lane.  So:
+        //   * only the chunks that hold P(J, J) in front of the 6 x 6 stage;
+        //   * the update in two parts (direct_update_part) and two phases: the LATE part first (it reads the old x_c = P(J, c >= 9) of the
+        //     early part, S^-1 in registers, and is stored at once), then the early part -- dx and its elements outside J with S^-1, then
+        //     the J rows with G, which has waited in LDS (gpark: 36 doubles per lane) -- and the injection.
+        constexpr int EPC = RC::EPC, CN = RC::CH_NOM, E0 = late_start<T, N>(), C_E = E0 / EPC;
+        T P[RC::NCOVP];
+        load_cov_chunks<T, N, 0, C_E, SEL_JJ>(rs, lane, P);
+        CoefSm<T> cs;
+        {
+            double Lam[21], bv[6];
+            acc.finish(Rd, w, Lam, bv);
+            T G[36];
+            {
+                double PJJ[36];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
+                info_solve<T>(Lam, bv, PJJ, G, cs.s, cs.m_);
+            }
+#pragma unroll
+            for (int i = 0; i < 36; ++i) gpark[i * 64] = G[i];
+        }
+        order_fence();
+        load_cov_chunks<T, N, 0, C_E, SEL_XL, AUX_NT>(rs, lane, P);
+        load_chunks<T, N, CN + C_E, RC::NCH, AUX_NT>(rs, lane, P + E0);
+        order_fence();
+        T dx[N];
+        direct_update_part<T, N, E0, L::NP, false, CoefSm<T>, 1>(P, dx, cs);
+        if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
+        store_chunks<T, N, CN + C_E, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P + E0);
+        order_fence();
+        // (the rest of the early part only now: requested in front of the late update its load targets spill)
+        load_cov_chunks<T, N, 0, C_E, 0, AUX_NT>(rs, lane, P);
+        order_fence();
+        direct_update_part<T, N, 0, E0, true, CoefSm<T>, 1>(P, dx, cs);
+        order_fence();
+        {
+            CoefG<T> cg;
+#pragma unroll
+            for (int i = 0; i < 36; ++i) cg.g[i] = gpark[i * 64];
+            direct_update_part<T, N, 0, E0, false, CoefG<T>, 2>(P, dx, cg);
+        }
+        order_fence();
+        store_chunks<T, N, CN, CN + C_E, FBUS_X_CORRECT_ST>(rs, lane, P);
+        order_fence();
+        T nom[L::NNOM];
+        load_chunks<T, N, 0, CN>(rs, lane, nom);
+        inject<T, N>(nom, dx);
+        store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
+        store_chunks<T, N, RC::CH_PQR, CN, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
+        return;
+    }
     // the covariance is requested here: it arrives under the 6 x 6 stage
     T P[RC::NCOVP];
     load_chunks<T, N, RC::CH_NOM, RC::NCH, AUX_NT>(rs, lane, P);
@@ -992,7 +1203,10 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     const int bc = b < B ? b : (int)(tile * 64u);
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
     __shared__ MeasLDS tbl;
-    __shared__ double part_mem[(NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1)];
+    // the roles' partial sums; fp64 records: behind them (role 0 has added them up by then) G waits here while the block outside J is updated
+    constexpr int PART_N = NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1, GPARK_N = sizeof(T) == 8 ? 36 * 64 : 1;
+    __shared__ double part_mem[PART_N > GPARK_N ? PART_N : GPARK_N];
+    T* gpark_mem = reinterpret_cast<T*>(part_mem);
     struct Meas { int id; T l[8], r[8]; };
     const bool stereo = right != nullptr;
     // the id and the 8 (+ 8) image coordinates of marker slot i: 16-byte loads (a slot's 8 coordinates are 32 / 64 contiguous bytes)
@@ -1013,6 +1227,7 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     };
     Meas cur, nxt;
     T pqr[L::NPQR];
+    if constexpr (NR == 1) simd_stagger<FBUS_X_STAGGER_MEAS>();
     {
         // the marker map -> LDS (all threads), this role's first marker, the pose part of the nominal state
         constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(double) * FBUS_MAX_MARKERS * MKC_STRIDE / 16;
@@ -1084,7 +1299,7 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         }
     }
     if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
-    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pix, -1);
+    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pix, -1, gpark_mem + lane);
     applied[b] = 1;
 }
 
@@ -1112,7 +1327,10 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
     const int bc = b < B ? b : (int)(tile * 64u);
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
     __shared__ MeasLDS tbl;
-    __shared__ double part_mem[(NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1)];
+    // the roles' partial sums; fp64 records: behind them (role 0 has added them up by then) G waits here while the block outside J is updated
+    constexpr int PART_N = NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1, GPARK_N = sizeof(T) == 8 ? 36 * 64 : 1;
+    __shared__ double part_mem[PART_N > GPARK_N ? PART_N : GPARK_N];
+    T* gpark_mem = reinterpret_cast<T*>(part_mem);
     struct Meas { int id; T l[12], r[8]; };
     const bool c3d = geometry == VIS_CORNERS3D;
     const int lw = c3d ? 12 : 8;
@@ -1156,6 +1374,7 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
     Meas cur, nxt;
     T pqr[L::NPQR];
     T prev_raw = T(0);
+    if constexpr (NR == 1) simd_stagger<FBUS_X_STAGGER_MEAS>();
     {
         constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(double) * FBUS_MAX_MARKERS * MKC_STRIDE / 16;
         constexpr int PI = (NI + NT - 1) / NT, PM = (NM + NT - 1) / NT;
@@ -1256,7 +1475,7 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
     }
     if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
     acc.expand_const(mc.NI);
-    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pos, new_prev);
+    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pos, new_prev, gpark_mem + lane);
     applied[b] = 1;
 }
 
@@ -1358,6 +1577,7 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
     T nom[L::NNOM];
     Meas cur, nxt;
     T prev_raw = T(0);
+    simd_stagger<FBUS_X_STAGGER_FRAME>();
     {
         T P[RC::NCOVP];
         {

@@ -4,339 +4,44 @@
 // place of the marker origin, through the flat-port model of C++/src/vision.cpp:496-599 run forward (ekf_meas.hpp); the update
 // matlab/MeasureUpdate.m:84-102 ; filter.cpp:709-739 in the one-shot form of ekf_meas.hpp::direct_update.
 //
-// Why.  correct_pixels2_kernel (ekf_meas.hpp) keeps a filter's whole update in one wave: ~400 registers, one wave per SIMD.  At one wave
-// per SIMD an fp64 instruction issues every 5.3 cycles (4.45 with two waves, profiles/r04_issue_rates.txt) and every wave of the launch
-// walks through the same phases at the same time -- all fold (memory idle), then all wait for their covariance, then all store.  Its NR
-// "roles" divide the FOLD of a filter's markers over NR waves, but the tail -- sums -> 6 x 6 stage -> update of 171 covariance elements
-// -> injection -> 50 chunk stores -- stays with role 0 while the others have left (round 4 measured ~9 us of a 17 us config-3 launch
-// there), and a 256-register form whose tail ran row-split through LDS on one wave lost (profiles/r04_meas_two_wave.txt).
-//
-// Here every wave stays below 256 registers (two waves per SIMD at 65 536 filters with two waves per tile) and the tail is divided:
-//   fold      role r folds markers r, r + NR, ...  corner by corner (pixel_fold_corners_nz: the arithmetic of pixel_fold_marker's
-//             square-port path, one corner's NCAM projections per pass of a loop that is not unrolled: ~230 registers instead of ~390)
+// Why.  correct_pixels2_kernel (ekf_meas.hpp) divides the FOLD of a filter's markers over NR waves ("roles") when a launch has fewer
+// tiles than the chip has SIMDs, but its tail -- sums -> 6 x 6 stage -> update of 171 covariance elements -> injection -> 50 chunk stores
+// -- stays with role 0 while the others have left.  Here the tail is divided too:
+//   fold      role r folds markers r, r + NR, ...  (pixel_fold_marker, four corners in lock step, as in the one-tail kernel)
 //   exchange  roles >= 1 leave their 27 sums in LDS; barrier
-//   SOLVER    (role 0) adds the sums in role order, forms Lam, b, solves the 6 x 6 stage in double from P_JJ (it has requested the
-//             chunks that hold P(J, J) and P(J, c >= 9) before the fold ended), leaves G, S^-1, m (63 values) in LDS; barrier;
-//             then updates and stores the LATE part of the covariance -- the chunks that hold only elements P(a, c), a, c >= 9
-//             (N = 18: storage [132, 172), the predict-invariant tail; all of type "outside J": P(a, c) -= x_a' S^-1 x_c)
+//   SOLVER    (role 0) has requested the chunks that hold P(J, J) in front of the exchange; it adds the sums in role order, forms Lam, b,
+//             solves the 6 x 6 stage in double, leaves G, S^-1, m (63 values) in LDS; barrier; then updates and stores the LATE part of
+//             the covariance -- the chunks that hold only elements P(a, c), a, c >= 9 (N = 18: storage [128, 172); all of type "outside
+//             J": P(a, c) -= x_a' S^-1 x_c), for which it has requested the x_c = P(J, c >= 9) behind the 6 x 6 stage
 //   UPDATER   (role 1) has requested the EARLY part (rows 0..8 and the collected diagonals: every x_c = P(J, c) lives there) and the
 //             nominal state while the solver worked; behind the second barrier it reads the 63 coefficients, forms dx = P(:, J) m,
 //             updates the early part (the J rows as the product G P(J, :), the rest by subtraction), injects dx, stores
-//   roles >= 2 (four waves per tile: small launches) fold their share and leave behind the second barrier.
-// Per element the operations are those of direct_update in the same order (direct_update_part below is that function restricted to a
-// storage range): the posterior equals the one-wave kernel's bit for bit given the same sums; the sums are added in role order as in
-// correct_pixels2_kernel<., ., NR, .>.
+//   roles >= 2 (four waves per tile) fold their share and leave behind the second barrier.
+// Per element the operations are those of direct_update in the same order (direct_update_part, ekf_meas.hpp): the posterior equals the
+// one-tail kernel's with the same number of roles bit for bit (the sums are added in role order there as here).
+// Measured (alternating A/B, HIP-event bracket per launch, profiles/r05_meas_split.txt): 16 384 filters x 4 slots, four waves per tile
+// 17.6 -> 16.7 us; 32 768 x 4, two waves per tile 23.3 -> 22.1 us; 32 768 x 16: 41.1 -> 39.8 us.  Chosen up to half a chip of tiles.
+// What was also built and LOST (commit b55c4d4, same file): two waves per tile at FULL chip (65 536 filters) with a 256-register fold,
+// corner by corner, so that two waves share a SIMD -- 85.6 us against 67.9 (16 slots), 47.3 against 33.2 (4 slots): one corner's single
+// dependent chain issues an fp64 instruction every ~10 cycles where four corners in lock step reach 5.3, and a second wave per SIMD
+// (at best 4.45 cycles per instruction for the pair) does not win that back.  Round 4's two-wave form lost the same way.
 // Square port (normal = (0, 0, 1), the reference's configuration) and fp32 records only: everything else keeps correct_pixels2_kernel.
 #pragma once
 #include "ekf_meas.hpp"
-#include "ekf_team.hpp"            // CovMap: storage index -> (row, column)
 
 namespace {
 
-// ---- who owns what -----------------------------------------------------------------------------------------------------
-// first storage index of the LATE part: a multiple of the chunk size behind which every element has row >= 9 (and so column >= 9:
-// no element of the J rows / columns, nothing the 6 x 6 stage reads)
-template <typename T, int N>
-constexpr int late_start()
-{
-    constexpr int EPC = Rec<T, N>::EPC, NP = Lay<N>::NP;
-    int e0 = NP;
-    for (int e = NP - 1; e >= 0 && cov_row<N>(e) >= 9; --e) e0 = e;
-    return (e0 + EPC - 1) / EPC * EPC;
-}
-constexpr bool in_J(int s) { return s < 3 || (s >= 6 && s < 9); }
-// what the SOLVER reads of the early part, by covariance chunk cc (0 = the first chunk behind the nominal state):
-//   SEL_JJ   a chunk that holds an element of P(J, J): the 6 x 6 stage's input, requested in front of the exchange
-//   SEL_XL   a chunk that holds an element P(J, c >= 9) = part of an x_c of the late columns (and no P(J, J) element: those it has
-//            already); requested behind the 6 x 6 stage, whose doubles leave no room for them
-enum { SEL_JJ = 1, SEL_XL = 2 };
-template <typename T, int N>
-constexpr int chunk_sel(int cc)
-{
-    constexpr int EPC = Rec<T, N>::EPC, NP = Lay<N>::NP;
-    bool jj = false, xl = false;
-    for (int k = 0; k < EPC; ++k) {
-        const int e = cc * EPC + k;
-        if (e >= NP) continue;
-        const int i = cov_row<N>(e), j = cov_col<N>(e);
-        jj = jj || (in_J(i) && in_J(j));
-        xl = xl || (in_J(i) && j >= 9);
-    }
-    return jj ? SEL_JJ : (xl ? SEL_XL : 0);
-}
-// chunks [C0, C1) of the covariance whose selector is SEL -> P (storage order; the others stay untouched)
-template <typename T, int N, int C0, int C1, int SEL, int AUX = AUX_DEFAULT>
-__device__ __forceinline__ void load_cov_chunks(__amdgpu_buffer_rsrc_t rs, unsigned lane, T* P)
-{
-    using RC = Rec<T, N>;
-    static_for<C0, C1>([&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-        if constexpr (chunk_sel<T, N>(cc) == SEL)
-            load_chunks<T, N, RC::CH_NOM + cc, RC::CH_NOM + cc + 1, AUX>(rs, lane, P + cc * RC::EPC);
-    });
-}
-
-// which elements of the three groups of direct_update lie in the storage range [LO, HI)
-template <int N, int LO, int HI> constexpr bool in_part(int i, int j) { return pidx<N>(i, j) >= LO && pidx<N>(i, j) < HI; }
-template <int N, int LO, int HI> constexpr bool part_any_rr(int c) { bool a_ = false; for (int a = 0; a <= c; ++a) a_ = a_ || in_part<N, LO, HI>(rcol(a), rcol(c)); return a_; }
-template <int N, int LO, int HI> constexpr bool part_any_jj() { bool a_ = false; for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) a_ = a_ || in_part<N, LO, HI>(jcol(i), jcol(j)); return a_; }
-template <int N, int LO, int HI> constexpr bool part_all_jj() { bool a_ = true; for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) a_ = a_ && in_part<N, LO, HI>(jcol(i), jcol(j)); return a_; }
-template <int N, int LO, int HI> constexpr bool part_any_jr(int c) { bool a_ = false; for (int i = 0; i < 6; ++i) a_ = a_ || in_part<N, LO, HI>(jcol(i), rcol(c)); return a_; }
-template <int N, int LO, int HI> constexpr bool part_all_jr(int c) { bool a_ = true; for (int i = 0; i < 6; ++i) a_ = a_ && in_part<N, LO, HI>(jcol(i), rcol(c)); return a_; }
-
-// direct_update (ekf_meas.hpp) restricted to the covariance elements with storage index in [LO, HI): the same operations on every
-// element it touches, in the same order.  P is the full-size array; every element of the J rows / columns that the touched elements
-// need must be loaded (x_c = P(J, c)); WANT_DX: dx = P(:, J) m as well (needs all of the J rows).
-template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF>
-__device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
-{
-#define PS(i, j) P[pidx<N>((i), (j))]
-#define INR(i, j) (in_part<N, LO, HI>((i), (j)))
-    constexpr int NR_ = N - 6;
-    if constexpr (WANT_DX) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            T s = PS(i, jcol(0)) * cf.m(0);
-#pragma unroll
-            for (int k = 1; k < 6; ++k) s += PS(i, jcol(k)) * cf.m(k);
-            dx[i] = s;
-        }
-    }
-    // the block outside J, column by column: t = Sinv x_c, then P(a, c) -= x_a . t for the columns a <= c (the x are still the old ones)
-    static_for<0, NR_>([&](auto c_) {
-        constexpr int c = decltype(c_)::value;
-        if constexpr (part_any_rr<N, LO, HI>(c)) {
-            T t[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                T s = cf.S(0, i) * PS(jcol(0), rcol(c));
-#pragma unroll
-                for (int j = 1; j < 6; ++j) s += cf.S(j, i) * PS(jcol(j), rcol(c));
-                t[i] = s;
-            }
-            static_for<0, c + 1>([&](auto a_) {
-                constexpr int a = decltype(a_)::value;
-                if constexpr (INR(rcol(a), rcol(c))) {
-                    T s = PS(jcol(0), rcol(a)) * t[0];
-#pragma unroll
-                    for (int k = 1; k < 6; ++k) s += PS(jcol(k), rcol(a)) * t[k];
-                    PS(rcol(a), rcol(c)) -= s;
-                }
-            });
-        }
-    });
-    // the J x J block from the old values (upper triangle of G P_JJ), then the J x r columns in place
-    if constexpr (part_any_jj<N, LO, HI>()) {
-        // (the J x J block lies in ONE part: the early one)
-        T nj[21];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) {
-                T s = cf.G(i, 0) * PS(jcol(0), jcol(j));
-#pragma unroll
-                for (int k = 1; k < 6; ++k) s += cf.G(i, k) * PS(jcol(k), jcol(j));
-                nj[lidx(i, j)] = s;
-            }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) PS(jcol(i), jcol(j)) = nj[lidx(i, j)];
-        static_assert(part_all_jj<N, LO, HI>(), "the J x J block must lie in one part");
-    }
-    static_for<0, NR_>([&](auto c_) {
-        constexpr int c = decltype(c_)::value;
-        if constexpr (part_any_jr<N, LO, HI>(c)) {
-            static_assert(part_all_jr<N, LO, HI>(c), "a column of the J rows must lie in one part");
-            T x[6], y[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) x[j] = PS(jcol(j), rcol(c));
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                T s = cf.G(i, 0) * x[0];
-#pragma unroll
-                for (int j = 1; j < 6; ++j) s += cf.G(i, j) * x[j];
-                y[i] = s;
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) PS(jcol(i), rcol(c)) = y[i];
-        }
-    });
-#undef INR
-#undef PS
-}
-
-// ---- one marker, corner by corner: the square-port path of pixel_fold_marker in ~230 registers --------------------------------
-// Same arithmetic per projection as pixel_fold_marker<NCAM, T, true> (ekf_meas.hpp; see there for the geometry, the closed-form start of
-// the port equation and the Halley step); one corner's NCAM projections per pass.  Corner k in the IMU frame by addition from corner 0
-// and the two edge vectors as there, the flags wave-uniform; its camera-frame position from the corner itself (see below).
-template <int NCAM, typename T>
-__device__ __forceinline__ void pixel_fold_corners_nz(PixAcc& acc, const double* p, const double* R, const double* pil, const MeasConst& mc,
-                                                      const double* mkc, const T* yl, const T* yr, double size)
-{
-    constexpr int NS = sizeof(T) == 8 ? 2 : 1;
-    constexpr int NP = NCAM;
-    double ru0[3], rAx[3], rAy[3];
-    {
-        double u0[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) u0[i] = mkc[i] - p[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            ru0[i] = R[i] * u0[0] + R[3 + i] * u0[1] + R[6 + i] * u0[2];
-            rAx[i] = size * (R[i] * mkc[3] + R[3 + i] * mkc[4] + R[6 + i] * mkc[5]);
-            rAy[i] = size * (R[i] * mkc[6] + R[3 + i] * mkc[7] + R[6 + i] * mkc[8]);
-        }
-    }
-    const double c0 = (mc.d_air + mc.d_glass * mc.a0) / mc.a1;
-    const double klim = 0.81 * mc.a1 * mc.a1 / (1.0 - mc.a1 * mc.a1);
-    const double q1 = 1.0 - mc.a1 * mc.a1, a12 = mc.a1 * mc.a1, Gd0 = mc.d_glass * mc.a0;
-#pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        // corners c_k = (0,0,0), (0,s,0), (s,s,0), (s,0,0) of the marker frame (vision.cpp:736-759)
-        const bool by = (k == 1 || k == 2), bx = (k >= 2);
-        double ru[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            // ru0 / ru0 + rAy / ru0 + rAx + rAy / ru0 + rAx, with pixel_fold_marker's association
-            const double a_ = by ? (bx ? rAx[i] + rAy[i] : rAy[i]) : (bx ? rAx[i] : 0.0);
-            ru[i] = (by || bx) ? ru0[i] + a_ : ru0[i];
-        }
-        double lat[NP][2], rho[NP], irho[NP], Wd[NP], vis[NP], t[NP];
-        {
-            double X[NP][3], r2[NP], zwq[NP], r2s[NP], xs[NP], ir0[NP], ze[NP];
-            bool ok[NP];
-            // the corner in the refraction frame of each camera: X = M_c (ru_k - pil) + t_c, from the corner itself (pixel_fold_marker adds the
-            // edge vectors in the camera frames instead -- 36 doubles that would have to stay live across the corners; same value to rounding)
-            const double tI[3] = { ru[0] - pil[0], ru[1] - pil[1], ru[2] - pil[2] };
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const double* M = q ? mc.McR : mc.McL;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) X[q][i] = M[3 * i] * tI[0] + M[3 * i + 1] * tI[1] + M[3 * i + 2] * tI[2] + (q ? mc.tR[i] : 0.0);
-            }
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                lat[q][0] = X[q][0]; lat[q][1] = X[q][1];
-                r2[q] = X[q][0] * X[q][0] + X[q][1] * X[q][1];
-                zwq[q] = X[q][2] - (mc.d_air + mc.d_glass);
-            }
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                ok[q] = (zwq[q] > 0.0) && (r2[q] < klim * zwq[q] * zwq[q]);
-                vis[q] = ok[q] ? 1.0 : 0.0;
-                r2s[q] = ok[q] ? r2[q] : 0.0;
-                const double zs = ok[q] ? zwq[q] : 1.0;
-                Wd[q] = zs * mc.a1;
-                ze[q] = zs + c0;
-                xs[q] = r2s[q] > 0.0 ? r2s[q] : 1.0;
-            }
-            md_rsq_n<NS, NP>(xs, ir0);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { irho[q] = (r2s[q] > 0.0) ? ir0[q] : 0.0; rho[q] = r2s[q] * irho[q]; }
-            double u[NP], w_[NP], r_[NP], s_[NP], izw[NP];
-            md_rcp_n<0, NP>(ze, u);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { u[q] *= rho[q]; w_[q] = fmax(a12 - q1 * u[q] * u[q], 1e-6); }
-            md_rsq_n<0, NP>(w_, w_);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { t[q] = u[q] * w_[q]; r_[q] = 1.0 + t[q] * t[q]; izw[q] = Wd[q]; }
-            md_rsq_n<0, NP>(r_, r_);
-            md_rcp_n<0, NP>(izw, izw);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { s_[q] = t[q] * r_[q]; w_[q] = 1.0 - mc.a0 * mc.a0 * s_[q] * s_[q]; }
-            md_rsq_n<0, NP>(w_, w_);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                u[q] = fmax((rho[q] - mc.d_air * t[q] - Gd0 * s_[q] * w_[q]) * izw[q] * mc.a1, 0.0);
-                w_[q] = fmax(a12 - q1 * u[q] * u[q], 1e-6);
-            }
-            md_rsq_n<0, NP>(w_, w_);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) t[q] = u[q] * w_[q];
-        }
-        double iLt[NP], c2[NP];
-        {
-            constexpr int NFIN = sizeof(T) == 8 ? 2 : 1;
-            PortEvalN<double, NP> f;
-            const double Gd = mc.d_glass * mc.a0;
-#pragma unroll
-            for (int rep = 0; rep < NFIN; ++rep) {
-                port_eval_n<NS, double, NP>(mc.a0, mc.a1, mc.d_air, Gd, Wd, rho, t, f);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) t[q] = fmax(t[q] + f.dt[q], 0.0);
-            }
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { f.Lt[q] += f.Ltt[q] * f.dt[q]; f.Lz[q] += f.Lzt[q] * f.dt[q]; }
-            md_rcp_n<NS, NP>(f.Lt, iLt);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) c2[q] = f.Lz[q] * iLt[q];
-        }
-        double kk[NP], uv[NP][2], a[NP][2][3], res[NP][2], e[NP][2], eM[NP][3];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) kk[q] = (irho[q] > 0.0) ? t[q] * irho[q] : iLt[q];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            uv[q][0] = kk[q] * lat[q][0];
-            uv[q][1] = kk[q] * lat[q][1];
-            e[q][0] = lat[q][0] * irho[q];
-            e[q][1] = lat[q][1] * irho[q];
-        }
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const double* M = q ? mc.McR : mc.McL;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) eM[q][j] = e[q][0] * M[j] + e[q][1] * M[3 + j];
-        }
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const double* M = q ? mc.McR : mc.McL;
-            const T* y = q ? yr : yl;
-            const double c1v = (iLt[q] - kk[q]) * vis[q], c2v = c2[q] * vis[q], kv = kk[q] * vis[q];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const double w1 = c1v * e[q][r], w3 = -c2v * e[q][r];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) a[q][r][j] = w1 * eM[q][j] + kv * M[3 * r + j] + w3 * M[6 + j];
-                // y[2 k + r] with a wave-uniform k: a chain of selects (no indexed register access)
-                const T y0 = y[r], y1 = y[2 + r], y2 = y[4 + r], y3 = y[6 + r];
-                const T yk = k == 0 ? y0 : (k == 1 ? y1 : (k == 2 ? y2 : y3));
-                res[q][r] = (double)yk - uv[q][r];
-            }
-        }
-        if constexpr (NCAM == 1) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) acc.add_row(a[0][r], res[0][r], ru);
-        } else {
-            double Np[6], np[3];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) Np[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) np[i] = 0.0;
-#pragma unroll
-            for (int c = 0; c < NCAM; ++c)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const double* ar = a[c][r];
-                    Np[0] += ar[0] * ar[0]; Np[1] += ar[0] * ar[1]; Np[2] += ar[0] * ar[2];
-                    Np[3] += ar[1] * ar[1]; Np[4] += ar[1] * ar[2]; Np[5] += ar[2] * ar[2];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) np[j] += ar[j] * res[c][r];
-                }
-            acc.add_corner(Np, np, ru);
-        }
-    }
-}
+// (late_start, chunk_sel, load_cov_chunks, direct_update_part: ekf_meas.hpp -- the fp64 tail there runs the same two parts in one wave)
 
 // LDS image of the 63 coefficients + the verdict (64 values of T per lane)
 constexpr int SPLIT_NCOEF = 64;
 
 // =================================================================================
 // correct() from corner pixels, update divided between the waves of a tile (see the head of this file).
-// NR = 2 (KG1: the 256-register fold, two waves per SIMD when the launch has two waves per tile on every SIMD) or 4.
+// NR = 2 (launches of a quarter to half a chip of tiles) or 4 (smaller ones): at most one wave per SIMD either way.
 // =================================================================================
-template <typename T, int N, int NR, bool KG1>
-__global__ void __launch_bounds__(64 * NR, KG1 ? 2 : 1)
+template <typename T, int N, int NR>
+__global__ void __launch_bounds__(64 * NR)
 correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
                             const T* __restrict__ right, double size, double r_pix, const unsigned char* __restrict__ skip,
                             unsigned char* __restrict__ applied, const short* __restrict__ id2slot, MeasConst mc)
@@ -426,13 +131,8 @@ correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __res
                 double mk[9];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-                if constexpr (KG1) {
-                    if (stereo) pixel_fold_corners_nz<2, T>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-                    else pixel_fold_corners_nz<1, T>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
-                } else {
-                    if (stereo) pixel_fold_marker<2, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-                    else pixel_fold_marker<1, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
-                }
+                if (stereo) pixel_fold_marker<2, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+                else pixel_fold_marker<1, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
                 nfold += 1.0;
             }
             cur = nxt;

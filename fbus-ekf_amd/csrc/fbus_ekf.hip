@@ -908,7 +908,6 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
         h->lp.two_wave_min_b = simds * 64 + 1;
         if (const char* e = std::getenv("FBUS_TWO_WAVE_MIN_B")) h->lp.two_wave_min_b = std::atoi(e);
         h->lp.meas_vec = std::getenv("FBUS_NO_MEAS_VEC") == nullptr;
-        h->lp.tail_split = std::getenv("FBUS_NO_TAIL_SPLIT") == nullptr;
         // 256 MiB is MI355X's (and MI300X's) Infinity Cache whatever the CU count of the SKU: not scaled with the device; only the
         // test knob FBUS_FAKE_SIMDS (a pretended smaller chip) scales it down with the SIMD count, FBUS_MALL_MB sets it outright
         h->mall_bytes = (size_t)256 << 20;
@@ -924,7 +923,7 @@ int fbus_ekf_create(fbus_ekf_t* out, const fbus_params* prm, int batch, int devi
     if (const char* e = std::getenv("FBUS_TEAM_PREDICT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_predict = v; }
     if (const char* e = std::getenv("FBUS_TEAM_CORRECT")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) h->team_correct = v; }
     if (const char* e = std::getenv("FBUS_NO_FRAME_MEAS")) h->no_frame_meas = std::atoi(e) != 0;
-    if (const char* e = std::getenv("FBUS_MEAS_SPLIT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 4 || v == 12) h->meas_split = v; }
+    if (const char* e = std::getenv("FBUS_MEAS_SPLIT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 4) h->meas_split = v; }
     if (const char* e = std::getenv("FBUS_TEAM_FRAME")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) h->team_frame = v; }
     if (const char* e = std::getenv("FBUS_PREDICT_LD"))          // experiment knob: nt | default | auto
         h->predict_ld = !std::strcmp(e, "nt") ? 1 : (!std::strcmp(e, "default") ? 2 : 0);

@@ -40,16 +40,12 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
                       int dt_stride, const DevConst<T>& dc, const LaunchPolicy& lp)
 {
     const int grid = (B + BLOCK - 1) / BLOCK;
-    TileMap plain;
-    plain.full = (unsigned)grid;
     // policy 0: nt loads and stores; 1: default-policy loads (first predict behind a kernel that stored the records with
     // the default policy); 2: default loads and stores (records do not fit the Infinity Cache) -- see predict_kernel
     if (K == 1) {
-        // more than one round of waves: the tiles beyond the last whole round as sub-tile waves, spread over all CUs (TileMap)
-        const TileMap tm = lp.tail_split ? TileMap::balanced((unsigned)grid, (unsigned)lp.simds) : plain;
 #define FBUS_LAUNCH_PREDICT(LD, ST)                                                                                     \
-    hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD, ST>), dim3(tm.grid((unsigned)grid)), dim3(BLOCK), 0, s, recs, B, K, accel, \
-                       gyro, dt, dt_stride, dc, tm)
+    hipLaunchKernelGGL((predict_kernel<T, N, D, false, LD, ST>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt, \
+                       dt_stride, dc)
         if (policy == 2) FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD_BIG, FBUS_X_PREDICT_ST_BIG);      // records larger than the Infinity Cache
         else if (policy == 1) FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD_WARM, AUX_NT);      // first predict behind a default-policy writer
         else FBUS_LAUNCH_PREDICT(FBUS_X_PREDICT_LD, FBUS_X_PREDICT_ST);
@@ -59,13 +55,13 @@ void launch_predict_k(hipStream_t s, T* recs, int B, int K, int policy, const T*
         // LDS between their uses (StepPark; 512 registers, one wave per SIMD).  Rounds 1-3 ran predict_n as K launches of the per-call
         // kernel -- the resident loop spilled 580 bytes per lane; the parked form spills 68 (N = 18) / 0 (N = 15).
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
-                           K, accel, gyro, dt, dt_stride, dc, plain);
+                           K, accel, gyro, dt, dt_stride, dc);
     } else if (lp.two_wave(B)) {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true, AUX_NT, FBUS_X_PREDICT_ST, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B,
-                           K, accel, gyro, dt, dt_stride, dc, plain);
+                           K, accel, gyro, dt, dt_stride, dc);
     } else {
         hipLaunchKernelGGL((predict_kernel<T, N, D, true>), dim3(grid), dim3(BLOCK), 0, s, recs, B, K, accel, gyro, dt,
-                           dt_stride, dc, plain);
+                           dt_stride, dc);
     }
 }
 #define FBUS_INST(D)                                                                                                  \
@@ -309,13 +305,10 @@ void launch_pixels_split_k(hipStream_t s, T* recs, int B, int M, const int* ids,
 {
     const int tiles = (B + 63) / 64;
     if (roles >= 3)
-        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 4, false>), dim3(tiles), dim3(256), 0, s, recs, B, M, ids, left, right, size,
-                           r_pix, skip, applied, id2slot, mc);
-    else if (roles == 12)       // experiment (FBUS_MEAS_SPLIT=12): two waves per tile with the 256-register corner-by-corner fold
-        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 2, true>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right, size,
+        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 4>), dim3(tiles), dim3(256), 0, s, recs, B, M, ids, left, right, size,
                            r_pix, skip, applied, id2slot, mc);
     else
-        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 2, false>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right, size,
+        hipLaunchKernelGGL((correct_pixels_split_kernel<T, N, 2>), dim3(tiles), dim3(128), 0, s, recs, B, M, ids, left, right, size,
                            r_pix, skip, applied, id2slot, mc);
 }
 #define FBUS_INST(D)                                                                                                   \

@@ -21,14 +21,6 @@
 constexpr int N = 18;
 using RC = Rec<float, N>;
 static std::vector<float>* g_h = nullptr;
-// TAIL_SPLIT=1: the library's balanced tail (TileMap::balanced over 1024 SIMDs); TAIL_SHIFT=s forces 1 << s waves per tail tile
-static TileMap tail_map(int tiles)
-{
-    TileMap tm; tm.full = (unsigned)tiles;
-    if (getenv("TAIL_SPLIT") && atoi(getenv("TAIL_SPLIT"))) tm = TileMap::balanced((unsigned)tiles, 1024u);
-    if (getenv("TAIL_SHIFT") && tiles > 1024) { tm.full = (unsigned)(tiles / 1024 * 1024); tm.shift = (unsigned)atoi(getenv("TAIL_SHIFT")); }
-    return tm;
-}
 static void reset_records(float* recs) { CK(hipMemcpy(recs, g_h->data(), g_h->size() * 4, hipMemcpyHostToDevice)); }
 
 template <int C0, int C1, int AUX>
@@ -177,12 +169,11 @@ static void run_lib_pol(float* recs, const float* acc, const float* gyr, const f
     DevConst<float> dc = {};
     dc.qd[0] = 1e-4f; dc.qd[1] = 1e-6f; dc.qd[2] = 1e-8f; dc.qd[3] = 1e-10f;
     const int tiles = B / 64, reps = 200;
-    const TileMap tm = tail_map(tiles);
     reset_records(recs);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto go = [&](int r) {
         const size_t o = (size_t)(r % pool) * B * 3;
-        predict_kernel<float, 18, 0, false, LD, ST><<<tm.grid((unsigned)tiles), 64>>>(recs, B, 1, acc + o, gyr + o, dt, 0, dc, tm);
+        predict_kernel<float, 18, 0, false, LD, ST><<<tiles, 64>>>(recs, B, 1, acc + o, gyr + o, dt, 0, dc);
     };
     for (int r = 0; r < 5; ++r) go(r);
     CK(hipDeviceSynchronize());
@@ -190,7 +181,7 @@ static void run_lib_pol(float* recs, const float* acc, const float* gyr, const f
     for (int r = 0; r < reps; ++r) go(r);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("   B %6d (%4d tiles, %4u waves, tail shift %u) library predict_kernel %s: %.2f us per launch\n", B, tiles, tm.grid((unsigned)tiles), tm.shift, name, ms * 1e3 / reps);
+    printf("   B %6d (%4d waves) library predict_kernel %s: %.2f us per launch\n", B, tiles, name, ms * 1e3 / reps);
 }
 
 static void run_lib(float* recs, const float* acc, const float* gyr, const float* dt, int B, int pool)
@@ -198,12 +189,11 @@ static void run_lib(float* recs, const float* acc, const float* gyr, const float
     DevConst<float> dc = {};
     dc.qd[0] = 1e-4f; dc.qd[1] = 1e-6f; dc.qd[2] = 1e-8f; dc.qd[3] = 1e-10f;
     const int tiles = B / 64, reps = 200;
-    const TileMap tm = tail_map(tiles);
     reset_records(recs);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto go = [&](int r) {
         const size_t o = (size_t)(r % pool) * B * 3;
-        predict_kernel<float, 18, 0, false><<<tm.grid((unsigned)tiles), 64>>>(recs, B, 1, acc + o, gyr + o, dt, 0, dc, tm);
+        predict_kernel<float, 18, 0, false><<<tiles, 64>>>(recs, B, 1, acc + o, gyr + o, dt, 0, dc);
     };
     for (int r = 0; r < 5; ++r) go(r);
     CK(hipDeviceSynchronize());
@@ -222,7 +212,6 @@ static void run_mixed(float* recs, const float* acc, const float* gyr, const flo
     DevConst<float> dc = {};
     dc.qd[0] = 1e-4f; dc.qd[1] = 1e-6f; dc.qd[2] = 1e-8f; dc.qd[3] = 1e-10f;
     const int tiles = B / 64, frames = 40;
-    const TileMap tm = tail_map(tiles);
     reset_records(recs);
     std::vector<hipEvent_t> ev(2 * frames);
     for (auto& e : ev) CK(hipEventCreate(&e));
@@ -231,7 +220,7 @@ static void run_mixed(float* recs, const float* acc, const float* gyr, const flo
         if (f >= 0) CK(hipEventRecord(ev[2 * f]));
         for (int k = 0; k < K; ++k, ++r) {
             const size_t o = (size_t)(r % 96) * B * 3;
-            predict_kernel<float, 18, 0, false><<<tm.grid((unsigned)tiles), 64>>>(recs, B, 1, acc + o, gyr + o, dt, 0, dc, tm);
+            predict_kernel<float, 18, 0, false><<<tiles, 64>>>(recs, B, 1, acc + o, gyr + o, dt, 0, dc);
         }
         if (f >= 0) CK(hipEventRecord(ev[2 * f + 1]));
         timeline_kernel<0, SAUX><<<tiles, 64>>>(recs, acc, gyr, dt, 1e-4f, 1e-6f, 1e-8f, 1e-10f, d_st, 1, 0);
