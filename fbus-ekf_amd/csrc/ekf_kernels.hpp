@@ -88,6 +88,12 @@ __device__ __forceinline__ T ld_once(const T* p) { return __builtin_nontemporal_
 #ifndef FBUS_X_FRAME_ST
 #define FBUS_X_FRAME_ST AUX_DEFAULT    // record stores of the fused frame / frame window kernels
 #endif
+#ifndef FBUS_X_FMEAS_ST
+// ... of the fused frame with the pixel / corner update (frame_meas_kernel): write-through, as the per-call updates store.  Same-box A/B
+// (profiles/r05_stagger.txt): M = 4 left 9.60e9 / 9.98e9 -> 1.005e10 / 1.012e10 steps/s, stereo 8.25 / 8.36 -> 8.61 / 8.38e9; the pose frame
+// and the frame window do not care (1.58-1.60e10 / 2.48-2.5e10 either way) and keep the default policy
+#define FBUS_X_FMEAS_ST AUX_SC1
+#endif
 #ifndef FBUS_X_PREDICT_LD
 #define FBUS_X_PREDICT_LD AUX_NT       // record-load policy of the streamed per-call predict (records that fit the Infinity Cache)
 #endif

@@ -1705,8 +1705,8 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
 #pragma unroll
             for (int k = 0; k < EPC; ++k) P[c * EPC + k] = e[k];
         }
-        store_chunks<T, N, 0, RC::CH_KIN, FBUS_X_FRAME_ST>(rs, lane, nom);
-        store_chunks<T, N, CN, RC::CH_VAR_END, FBUS_X_FRAME_ST>(rs, lane, P);
+        store_chunks<T, N, 0, RC::CH_KIN, FBUS_X_FMEAS_ST>(rs, lane, nom);
+        store_chunks<T, N, CN, RC::CH_VAR_END, FBUS_X_FMEAS_ST>(rs, lane, P);
         if (M > 0) applied[b] = 0;
         return;
     }
@@ -1724,8 +1724,8 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
     meas_solve_update<T, N>(P, acc, Rd, 1.0 / r_meas, dx);
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
-    store_chunks<T, N, 0, CN, FBUS_X_FRAME_ST>(rs, lane, nom);
-    store_chunks<T, N, CN, RC::NCH, FBUS_X_FRAME_ST>(rs, lane, P);
+    store_chunks<T, N, 0, CN, FBUS_X_FMEAS_ST>(rs, lane, nom);
+    store_chunks<T, N, CN, RC::NCH, FBUS_X_FMEAS_ST>(rs, lane, P);
     applied[b] = 1;
 }
 

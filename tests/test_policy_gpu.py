@@ -196,3 +196,51 @@ def test_shards_equal_the_single_handle_bit_for_bit_under_the_policy_batch():
             d0 = np.abs(gathered[0].astype(np.float64) - single[0]).max()
             print(f"[shards] un-pinned shards against the single handle: max |d nominal| {d0:.2e}, bit-equal {np.array_equal(gathered[0], single[0])}")
             assert d0 < 1e-4
+
+
+def test_shards_of_a_job_above_one_round_equal_the_single_handle_bit_for_bit():
+    """(round 5, advisor) 73 728 filters are more than one wave per SIMD: the single handle runs the <= 256-register forms (row-split
+    correct, parked predict_n, frame2_kernel).  Its two shards of 36 864 filters are each BELOW that threshold -- left alone they take the
+    one-wave forms, which agree with the others to an ulp only.  With the policy batch set to the job's total the shards run the job's
+    forms (LaunchPolicy::policy_b) and the gathered result is bit-equal."""
+    import torch
+    total, M, K = 73728, 4, 5
+    prm, nom, rot, P, prev, acc3, gyr3, ids, pos, quat = _inputs(total, M, with_cov=False)
+    acc, gyr = synth.imu_samples(0, total, 0, K, nom)
+    acc, gyr = _r32(acc), _r32(gyr)
+    dts = np.full(K, DT[0])
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+    def job(flt, lo, hi):
+        flt.set_state(nom[lo:hi], rot[lo:hi], None, prev[lo:hi])
+        flt.reset_cov()
+        flt.predict_n(np.ascontiguousarray(acc[:, lo:hi]), np.ascontiguousarray(gyr[:, lo:hi]), dts)       # parked above one round
+        flt.correct(ids[lo:hi], pos[lo:hi], quat[lo:hi], capi.MODE_STACKED)                                   # row-split above one round
+        flt.frame(f32(acc[:3, lo:hi]), f32(gyr[:3, lo:hi]), f32(dts[:3]), torch.from_numpy(np.ascontiguousarray(ids[lo:hi])).cuda(),
+                  f32(pos[lo:hi]), f32(quat[lo:hi]), capi.MODE_STACKED, fused=True)                            # frame2_kernel above one round
+        flt.sync()
+        return flt.get_state()
+
+    with BatchedFilter(total, prm) as flt:
+        if flt.launch_info(capi.INFO_SIMDS) != 1024:
+            pytest.skip("thresholds of the 1024-SIMD device")
+        assert total >= flt.launch_info(capi.INFO_TWO_WAVE_MIN_B)
+        single = job(flt, 0, total)
+    half = total // 2
+    for pinned in (True, False):
+        parts = []
+        for lo, hi in ((0, half), (half, total)):
+            with BatchedFilter(hi - lo, prm) as flt:
+                assert hi - lo < flt.launch_info(capi.INFO_TWO_WAVE_MIN_B)
+                if pinned:
+                    flt.set_policy_batch(total)
+                parts.append(job(flt, lo, hi))
+        gathered = [np.concatenate([p[i] for p in parts]) for i in range(4)]
+        if pinned:
+            for name, a, b in zip(("nominal", "rot", "P", "prev"), gathered, single):
+                assert np.array_equal(a, b), f"pinned shards differ from the single handle in {name}"
+        else:
+            same = all(np.array_equal(a, b) for a, b in zip(gathered, single))
+            d = np.abs(gathered[2].astype(np.float64) - single[2]).max() / np.abs(single[2]).max()
+            print(f"[shards] un-pinned shards of 73 728 filters against the single handle: bit-equal {same}, max |d P| / max |P| {d:.2e}")
+            assert d < 1e-6              # (the one-wave forms against the <= 256-register forms: to an ulp, not to the bit)
