@@ -38,12 +38,22 @@ __device__ __forceinline__ unsigned my_lane() { return threadIdx.x & 63u; }
 #ifndef FBUS_X_STAGGER_MEAS
 #define FBUS_X_STAGGER_MEAS 32      // the per-call pixel / corner updates with one wave per tile
 #endif
+#ifndef FBUS_X_STAGGER_PREDN
+#define FBUS_X_STAGGER_PREDN 0      // predict_n with one wave per SIMD (the unparked K-step loop)
+#endif
+#ifndef FBUS_X_STAGGER_F64FRAME
+#define FBUS_X_STAGGER_F64FRAME 0   // frame2_kernel<double> (one wave per SIMD, 1600-byte records)
+#endif
 template <int UNITS>
 __device__ __forceinline__ void simd_stagger()
 {
     if constexpr (UNITS > 0) {
         const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);      // 2 bits at offset 4 of HW_ID
-        for (unsigned i = 0; i < simd; ++i) __builtin_amdgcn_s_sleep(UNITS);
+        for (unsigned i = 0; i < simd; ++i) {
+#pragma unroll
+            for (int j = 0; j < UNITS / 127; ++j) __builtin_amdgcn_s_sleep(127);
+            if constexpr (UNITS % 127 > 0) __builtin_amdgcn_s_sleep(UNITS % 127);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -506,6 +516,7 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[Lay<N>::NNOM], P[RC::NCOVP];
     if (MULTI) {
+        if constexpr (!PARK) simd_stagger<FBUS_X_STAGGER_PREDN>();
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
         if constexpr (PARK) {
@@ -1046,6 +1057,7 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
     if constexpr (MAP_LATE) {
+        simd_stagger<FBUS_X_STAGGER_F64FRAME>();
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
     } else {
