@@ -38,12 +38,7 @@ __device__ __forceinline__ unsigned my_lane() { return threadIdx.x & 63u; }
 #ifndef FBUS_X_STAGGER_MEAS
 #define FBUS_X_STAGGER_MEAS 32      // the per-call pixel / corner updates with one wave per tile
 #endif
-#ifndef FBUS_X_STAGGER_PREDN
-#define FBUS_X_STAGGER_PREDN 0      // predict_n with one wave per SIMD (the unparked K-step loop)
-#endif
-#ifndef FBUS_X_STAGGER_F64FRAME
-#define FBUS_X_STAGGER_F64FRAME 0   // frame2_kernel<double> (one wave per SIMD, 1600-byte records)
-#endif
+// (also tried: predict_n K = 7 at 64 units 30.0 -> 29.3 us, frame2_kernel<double> at 128 units 85 -> 88-90 us: not adopted)
 template <int UNITS>
 __device__ __forceinline__ void simd_stagger()
 {
@@ -516,7 +511,6 @@ predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, 
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[Lay<N>::NNOM], P[RC::NCOVP];
     if (MULTI) {
-        if constexpr (!PARK) simd_stagger<FBUS_X_STAGGER_PREDN>();
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
         if constexpr (PARK) {
@@ -1057,7 +1051,6 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, my_tile());
     T nom[L::NNOM], P[RC::NCOVP];
     if constexpr (MAP_LATE) {
-        simd_stagger<FBUS_X_STAGGER_F64FRAME>();
         load_chunks<T, N, 0, CN, AUX_NT>(rs, my_lane(), nom);
         load_chunks<T, N, CN, RC::NCH, AUX_NT>(rs, my_lane(), P);
     } else {

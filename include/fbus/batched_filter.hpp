@@ -106,6 +106,17 @@ public:
                          const uint8_t* skip = nullptr)
     { check(fbus_ekf_correct_corners(h_, M, ids, left, right, geometry, int(mode), skip), "correct_corners"); }
 
+    // (round 5) one camera frame with the north star's update in ONE launch (device pointers): K predicts, then correct_pixels
+    // (kind = FBUS_MEAS_PIXELS; right may be null = left camera) or correct_corners (FBUS_MEAS_CORNERS with its geometry / mode) --
+    // filter.cpp:232-235 with the reprojection rows in place of the pose rows
+    void frame_meas_fused_dev(int K, const Real* accel, const Real* gyro, const Real* dt, int kind, int M, const int32_t* ids,
+                              const Real* left, const Real* right = nullptr, int geometry = FBUS_VIS_REFRACTIVE,
+                              Mode mode = Mode::Stacked, const uint8_t* skip = nullptr)
+    {
+        check(fbus_ekf_frame_meas_fused_dev(h_, K, accel, gyro, dt, 0, kind, M, ids, left, right, geometry, int(mode), skip),
+              "frame_meas_fused_dev");
+    }
+
     // waves per 64-filter tile (fbus_ekf_set_team): 0 = chosen per launch, 1 = always one, 2..4 = always that many
     void set_team(int predict_roles, int correct_roles) { check(fbus_ekf_set_team(h_, predict_roles, correct_roles), "set_team"); }
 

@@ -220,3 +220,57 @@ def test_fused_frame_at_the_bench_size():
         assert np.isfinite(sa[0]).all() and np.isfinite(Ps).all() and np.array_equal(Ps, np.swapaxes(Ps, 1, 2))
         dg = np.sqrt(np.einsum("bii->bi", Ps))
         assert np.linalg.eigvalsh(Ps / (dg[:, :, None] * dg[:, None, :])).min() > 0
+
+
+def test_cpp_mirror_reaches_the_new_entry_point(tmp_path):
+    """include/fbus/batched_filter.hpp::frame_meas_fused_dev compiled with plain g++ against the device library: K predicts through
+    the new entry point (M = 0: predicts only) equal fbus_ekf_predict_n_dev bit for bit, and a bad `kind` is refused by exception."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(ROOT, "fbus-ekf_amd", "lib")
+    src = tmp_path / "fm.cpp"
+    src.write_text(r'''
+#include <fbus/batched_filter.hpp>
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+int main() {
+    using BF = fbus::BatchedFilter<float>;
+    const int B = 300, K = 4;
+    std::vector<float> a(size_t(K) * B * 3), w(size_t(K) * B * 3), dt(K, 0.005f);
+    for (size_t i = 0; i < a.size(); ++i) { a[i] = 0.05f * float(i % 11) - 0.2f; w[i] = 0.002f * float(i % 7) - 0.004f; }
+    float *da, *dw, *ddt;
+    if (hipMalloc((void**)&da, a.size() * 4) != hipSuccess || hipMalloc((void**)&dw, w.size() * 4) != hipSuccess || hipMalloc((void**)&ddt, K * 4) != hipSuccess) return 2;
+    hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ddt, dt.data(), K * 4, hipMemcpyHostToDevice);
+    std::vector<char> r1, r2;
+    for (int pass = 0; pass < 2; ++pass) {
+        BF f(B, BF::defaults(FBUS_DIALECT_MATLAB), 0);
+        f.reset_covariance();
+        if (pass == 0) f.frame_meas_fused_dev(K, da, dw, ddt, FBUS_MEAS_PIXELS, 0, nullptr, nullptr);
+        else if (fbus_ekf_predict_n_dev(f.handle(), K, da, dw, ddt, 0) != FBUS_OK) return 3;
+        f.sync();
+        void* recs = nullptr; size_t tot = 0;
+        fbus_ekf_records(f.handle(), &recs, nullptr, &tot);
+        std::vector<char>& r = pass ? r2 : r1;
+        r.resize(tot);
+        hipMemcpy(r.data(), recs, tot, hipMemcpyDeviceToHost);
+        if (pass == 1) {
+            bool threw = false;
+            try { f.frame_meas_fused_dev(K, da, dw, ddt, 7, 0, nullptr, nullptr); } catch (const std::exception&) { threw = true; }
+            if (!threw) return 4;
+        }
+    }
+    std::printf("records equal %d\n", int(r1.size() == r2.size() && std::memcmp(r1.data(), r2.data(), r1.size()) == 0));
+    return (r1.size() == r2.size() && std::memcmp(r1.data(), r2.data(), r1.size()) == 0) ? 0 : 5;
+}
+''')
+    exe = tmp_path / "fm"
+    subprocess.run(["g++", "-std=c++14", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    str(src), "-o", str(exe), "-L", libdir, "-lfbus_ekf", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "records equal 1" in r.stdout
