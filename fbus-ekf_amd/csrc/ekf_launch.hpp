@@ -90,8 +90,9 @@ void launch_corners2_k(hipStream_t s, T* recs, int B, int M, const int* ids, con
 // ---- one camera frame with the north star's MeasureUpdate in one launch (ekf_meas.hpp::frame_meas_kernel; fp32) -----------------
 // kind: corner pixels (geometry / mode ignored; right == nullptr: left camera) or stereo corners (geometry, mode as correct_corners)
 enum { MEAS_PIXELS = 0, MEAS_CORNERS = 1 };
+// F = 1: one frame of kcount[0] predicts; F > 1: a window of F frames in one launch (kcount: F host bytes; measurements [F][B][M]...)
 template <typename T, int N, int D>
-void launch_frame_meas_k(hipStream_t s, T* recs, int B, int K, const T* accel, const T* gyro, const T* dt, int dt_stride, int kind,
+void launch_frame_meas_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro, const T* dt, int dt_stride, int kind,
                          int M, const int* ids, const T* left, const T* right, int geometry, int mode, double size, double r_meas,
                          double switch_thres, const unsigned char* skip, unsigned char* applied, const short* id2slot,
                          const MeasConst& mc, const VisConst<double>& vc, const VisConst<T>& vct, const T* qd);

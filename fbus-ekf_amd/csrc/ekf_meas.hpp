@@ -1499,9 +1499,9 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
 // =================================================================================
 template <typename T> struct QDiag { T qd[4]; };      // (MEAS_PIXELS / MEAS_CORNERS: ekf_launch.hpp)
 
-template <typename T, int N, int DIALECT, int KIND, bool NZ>
+template <typename T, int N, int DIALECT, int KIND, bool NZ, bool WINDOW = false>
 __global__ void __launch_bounds__(64)
-frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
+frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __restrict__ accel, const T* __restrict__ gyro,
                   const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ left,
                   const T* __restrict__ right, int geometry, int mode, double size, double r_meas, double switch_thres,
                   const unsigned char* __restrict__ skip, unsigned char* __restrict__ applied, const short* __restrict__ id2slot,
@@ -1516,7 +1516,7 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
     const unsigned tile = blockIdx.x;
     const int b = (int)(tile * 64u + lane);
     const int bc = b < B ? b : (int)(tile * 64u);
-    const bool live = b < B && M > 0 && !(skip && skip[bc]);
+    size_t fo = 0;                                       // f * B: where frame f's measurements start (WINDOW)
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc<T, N>(recs, tile);
     __shared__ MeasLDS tbl;
     __shared__ u32x4 park_mem[PCH * 64];
@@ -1527,7 +1527,7 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
     struct Meas { int id; T l[KIND == MEAS_CORNERS ? 12 : 8], r[8]; };
     // the id and the image coordinates of marker slot i (16-byte loads; the layouts of correct_pixels2 / correct_corners2_kernel)
     auto fetch = [&](int i, Meas& mm) __attribute__((always_inline)) {
-        const size_t o = (size_t)bc * M + i;
+        const size_t o = (fo + (size_t)bc) * M + i;
         constexpr int EP = 16 / (int)sizeof(T);
         mm.id = ids[o];
         const u32x4* pl = reinterpret_cast<const u32x4*>(left + o * lw);
@@ -1574,12 +1574,11 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
             }
         }
     };
-    T nom[L::NNOM];
+    T nom[L::NNOM], P[RC::NCOVP];
     Meas cur, nxt;
     T prev_raw = T(0);
     simd_stagger<FBUS_X_STAGGER_FRAME>();
     {
-        T P[RC::NCOVP];
         {
             // the marker map -> LDS, the record behind it (lanes past B load their existing tile too: no branch in front of the loads)
             constexpr int NI = (int)sizeof(short) * (FBUS_MAX_MARKER_ID + 1) / 16, NM = (int)sizeof(double) * FBUS_MAX_MARKERS * MKC_STRIDE / 16;
@@ -1603,10 +1602,24 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
             for (int q = 0; q < PM; ++q) { const int i = threadIdx.x + q * NT; if (i < NM) dm[i] = vm[q]; }
             order_fence();
         }
-        if (b >= B) return;
+    }
+    if (b >= B) return;
+    // WINDOW: F times { K_f ImuUpdates, the update } with the record resident from the first load to the last store (offline replay of a
+    // recorded stretch of corners.txt, FBUS_EKF.m:151-210); otherwise one pass (F = 1).  Same device functions in the same order per filter
+    // as F launches of the frame form: bit-identical results.
+    int k0 = 0;
+    bool did = false;
+#pragma unroll 1
+    for (int f = 0; f < (WINDOW ? F : 1); ++f) {
+    const int K = kc.k[f];
+    fo = (size_t)f * B;
+    const bool live = M > 0 && !(skip && skip[fo + b]);
+    {
         // K ImuUpdates; under the covariance stages of the last one the first marker's image points are requested
         auto first_marker = [&]() __attribute__((always_inline)) { if (M > 0) fetch(0, cur); };
-        predict_steps<T, N, DIALECT>(nom, P, K, accel, gyro, dt, dt_stride, B, b, qd.qd, first_marker);
+        predict_steps<T, N, DIALECT>(nom, P, K, accel + (size_t)k0 * B * 3, gyro + (size_t)k0 * B * 3, dt + (size_t)k0 * (dt_stride ? B : 1),
+                                     dt_stride, B, b, qd.qd, first_marker);
+        k0 += K;
         order_fence();
         if (KIND == MEAS_CORNERS && mode == MODE_NEAREST && DIALECT == DIALECT_CPP) prev_raw = P[L::OFF_PREV - L::OFF_COV];
         // the covariance as predicted -> LDS (what ImuUpdate can change; the rest is in the record as it was)
@@ -1695,8 +1708,8 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
         }
     }
     order_fence();
-    T P[RC::NCOVP];
-    if (!live || nfold == 0.0) {
+    did = live && nfold != 0.0;
+    if (!did) {
         // no update for this filter (skipped, no usable marker, M = 0): the record as predicted -- what ImuUpdate writes
 #pragma unroll
         for (int c = 0; c < PCH; ++c) {
@@ -1705,10 +1718,16 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
 #pragma unroll
             for (int k = 0; k < EPC; ++k) P[c * EPC + k] = e[k];
         }
-        store_chunks<T, N, 0, RC::CH_KIN, FBUS_X_FMEAS_ST>(rs, lane, nom);
-        store_chunks<T, N, CN, RC::CH_VAR_END, FBUS_X_FMEAS_ST>(rs, lane, P);
-        if (M > 0) applied[b] = 0;
-        return;
+        if constexpr (!WINDOW) {
+            store_chunks<T, N, 0, RC::CH_KIN, FBUS_X_FMEAS_ST>(rs, lane, nom);
+            store_chunks<T, N, CN, RC::CH_VAR_END, FBUS_X_FMEAS_ST>(rs, lane, P);
+            if (M > 0) applied[b] = 0;
+            return;
+        } else {
+            // the next frame's ImuUpdates read the predict-invariant tail as well: back from the record (current: see below)
+            if constexpr (RC::CH_VAR_END < RC::NCH) load_chunks<T, N, RC::CH_VAR_END, RC::NCH>(rs, lane, P + PCH * EPC);
+            continue;
+        }
     }
     // the predict-invariant tail from the record (L2-hot: this wave read it at the top), the rest back from LDS
     if constexpr (RC::CH_VAR_END < RC::NCH) load_chunks<T, N, RC::CH_VAR_END, RC::NCH>(rs, lane, P + PCH * EPC);
@@ -1724,9 +1743,26 @@ frame_meas_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ acce
     meas_solve_update<T, N>(P, acc, Rd, 1.0 / r_meas, dx);
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
-    store_chunks<T, N, 0, CN, FBUS_X_FMEAS_ST>(rs, lane, nom);
-    store_chunks<T, N, CN, RC::NCH, FBUS_X_FMEAS_ST>(rs, lane, P);
-    applied[b] = 1;
+    if constexpr (!WINDOW) {
+        store_chunks<T, N, 0, CN, FBUS_X_FMEAS_ST>(rs, lane, nom);
+        store_chunks<T, N, CN, RC::NCH, FBUS_X_FMEAS_ST>(rs, lane, P);
+        applied[b] = 1;
+        return;
+    } else {
+        // the update changed the predict-invariant tail too, and the next frame's tail fetches it from the record again: out it goes
+        // (ten chunks; a later load of this wave from the same addresses returns what was stored: vector memory operations of one wave
+        // are served in order -- frame2_kernel relies on the same)
+        if constexpr (RC::CH_VAR_END < RC::NCH) {
+            if (f + 1 < F) store_chunks<T, N, RC::CH_VAR_END, RC::NCH, FBUS_X_FMEAS_ST>(rs, lane, P + PCH * EPC);
+        }
+        order_fence();
+    }
+    }   // frames
+    if constexpr (WINDOW) {
+        store_chunks<T, N, 0, CN, FBUS_X_FMEAS_ST>(rs, lane, nom);
+        store_chunks<T, N, CN, RC::NCH, FBUS_X_FMEAS_ST>(rs, lane, P);
+        if (M > 0 && F > 0) applied[b] = did ? 1 : 0;
+    }
 }
 
 

@@ -698,13 +698,20 @@ int launch_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* l
 // per tile anyway -- fp32 records, more than half a chip of tiles (or fbus_ekf_set_team(., 1)) -- and bit-equal to the per-call
 // sequence there; otherwise predict_n + the per-call update (whose team forms fill a small launch better than one resident wave
 // per tile could; fp64 records: the resident fold + covariance do not fit 512 registers).
-template <typename T, int N, int D>
-int launch_frame_meas_t(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter, int kind, int M,
-                        const int32_t* ids, const void* left, const void* right, int geometry, int mode, const uint8_t* skip)
+// fused: does this handle take the resident kernel (frame_meas_kernel) for M marker slots of this kind / mode?
+template <typename T>
+bool frame_meas_resident(const fbus_ekf* h, int kind, int M, int mode)
 {
     const int roles = (kind == MEAS_CORNERS && mode != MODE_STACKED) ? 1 : team_roles_pixels(h, M);
-    const bool fused = sizeof(T) == 4 && M > 0 && roles == 1 && !h->no_frame_meas;
-    if (!fused) {
+    return sizeof(T) == 4 && M > 0 && roles == 1 && !h->no_frame_meas;
+}
+template <typename T, int N, int D>
+int launch_frame_meas_t(fbus_ekf_t h, int F, const unsigned char* kc, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
+                        int kind, int M, const int32_t* ids, const void* left, const void* right, int geometry, int mode, const uint8_t* skip)
+{
+    // F = 1: one frame; F > 1: a window (the caller has checked that the resident kernel applies)
+    const int K = kc[0];
+    if (F == 1 && !frame_meas_resident<T>(h, kind, M, mode)) {
         int rc = FBUS_OK;
         if (K > 0) rc = launch_predict_t<T, N, D>(h, K, accel, gyro, dt, dt_per_filter);
         if (rc == FBUS_OK && M > 0)
@@ -714,11 +721,11 @@ int launch_frame_meas_t(fbus_ekf_t h, int K, const void* accel, const void* gyro
     }
     if constexpr (sizeof(T) == 4) {
         if (((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right)) & 15) != 0)
-            return fail(h, FBUS_ERR_INVALID, "fbus_ekf_frame_meas_fused_dev: left / right must be 16-byte aligned device pointers");
-        const int ev = timing_begin(h, FBUS_KERNEL_FRAME);
+            return fail(h, FBUS_ERR_INVALID, "fbus_ekf_frame(s)_meas_fused_dev: left / right must be 16-byte aligned device pointers");
+        const int ev = timing_begin(h, FBUS_KERNEL_FRAME, F);
         h->records_warm = true;
         const DevConst<T> dc = make_dc<T>(h);
-        launch_frame_meas_k<T, N, D>(h->stream, (T*)h->recs, h->B, K, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0,
+        launch_frame_meas_k<T, N, D>(h->stream, (T*)h->recs, h->B, F, kc, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0,
                                      kind, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode, h->prm.marker_size,
                                      kind == MEAS_PIXELS ? h->prm.r_pix : h->prm.r_pos, h->prm.switch_thres, (const unsigned char*)skip,
                                      h->d_applied, h->d_id2slot, make_mc(h), make_vc<double>(h), make_vc<T>(h), dc.qd);
@@ -727,10 +734,14 @@ int launch_frame_meas_t(fbus_ekf_t h, int K, const void* accel, const void* gyro
     }
     return FBUS_OK;
 }
-int launch_frame_meas(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int per, int kind, int M,
-                      const int32_t* ids, const void* left, const void* right, int geometry, int mode, const uint8_t* skip)
+int launch_frame_meas(fbus_ekf_t h, int F, const unsigned char* kc, const void* accel, const void* gyro, const void* dt, int per, int kind,
+                      int M, const int32_t* ids, const void* left, const void* right, int geometry, int mode, const uint8_t* skip)
 {
-    DISPATCH(h, launch_frame_meas_t, h, K, accel, gyro, dt, per, kind, M, ids, left, right, geometry, mode, skip);
+    DISPATCH(h, launch_frame_meas_t, h, F, kc, accel, gyro, dt, per, kind, M, ids, left, right, geometry, mode, skip);
+}
+bool frame_meas_is_resident(const fbus_ekf* h, int kind, int M, int mode)
+{
+    return h->dtype == 32 ? frame_meas_resident<float>(h, kind, M, mode) : false;
 }
 
 int launch_correct_corners(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, int geometry,
@@ -1500,7 +1511,60 @@ int fbus_ekf_frame_meas_fused_dev(fbus_ekf_t h, int K, const void* accel, const 
         if (M > 0 && geometry != FBUS_VIS_CORNERS3D && !right) return FBUS_ERR_INVALID;
         if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     }
-    return launch_frame_meas(h, K, accel, gyro, dt, dt_per_filter, kind, M, ids, left, right, geometry, mode, skip);
+    if (K > 255) {          // (the resident kernel counts a frame's samples in a byte)
+        int rc = launch_predict(h, K, accel, gyro, dt, dt_per_filter);
+        if (rc == FBUS_OK && M > 0)
+            rc = kind == FBUS_MEAS_PIXELS ? launch_correct_pixels(h, M, ids, left, right, skip)
+                                          : launch_correct_corners(h, M, ids, left, right, geometry, mode, skip);
+        return rc;
+    }
+    const unsigned char kc1 = (unsigned char)K;
+    return launch_frame_meas(h, 1, &kc1, accel, gyro, dt, dt_per_filter, kind, M, ids, left, right, geometry, mode, skip);
+}
+
+int fbus_ekf_frames_meas_fused_dev(fbus_ekf_t h, int nframes, const int32_t* kcount, const void* accel, const void* gyro, const void* dt,
+                                   int dt_per_filter, int kind, int M, const int32_t* ids, const void* left, const void* right, int geometry,
+                                   int mode, const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || nframes < 0 || nframes > FBUS_MAX_WINDOW_FRAMES || M < 0 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (kind != FBUS_MEAS_PIXELS && kind != FBUS_MEAS_CORNERS) return FBUS_ERR_UNSUPPORTED;
+    if (nframes > 0 && !kcount) return FBUS_ERR_INVALID;
+    unsigned char kc[FBUS_MAX_WINDOW_FRAMES];
+    size_t total = 0;
+    for (int f = 0; f < nframes; ++f) {
+        if (kcount[f] < 0 || kcount[f] > 255) return FBUS_ERR_INVALID;
+        kc[f] = (unsigned char)kcount[f];
+        total += (size_t)kcount[f];
+    }
+    if (total > 0 && (!accel || !gyro || !dt)) return FBUS_ERR_INVALID;
+    if (M > 0 && nframes > 0 && (!ids || !left)) return FBUS_ERR_INVALID;
+    if (kind == FBUS_MEAS_PIXELS) {
+        if (!(h->prm.r_pix > 0)) return fail(h, FBUS_ERR_INVALID, "r_pix must be positive");
+        geometry = FBUS_VIS_REFRACTIVE; mode = FBUS_MODE_STACKED;
+    } else {
+        if (geometry != FBUS_VIS_REFRACTIVE && geometry != FBUS_VIS_PINHOLE && geometry != FBUS_VIS_CORNERS3D) return FBUS_ERR_UNSUPPORTED;
+        if (M > 0 && nframes > 0 && geometry != FBUS_VIS_CORNERS3D && !right) return FBUS_ERR_INVALID;
+        if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    }
+    if (nframes == 0) return FBUS_OK;
+    // the resident window kernel where the frame form takes the resident kernel (fp32 records, one wave per tile); elsewhere frame by
+    // frame through the frame entry point's routes -- the same arithmetic
+    if (nframes > 1 && frame_meas_is_resident(h, kind, M, mode))
+        return launch_frame_meas(h, nframes, kc, accel, gyro, dt, dt_per_filter, kind, M, ids, left, right, geometry, mode, skip);
+    const size_t es = esize(h), B = (size_t)h->B;
+    const size_t lw = (kind == FBUS_MEAS_CORNERS && geometry == FBUS_VIS_CORNERS3D) ? 12 : 8;
+    size_t k0 = 0;
+    for (int f = 0; f < nframes; ++f) {
+        const int rc = launch_frame_meas(h, 1, kc + f, (const char*)accel + k0 * B * 3 * es, (const char*)gyro + k0 * B * 3 * es,
+                                         (const char*)dt + k0 * (dt_per_filter ? B : 1) * es, dt_per_filter, kind, M,
+                                         ids ? ids + (size_t)f * B * M : nullptr, left ? (const char*)left + (size_t)f * B * M * lw * es : nullptr,
+                                         right ? (const char*)right + (size_t)f * B * M * 8 * es : nullptr, geometry, mode,
+                                         skip ? skip + (size_t)f * B : nullptr);
+        if (rc != FBUS_OK) return rc;
+        k0 += kc[f];
+    }
+    return FBUS_OK;
 }
 
 int fbus_ekf_frames_fused_dev(fbus_ekf_t h, int nframes, const int32_t* kcount, const void* accel, const void* gyro,

@@ -272,27 +272,34 @@ void launch_corners2_k(hipStream_t s, T* recs, int B, int M, const int* ids, con
                                                              const MeasConst&, const VisConst<double>&, const VisConst<FBUS_TU_T>&);
 #elif FBUS_TU_FAMILY == 8
 template <typename T, int N, int D>
-void launch_frame_meas_k(hipStream_t s, T* recs, int B, int K, const T* accel, const T* gyro, const T* dt, int dt_stride, int kind,
-                         int M, const int* ids, const T* left, const T* right, int geometry, int mode, double size, double r_meas,
-                         double switch_thres, const unsigned char* skip, unsigned char* applied, const short* id2slot,
+void launch_frame_meas_k(hipStream_t s, T* recs, int B, int F, const unsigned char* kcount, const T* accel, const T* gyro, const T* dt,
+                         int dt_stride, int kind, int M, const int* ids, const T* left, const T* right, int geometry, int mode, double size,
+                         double r_meas, double switch_thres, const unsigned char* skip, unsigned char* applied, const short* id2slot,
                          const MeasConst& mc, const VisConst<double>& vc, const VisConst<T>& vct, const T* qd)
 {
     const int tiles = (B + 63) / 64;
+    FrameCounts kc;
+    for (int f = 0; f < FBUS_MAX_WINDOW_FRAMES; ++f) kc.k[f] = f < F ? kcount[f] : 0;
     QDiag<T> q;
     for (int i = 0; i < 4; ++i) q.qd[i] = qd[i];
     // the port square to the camera (the reference's configuration): the shorter fold / triangulation, as the per-call launchers choose
     const bool nz = (kind == MEAS_PIXELS) ? (mc.n[0] == 0.0 && mc.n[1] == 0.0 && mc.n[2] == 1.0)
                                           : (vc.nrm[0] == 0.0 && vc.nrm[1] == 0.0 && vc.nrm[2] == 1.0);
 #define FBUS_LAUNCH_FM(KIND, NZF)                                                                                        \
-    hipLaunchKernelGGL((frame_meas_kernel<T, N, D, KIND, NZF>), dim3(tiles), dim3(64), 0, s, recs, B, K, accel, gyro, dt,  \
-                       dt_stride, M, ids, left, right, geometry, mode, size, r_meas, switch_thres, skip, applied, id2slot, mc, vc, \
-                       vct, q)
+    do {                                                                                                                 \
+        if (F > 1) hipLaunchKernelGGL((frame_meas_kernel<T, N, D, KIND, NZF, true>), dim3(tiles), dim3(64), 0, s, recs, B, F, kc, accel, \
+                                      gyro, dt, dt_stride, M, ids, left, right, geometry, mode, size, r_meas, switch_thres, skip, \
+                                      applied, id2slot, mc, vc, vct, q);                                                 \
+        else hipLaunchKernelGGL((frame_meas_kernel<T, N, D, KIND, NZF, false>), dim3(tiles), dim3(64), 0, s, recs, B, F, kc, accel, \
+                                gyro, dt, dt_stride, M, ids, left, right, geometry, mode, size, r_meas, switch_thres, skip,  \
+                                applied, id2slot, mc, vc, vct, q);                                                       \
+    } while (0)
     if (kind == MEAS_PIXELS) { if (nz) FBUS_LAUNCH_FM(MEAS_PIXELS, true); else FBUS_LAUNCH_FM(MEAS_PIXELS, false); }
     else                     { if (nz) FBUS_LAUNCH_FM(MEAS_CORNERS, true); else FBUS_LAUNCH_FM(MEAS_CORNERS, false); }
 #undef FBUS_LAUNCH_FM
 }
 #define FBUS_INST(D)                                                                                                   \
-    template void launch_frame_meas_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const FBUS_TU_T*,     \
+    template void launch_frame_meas_k<FBUS_TU_T, FBUS_TU_N, D>(hipStream_t, FBUS_TU_T*, int, int, const unsigned char*, const FBUS_TU_T*, \
                                                                const FBUS_TU_T*, const FBUS_TU_T*, int, int, int, const int*, \
                                                                const FBUS_TU_T*, const FBUS_TU_T*, int, int, double, double, \
                                                                double, const unsigned char*, unsigned char*, const short*, \

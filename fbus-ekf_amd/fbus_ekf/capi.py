@@ -128,6 +128,7 @@ def load_library():
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_meas_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
+        "fbus_ekf_frames_meas_fused_dev": ([H, C.c_int, ip, vp, vp, vp, C.c_int, C.c_int, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
         "fbus_ekf_frames_fused_dev": ([H, C.c_int, ip, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_init_gravity_bias": ([H, C.c_int, vp, vp], C.c_int),
         "fbus_ekf_init_gravity_bias_dev": ([H, C.c_int, vp, vp], C.c_int),

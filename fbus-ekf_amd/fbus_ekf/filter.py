@@ -385,6 +385,38 @@ class BatchedFilter:
         self._check(rc, "frame_meas_fused_dev")
         self._order_out(cur)
 
+    def frames_meas(self, kcount, accel, gyro, dt, ids, left, right=None, kind=capi.MEAS_PIXELS, geometry=capi.VIS_REFRACTIVE,
+                    mode=capi.MODE_STACKED, skip=None):
+        """A window of camera frames with the north star's MeasureUpdate in ONE launch (fbus_ekf_frames_meas_fused_dev; device arrays):
+        len(kcount) times { kcount[f] predicts, correct_pixels / correct_corners }.  accel, gyro: (sum kcount, B, 3); dt: (sum kcount,) or
+        (sum kcount, B); ids: (F, B, M); left / right: (F, B, M, 8) [(F, B, M, 12) for VIS_CORNERS3D]; skip: (F, B) or None."""
+        B = self.B
+        kcount = np.ascontiguousarray(kcount, np.int32)
+        F, Kt = int(kcount.size), int(kcount.sum())
+        if F > capi.MAX_WINDOW_FRAMES:
+            raise ValueError(f"at most {capi.MAX_WINDOW_FRAMES} frames per window")
+        M = ids.numel() // (B * F) if (ids is not None and F > 0) else 0
+        per = 0
+        if Kt > 0:
+            per = 1 if (dt.numel() == Kt * B and B > 1) else 0
+            if not per and dt.numel() < Kt:
+                raise ValueError("dt must have sum(kcount) or sum(kcount)*B elements")
+            self._dev_checked(accel, Kt * B * 3, "accel"); self._dev_checked(gyro, Kt * B * 3, "gyro")
+            self._dev_checked(dt, dt.numel(), "dt")
+        if M > 0:
+            lw = 12 if (kind == capi.MEAS_CORNERS and geometry == capi.VIS_CORNERS3D) else 8
+            self._dev_checked(ids, F * B * M, "ids"); self._dev_checked(left, F * B * M * lw, "left")
+            if right is not None:
+                self._dev_checked(right, F * B * M * 8, "right")
+        if skip is not None:
+            self._dev_checked(skip, F * B, "skip")
+        cur = self._order_in(accel, gyro, dt, ids, left, right, skip)
+        rc = self._lib.fbus_ekf_frames_meas_fused_dev(self._h, F, kcount.ctypes.data_as(C.POINTER(C.c_int32)), self._p(accel), self._p(gyro),
+                                                      self._p(dt), per, kind, M, self._p(ids), self._p(left), self._p(right), geometry, mode,
+                                                      self._p(skip))
+        self._check(rc, "frames_meas_fused_dev")
+        self._order_out(cur)
+
     def frames(self, kcount, accel, gyro, dt, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
         """A window of camera frames in ONE launch (device arrays): len(kcount) times { kcount[f] predicts, one correct }
         with the records resident in registers in between -- the frame loop of FBUS_EKF.m:151-210 over a recorded stretch.

@@ -117,6 +117,15 @@ public:
               "frame_meas_fused_dev");
     }
 
+    // ... and a window of such frames in one launch (offline replay of recorded corners; measurements [F][B][M]...)
+    void frames_meas_fused_dev(const std::vector<int32_t>& kcount, const Real* accel, const Real* gyro, const Real* dt, int kind, int M,
+                               const int32_t* ids, const Real* left, const Real* right = nullptr, int geometry = FBUS_VIS_REFRACTIVE,
+                               Mode mode = Mode::Stacked, const uint8_t* skip = nullptr)
+    {
+        check(fbus_ekf_frames_meas_fused_dev(h_, int(kcount.size()), kcount.data(), accel, gyro, dt, 0, kind, M, ids, left, right, geometry,
+                                             int(mode), skip), "frames_meas_fused_dev");
+    }
+
     // waves per 64-filter tile (fbus_ekf_set_team): 0 = chosen per launch, 1 = always one, 2..4 = always that many
     void set_team(int predict_roles, int correct_roles) { check(fbus_ekf_set_team(h_, predict_roles, correct_roles), "set_team"); }
 

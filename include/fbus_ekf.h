@@ -105,7 +105,7 @@ int fbus_params_validate(const fbus_params* prm, char* msg, size_t msg_len);
  * the caller's compile-time sizeof(fbus_params) and FBUS_ABI_VERSION to fbus_ekf_create_checked, which refuses a
  * mismatch with FBUS_ERR_ABI.  (Bindings that cannot use the macro -- ctypes, loadlibrary -- call
  * fbus_ekf_abi_version() / fbus_params_size() once after loading and compare; the Python mirror does.)
- *   5  round 5: fbus_ekf_frame_meas_fused_dev (struct unchanged)
+ *   5  round 5: fbus_ekf_frame_meas_fused_dev, fbus_ekf_frames_meas_fused_dev (struct unchanged)
  *   4  round 4: fbus_ekf_set_policy_batch, fbus_ekf_launch_info (struct unchanged)
  *   3  round 3: FBUS_ERR_ABI, create_checked, team kernels (fbus_ekf_set_team), fbus_ekf_gather
  *   2  round 2: r_pix in fbus_params, set_stream(NULL) = legacy default stream
@@ -286,6 +286,17 @@ enum { FBUS_MEAS_PIXELS = 0, FBUS_MEAS_CORNERS = 1 };
 int fbus_ekf_frame_meas_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
                                   int kind, int M, const int32_t* ids, const void* left, const void* right, int geometry, int mode,
                                   const uint8_t* skip);
+
+/* (round 5) A WINDOW of such frames in ONE launch (offline replay of a recorded stretch of corners.txt through the north star's model: the
+ * frame loop of matlab/FBUS_EKF.m:151-210 with the reprojection / corner rows): nframes times { kcount[f] predicts, the update }, the
+ * records resident from the first load to the last store.  Same arithmetic and results as nframes calls of
+ * fbus_ekf_frame_meas_fused_dev (bit-equal where that takes its resident kernel; elsewhere this entry point runs frame by frame).
+ *   kcount HOST array, nframes entries (<= FBUS_MAX_WINDOW_FRAMES), each 0..255;  accel, gyro [sum kcount][B][3], dt [sum kcount] or [..][B]
+ *   ids [nframes][B][M], left / right [nframes][B][M][8] ([..][12] corner positions for FBUS_VIS_CORNERS3D), skip [nframes][B] or NULL
+ * fbus_ekf_get_applied afterwards reports the LAST frame of the window. */
+int fbus_ekf_frames_meas_fused_dev(fbus_ekf_t h, int nframes, const int32_t* kcount, const void* accel, const void* gyro, const void* dt,
+                                   int dt_per_filter, int kind, int M, const int32_t* ids, const void* left, const void* right, int geometry,
+                                   int mode, const uint8_t* skip);
 
 /* A WINDOW of camera frames in ONE launch (offline replay of a recorded stretch: the frame loop of
  * matlab/FBUS_EKF.m:151-210 / FilterThreadFunction, filter.cpp:229-235): nframes times { kcount[f] predicts, one

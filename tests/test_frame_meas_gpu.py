@@ -274,3 +274,89 @@ int main() {
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "records equal 1" in r.stdout
+
+
+@pytest.mark.parametrize("what,stereo,mode", [("pixels", False, capi.MODE_STACKED), ("pixels", True, capi.MODE_STACKED),
+                                              ("corners", True, capi.MODE_STACKED), ("corners", True, capi.MODE_NEAREST)])
+@pytest.mark.parametrize("dialect,n", [(0, 18), (1, 18), (0, 15)])
+def test_window_of_frames_with_the_north_star_update(dialect, n, what, stereo, mode):
+    """fbus_ekf_frames_meas_fused_dev: a window of camera frames -- { K_f predicts, the pixel / corner update } x F with the record resident
+    -- against the same frames as F launches of the frame form (the same kernel body, instantiated with and without the frame loop), and
+    against the oracle through the window gate.  A frame without IMU samples, a filter that sees nothing in one frame, unknown ids in
+    another, masked filters."""
+    import torch
+    B, M = 448 - 5, 4
+    kcount = [3, 0, 2, 4]
+    F, Kt = len(kcount), sum(kcount)
+    prm, nom, rot, P, prev, ids0, left0, right0 = _scene(B, M, dialect, n, seed=61 + dialect)
+    acc, gyr = synth.imu_samples(0, B, 0, Kt, nom)
+    acc, gyr = r32(acc), r32(gyr)
+    rng = np.random.default_rng(7)
+    ids = np.stack([ids0] * F); left = np.stack([left0] * F); right = np.stack([right0] * F)
+    left = r32(left + rng.normal(0, 2e-4, left.shape)); right = r32(right + rng.normal(0, 2e-4, right.shape))
+    ids[1, 5] = -1
+    ids[2, 6, :] = 9
+    skip = np.zeros((F, B), np.uint8); skip[2, 11] = 1; skip[3, 12] = 1; skip[0, 13] = 1
+    dd = _dev(torch, 32)
+    d_acc, d_gyr, d_dt = dd(acc), dd(gyr), dd(np.full(Kt, DT[0]))
+    d_ids, d_left, d_right, d_skip = dd(ids), dd(left), dd(right), dd(skip)
+    kind = capi.MEAS_PIXELS if what == "pixels" else capi.MEAS_CORNERS
+    with BatchedFilter(B, prm, nstate=n) as fa, BatchedFilter(B, prm, nstate=n) as fb:
+        for f in (fa, fb):
+            f.set_team(1, 1)
+            f.set_state(nom, rot, P, prev)
+        fa.frames_meas(kcount, d_acc, d_gyr, d_dt, d_ids, d_left, d_right if stereo else None, kind, capi.VIS_REFRACTIVE, mode, skip=d_skip)
+        k0 = 0
+        for f, K in enumerate(kcount):
+            a, g, t = (d_acc[k0:k0 + K], d_gyr[k0:k0 + K], d_dt[k0:k0 + K]) if K else (None, None, None)
+            fb.frame_meas(a, g, t, d_ids[f], d_left[f], d_right[f] if stereo else None, kind, capi.VIS_REFRACTIVE, mode, skip=d_skip[f])
+            k0 += K
+        fa.sync(); fb.sync()
+        sa, sb = fa.get_state(), fb.get_state()
+        assert np.array_equal(fa.applied(), fb.applied())
+    # bit for bit: the window form and the frame form are one kernel body, with and without the frame loop (measured: equal in every case)
+    for x, y, name in zip(sa, sb, ("nominal", "rot", "P", "prev")):
+        assert np.array_equal(x, y), f"window != frame by frame in {name}: {what} stereo={stereo} mode={mode}"
+    # the oracle, frame by frame -- twice: fp64 throughout, and fp64 arithmetic with the RECORD rounded to fp32 after every step (the floor
+    # of tests/util.py::assert_window_parity: four reprojection updates 15-20 ms apart pin the position to ~1e-4 m and differentiate the
+    # fp32 position's 6e-8 m quantum into the velocity -- an exact-arithmetic filter with fp32 records is 1e-4 (literal) off the fp64 run
+    # here, and so is the kernel)
+    vp = oc.vision_params()
+    corners = None
+    if what == "corners":
+        corners = np.zeros((F, B, M, 4, 3))
+        for f in range(F):
+            for b in range(B):
+                for m in range(M):
+                    if ids[f, b, m] >= 0:
+                        corners[f, b, m] = oc.refraction_triangulate(vp, left[f, b, m], right[f, b, m])
+
+    def oracle_run(fp32_records):
+        eng = OracleEngine(B, dialect, n)
+        eng.set_state(nom, rot, P, prev)
+
+        def q():
+            if fp32_records:
+                eng.nominal[...] = r32(eng.nominal); eng.rot[...] = r32(eng.rot); eng.P[...] = r32(eng.P)
+        k0 = 0
+        for f, K in enumerate(kcount):
+            for k in range(K):
+                eng.predict(acc[k0 + k], gyr[k0 + k], DT); q()
+            k0 += K
+            keep = eng.get_state()
+            if what == "pixels":
+                eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids[f], left[f], right[f] if stereo else None, SIZE, prm.r_pix)
+            else:
+                eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids[f], corners[f], SIZE, mode)
+            now = eng.get_state()
+            for x, y in zip(now, keep):
+                x[skip[f] == 1] = y[skip[f] == 1]
+            eng.set_state(*now)
+            q()
+        return eng.get_state()
+
+    ref = oracle_run(False)
+    from util import parity_errors
+    floor = parity_errors(oracle_run(True), ref)
+    assert_window_parity(sa, ref, f"window of {F} frames vs oracle N={n} d{dialect} {what} {'stereo' if stereo else 'left'} mode {mode}",
+                         dialect, n, floor=floor)

@@ -149,18 +149,30 @@ def window_literal_tol(dialect, nstate):
     return WINDOW_LITERAL_TOL_CPP18 if (dialect == 1 and nstate == 18) else STATE_TOL
 
 
-def assert_window_parity(got, ref, what, dialect, nstate, verbose=True, prev=True):
-    """THE gate of free-running windows (fp32 kernels against the fp64 oracle, or two fp32 kernel forms against each other)."""
+FLOOR_FACTOR = 3.0
+
+
+def assert_window_parity(got, ref, what, dialect, nstate, verbose=True, prev=True, floor=None):
+    """THE gate of free-running windows (fp32 kernels against the fp64 oracle, or two fp32 kernel forms against each other).
+    `floor` (optional): parity_errors of the fp64 ORACLE run with fp32 RECORDS (the record rounded to fp32 after every step, exact
+    arithmetic inside the steps) against the fp64 oracle on the same inputs -- what the test computed on the CPU.  Where that floor
+    exceeds a standard bound, the bound becomes FLOOR_FACTOR x the floor: a kernel is held to the north star's figures or to three
+    times what an exact-arithmetic filter with its record type loses, whichever is larger (camera frames a few IMU samples apart whose
+    reprojection rows pin the position to 1e-4 m differentiate the fp32 position's 6e-8 m quantum into the velocity)."""
     e = parity_errors(got, ref)
+    fl = floor or {}
+    tol = lambda name, std: max(std, FLOOR_FACTOR * fl.get(name, 0.0))
     if verbose:
         print(f"[parity] {what}: literal {e['literal']:.2e}  sigma-aware {e['sigma']:.2e} ({e['sigma_block']})  "
-              f"plain per-block {e['plain']:.2e} ({e['plain_block']})  cov {e['cov']:.2e}  cov block-wise {e['cov_block']:.2e}")
-    lit = window_literal_tol(dialect, nstate)
+              f"plain per-block {e['plain']:.2e} ({e['plain_block']})  cov {e['cov']:.2e}  cov block-wise {e['cov_block']:.2e}" +
+              (f"   [fp32-record floor: literal {fl['literal']:.2e} sigma-aware {fl['sigma']:.2e} plain {fl['plain']:.2e} cov block-wise {fl['cov_block']:.2e}]"
+               if floor else ""))
+    lit = tol("literal", window_literal_tol(dialect, nstate))
     assert e["literal"] <= lit, f"{what}: literal state rel err {e['literal']:.3g} > {lit:g}"
-    assert e["sigma"] <= WINDOW_TOL, f"{what}: state rel err {e['sigma']:.3g} in block {e['sigma_block']}"
-    assert e["plain"] <= PLAIN_WINDOW_TOL, f"{what}: plain per-block state rel err {e['plain']:.3g} in block {e['plain_block']}"
-    assert e["cov"] <= COV_TOL, f"{what}: covariance rel err {e['cov']:.3g}"
-    assert e["cov_block"] <= WINDOW_COV_BLOCK_TOL, f"{what}: block-wise covariance rel err {e['cov_block']:.3g}"
+    assert e["sigma"] <= tol("sigma", WINDOW_TOL), f"{what}: state rel err {e['sigma']:.3g} in block {e['sigma_block']}"
+    assert e["plain"] <= tol("plain", PLAIN_WINDOW_TOL), f"{what}: plain per-block state rel err {e['plain']:.3g} in block {e['plain_block']}"
+    assert e["cov"] <= tol("cov", COV_TOL), f"{what}: covariance rel err {e['cov']:.3g}"
+    assert e["cov_block"] <= tol("cov_block", WINDOW_COV_BLOCK_TOL), f"{what}: block-wise covariance rel err {e['cov_block']:.3g}"
     assert e["asym"] == 0, f"{what}: covariance not exactly symmetric"
     if prev:
         assert e["prev_equal"], f"{what}: prev marker id"
