@@ -47,11 +47,19 @@ def pose_from_marker(meas_row, params):
     return p, q, R
 
 
-def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
+def replay(engine, imu, image, params, max_frames=None, matlab_reset=True, corners=None, stereo=True):
     """Runs the recording through `engine` (B = 1).  Returns (states, npredict):
-    states[k] = [t, nominal(19), rot(9), P(N*N)] after frame k."""
+    states[k] = [t, nominal(19), rot(9), P(N*N)] after frame k.
+    corners (optional; round 5): the rows of corners.txt that belong to the rows of image.txt (`t id` + 8 left + 8 right undistorted
+    normalised corner coordinates, vision.cpp:111-119).  The frame loop, the initialisation and the resets stay as they are (they use
+    the marker poses of image.txt, as the reference does), but every MeasureUpdate becomes the north star's: correct() from the corner
+    PIXELS through the flat-port model (engine.correct_pixels; stereo=False: the left camera's rows only)."""
     imu = np.asarray(imu, float)
     image = np.asarray(image, float)
+    if corners is not None:
+        corners = np.asarray(corners, float)
+        if len(corners) != len(image) or np.abs(corners[:, 0] - image[:, 0]).max() > 1e-9:
+            raise ValueError("corners rows must be the rows of image (same time stamps)")
     N = engine.N
     P0 = np.diag(np.repeat(np.array(list(params.p0_diag)), 3)[:N])[None]
     engine.set_state(np.zeros((1, 19)), np.zeros((1, 9)), P0, np.zeros(1, np.int32))
@@ -69,6 +77,7 @@ def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
             j += 1
         cur = image[n_img, 0]
         meas = image[n_img:j, 1:9]
+        crn = corners[n_img:j] if corners is not None else None
         n_img = j
         cnt = 0
         if cur - pre_img > 0.1 and pre_img != 0 and matlab_reset:   # FBUS_EKF.m:168-171, ResetState.m:75-79
@@ -91,7 +100,10 @@ def replay(engine, imu, image, params, max_frames=None, matlab_reset=True):
                 k += 1
             idx = k
             pre_img = cur
-            engine.correct(meas[:, 0].astype(np.int32)[None], meas[None, :, 1:4], meas[None, :, 4:8], 0)
+            if crn is None:
+                engine.correct(meas[:, 0].astype(np.int32)[None], meas[None, :, 1:4], meas[None, :, 4:8], 0)
+            else:
+                engine.correct_pixels(crn[:, 1].astype(np.int32)[None], crn[None, :, 2:10], crn[None, :, 10:18] if stereo else None)
         nominal, rot, P, _ = engine.get_state()
         out.append(np.concatenate([[cur], nominal.ravel(), rot.ravel(), P.ravel()]).astype(np.float64))
         npred.append(cnt)

@@ -181,6 +181,9 @@ def recordings():
         fus = np.loadtxt(f"{REF}/{d}/fusion.txt")
         out[f"{tag}_fusion_bg"] = fus[:, [0, 14, 15, 16]]
         out[f"{tag}_fusion_pose"] = fus[:, 0:8]          # t, p(3), q(wxyz): the recorded fused trajectory (older revision)
+    # the water recording's corners.txt in full (`t id` + 8 left + 8 right undistorted normalised corner coordinates, vision.cpp:111-119):
+    # what the cameras saw, row for row with image.txt -- the input of the replay through the north star's reprojection rows
+    out["water_corners"] = np.loadtxt(f"{REF}/waterdata/dataset-06/corners.txt")
     np.savez_compressed(os.path.join(HERE, "recordings.npz"), **out)
 
 

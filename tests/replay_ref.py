@@ -43,6 +43,16 @@ class OracleEngine:
     def correct(self, ids, pos, quat, mode=0, skip=None):
         return self.orc.correct(self.nominal, self.rot, self.P, self.prev, ids, pos, quat, mode)
 
+    # the north star's update on the oracle side: marker_size / r_pix are the handle's parameters (set them from fbus_params)
+    marker_size, r_pix = 0.28, 1e-6
+
+    def correct_pixels(self, ids, left, right=None, skip=None):
+        ids = np.ascontiguousarray(ids, np.int32).reshape(self.B, -1)
+        M = ids.shape[1]
+        left = np.ascontiguousarray(left, float).reshape(self.B, M, 8)
+        right = None if right is None else np.ascontiguousarray(right, float).reshape(self.B, M, 8)
+        return self.orc.correct_pixels(self.nominal, self.rot, self.P, self.prev, ids, left, right, self.marker_size, self.r_pix)
+
 
 def replay_with_oracle(imu, image, dialect, nframes):
     eng = OracleEngine(1, dialect, 18)

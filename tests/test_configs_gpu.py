@@ -411,3 +411,75 @@ def test_cpp_frame_loop_with_resets_and_gapped_recording():
         with BatchedFilter(1, prm, dtype=64) as flt:
             got, n = replay.replay(flt, imu, image, prm)
         assert (n == nref).all() and np.abs(got[:, 1:29] - ref[:, 1:29]).max() < 1e-9
+
+
+WATER_MARKER_SIDE = 0.1142        # metres: what the water recording's own corners triangulate to (median side 0.1142, std 0.0016, over 852 sides;
+                                  # vision.hpp:114 says 0.28 and paramconfig.yml:23 0.48 -- neither is what was in the tank; the pose pipeline never uses it)
+
+
+def test_water_recording_through_the_north_stars_reprojection_rows():
+    """The reference's water recording (waterdata/dataset-06: imu.txt + corners.txt, what its cameras SAW through the flat port) replayed with
+    the north star's MeasureUpdate: FBUS_EKF.m's frame loop, every update = correct() from the stereo corner pixels through the flat-port
+    model (fbus_ekf_correct_pixels) instead of from the marker pose of image.txt.
+      * fp64 device == oracle frame by frame; fp32 device against the oracle through the window gate with the fp32-record floor the test
+        computes (100 frames, ~4000 ImuUpdates);
+      * the model explains the reference's DATA: at the filter's posterior the forward projection of the marker's corners reproduces the
+        recorded corner pixels to ~1 px rms (2.6e-3 in normalised coordinates, the marker's side being known to 1.4 %), and the trajectory
+        stays within centimetres of the pose-row replay of the same recording."""
+    import oracle_capi as oc
+    from util import assert_window_parity, parity_errors
+    d = np.load(os.path.join(GOLD, "recordings.npz"))
+    imu, image, corners = d["water_imu"], d["water_image"], d["water_corners"]
+    nfr = 100
+    r32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    for dialect in (0, 1):
+        prm = capi.default_params(dialect)
+        prm.marker_size = WATER_MARKER_SIDE
+
+        class Fp32Records(OracleEngine):                    # the oracle with fp32 RECORDS: rounds its state after every step
+            def predict(self, *a):
+                super().predict(*a); self._q()
+
+            def correct_pixels(self, *a, **k):
+                r = super().correct_pixels(*a, **k); self._q(); return r
+
+            def _q(self):
+                self.nominal[...] = r32(self.nominal); self.rot[...] = r32(self.rot); self.P[...] = r32(self.P)
+        eng, engq = OracleEngine(1, dialect, 18), Fp32Records(1, dialect, 18)
+        for e in (eng, engq):
+            e.marker_size, e.r_pix = prm.marker_size, prm.r_pix
+        ref, nref = replay.replay(eng, imu, image, prm, max_frames=nfr, corners=corners)
+        refq, _ = replay.replay(engq, imu, image, prm, max_frames=nfr, corners=corners)
+        unpack = lambda s: (s[-1:, 1:20], s[-1:, 20:29], s[-1:, 29:].reshape(1, 18, 18), np.zeros(1, np.int32))
+        with BatchedFilter(1, prm, dtype=64) as flt:
+            got, n = replay.replay(flt, imu, image, prm, max_frames=nfr, corners=corners)
+        assert (n == nref).all() and n.sum() > 3500
+        assert np.abs(got[:, 1:20] - ref[:, 1:20]).max() < 1e-7          # (the oracle's rows are central differences of its projection)
+        with BatchedFilter(1, prm, dtype=32) as flt:
+            g32, _ = replay.replay(flt, imu, image, prm, max_frames=nfr, corners=corners)
+        floor = parity_errors(unpack(refq), unpack(ref))
+        assert_window_parity(unpack(g32), unpack(ref), f"water recording through the pixel rows, dialect {dialect}, {nfr} frames / {int(n.sum())} IMU steps, fp32",
+                             dialect, 18, floor=floor, prev=False)
+        # the recorded pixels at the posterior (fp32 device trajectory, oracle's forward projection)
+        R_IL, P_IL, _ = synth.camera_constants(prm)
+        mids, mpos, mquat = synth.marker_table(prm)
+        s = prm.marker_size
+        c = np.array([[0, 0, 0], [0, s, 0], [s, s, 0], [s, 0, 0.0]])
+        vp = oc.vision_params()
+        res = []
+        for row in g32:
+            cr = corners[np.argmin(np.abs(corners[:, 0] - row[0]))]
+            nom = row[1:20]
+            R0 = synth.q2R(nom[6:10])
+            world = mpos[0] + (synth.q2R(mquat[0]) @ c.T).T
+            cam = (R_IL @ (R0.T @ (world - nom[0:3] - R0 @ P_IL).T)).T
+            uvL, uvR, ok = oc.project_stereo(vp, cam)
+            assert ok.all()
+            res.append(np.concatenate([uvL.ravel() - cr[2:10], uvR.ravel() - cr[10:18]]))
+        rms = float(np.sqrt((np.array(res) ** 2).mean()))
+        pose_eng = OracleEngine(1, dialect, 18)
+        pose, _ = replay.replay(pose_eng, imu, image, prm, max_frames=nfr)
+        gap = float(np.linalg.norm(g32[:, 1:4] - pose[:, 1:4], axis=1).max())
+        print(f"[parity] water recording through the pixel rows, dialect {dialect}: reprojection residual of the RECORDED corners at the posterior "
+              f"{rms:.2e} rms (normalised coordinates); position against the pose-row replay of the same recording: max {gap:.3f} m")
+        assert rms < 5e-3 and gap < 0.05

@@ -419,3 +419,48 @@ def test_water_replay_follows_the_recorded_fused_trajectory():
     dp, dr, exc, ratio = relative_motion_gap(states, d["water_fusion_pose"])
     print(f"water, C++ dialect: relative-motion gap to fusion.txt {dp:.3f} m / {dr:.1f} deg over a {exc:.2f} m excursion, distance ratio {ratio[0]:.2f}..{ratio[1]:.2f}")
     assert exc > 0.5 and dp < 0.2 and dr < 10.0 and 0.7 < ratio[0] and ratio[1] < 1.15
+
+
+def test_reprojection_rows_explain_the_water_recording():
+    """The north star's measurement model against the reference's own DATA (oracle only, CPU): the water recording's corners.txt replayed
+    through FBUS_EKF.m's frame loop with every update taken from the corner pixels (flat-port forward projection, 16 rows per frame).
+    At the filter's posterior the projected corners of the marker reproduce the RECORDED pixels to ~1 px rms, and the trajectory stays
+    within centimetres of the pose-row replay of the same recording -- with the marker side the recording itself triangulates to
+    (0.1142 m; with vision.hpp:114's 0.28 m the same replay leaves the tank: the residual is what tells)."""
+    import oracle_capi as oc
+    from fbus_ekf import capi, replay, synth
+    from replay_ref import OracleEngine
+    d = np.load(os.path.join(GOLD, "recordings.npz"))
+    imu, image, corners = d["water_imu"], d["water_image"], d["water_corners"]
+    vp = oc.vision_params()
+    sides = []
+    for r in corners[::25]:
+        t = oc.refraction_triangulate(vp, r[2:10], r[10:18])
+        sides += [np.linalg.norm(t[(k + 1) % 4] - t[k]) for k in range(4)]
+    side = float(np.median(sides))
+    assert abs(side - 0.1142) < 1.5e-3 and np.std(sides) < 3e-3
+
+    def run(size, nfr):
+        prm = capi.default_params(0)
+        prm.marker_size = size
+        eng = OracleEngine(1, 0, 18)
+        eng.marker_size, eng.r_pix = size, prm.r_pix
+        st, n = replay.replay(eng, imu, image, prm, max_frames=nfr, corners=corners)
+        R_IL, P_IL, _ = synth.camera_constants(prm)
+        mids, mpos, mquat = synth.marker_table(prm)
+        c = np.array([[0, 0, 0], [0, size, 0], [size, size, 0], [size, 0, 0.0]])
+        res = []
+        for row in st:
+            cr = corners[np.argmin(np.abs(corners[:, 0] - row[0]))]
+            R0 = synth.q2R(row[7:11])
+            cam = (R_IL @ (R0.T @ (mpos[0] + (synth.q2R(mquat[0]) @ c.T).T - row[1:4] - R0 @ P_IL).T)).T
+            uvL, uvR, ok = oc.project_stereo(vp, cam)
+            res.append(np.concatenate([uvL.ravel() - cr[2:10], uvR.ravel() - cr[10:18]]))
+        pose, _ = replay.replay(OracleEngine(1, 0, 18), imu, image, prm, max_frames=nfr)
+        return float(np.sqrt((np.array(res) ** 2).mean())), float(np.linalg.norm(st[:, 1:4] - pose[:, 1:4], axis=1).max()), st
+
+    rms, gap, st = run(side, 150)
+    print(f"[oracle] water recording through the pixel rows: marker side {side:.4f} m, reprojection residual {rms:.2e} rms, gap to the pose-row replay {gap:.3f} m")
+    assert np.isfinite(st).all() and rms < 5e-3 and gap < 0.05
+    rms_wrong, gap_wrong, _ = run(0.28, 30)
+    assert rms_wrong > 10 * rms                      # the wrong marker side shows in the residual at once
