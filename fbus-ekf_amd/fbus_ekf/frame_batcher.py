@@ -33,6 +33,27 @@ class FrameBatcher:
     def on_detections(self, t_frame, ids, pos, quat, mode):
         """One detection list stamped t_frame: BatchImuProcessing, then ObservationUpdate.  Returns the number of
         predict steps issued."""
+        used = self._advance_to(t_frame)
+        ids = np.asarray(ids, np.int32).reshape(-1)
+        if ids.size:
+            M = ids.size
+            self.flt.correct(np.tile(ids, (self.B, 1)), np.tile(np.asarray(pos, self.dtype).reshape(1, M, 3), (self.B, 1, 1)),
+                             np.tile(np.asarray(quat, self.dtype).reshape(1, M, 4), (self.B, 1, 1)), mode)
+        return used
+
+    def on_corner_pixels(self, t_frame, ids, left, right=None):
+        """(round 5) the same pass with what the cameras saw: the corner pixels of the detected markers (left / right: (M, 8) normalised
+        image coordinates, the corners.txt layout) -> BatchImuProcessing, then filter.correct_pixels -- the north star's MeasureUpdate."""
+        used = self._advance_to(t_frame)
+        ids = np.asarray(ids, np.int32).reshape(-1)
+        if ids.size:
+            M = ids.size
+            rgt = None if right is None else np.tile(np.asarray(right, self.dtype).reshape(1, M, 8), (self.B, 1, 1))
+            self.flt.correct_pixels(np.tile(ids, (self.B, 1)), np.tile(np.asarray(left, self.dtype).reshape(1, M, 8), (self.B, 1, 1)), rgt)
+        return used
+
+    def _advance_to(self, t_frame):
+        """BatchImuProcessing (filter.cpp:483-531)"""
         used = consumed = 0
         for (ts, a, w) in self.buf:                     # filter.cpp:493-517
             if ts < self.t_state:
@@ -46,11 +67,6 @@ class FrameBatcher:
             self.t_state = ts                           # filter.cpp:516
             used += 1
         del self.buf[:consumed]                         # ClearImuBuffer, filter.cpp:520
-        ids = np.asarray(ids, np.int32).reshape(-1)
-        if ids.size:
-            M = ids.size
-            self.flt.correct(np.tile(ids, (self.B, 1)), np.tile(np.asarray(pos, self.dtype).reshape(1, M, 3), (self.B, 1, 1)),
-                             np.tile(np.asarray(quat, self.dtype).reshape(1, M, 4), (self.B, 1, 1)), mode)
         return used
 
     @property

@@ -10,6 +10,7 @@
 //                                                          used samples (and older ones) leave the buffer
 //                         ObservationUpdate  :622-754      -> Filter::correct (marker choice + hysteresis run
 //                                                          inside the kernel)
+//   on_corner_pixels()  the same pass with the detected markers' corner pixels -> Filter::correct_pixels (north star)
 // Pure sequencing: no filter arithmetic happens here.  `Filter` is fbus::BatchedFilter<Real> (or anything with
 // the same predict/correct members, which is how the CPU test drives it with a recorder).  All B filters of the
 // handle receive the same sensor stream (B hypotheses of one robot); for independent streams call the batched
@@ -48,26 +49,35 @@ public:
         if (buf_.size() > max_) buf_.erase(buf_.begin(), buf_.begin() + static_cast<std::ptrdiff_t>(trim_));
     }
 
+    // (round 5) the same pass with what the cameras SAW instead of marker poses: the corner pixels of the M detected markers (left:
+    // M x 8 normalised image coordinates x0 y0 .. x3 y3, the corners.txt layout of vision.cpp:111-119; right: the same from the right
+    // camera, or nullptr) -> BatchImuProcessing, then Filter::correct_pixels -- the north star's MeasureUpdate in the live loop
+    int on_corner_pixels(double t_frame, int M, const std::int32_t* ids, const Real* left, const Real* right)
+    {
+        const int used = advance_to(t_frame);
+        if (M > 0) {
+            ids_.assign(static_cast<std::size_t>(B_) * M, 0);
+            pos_.assign(static_cast<std::size_t>(B_) * M * 8, Real(0));
+            quat_.assign(right ? static_cast<std::size_t>(B_) * M * 8 : 0, Real(0));
+            for (int b = 0; b < B_; ++b)
+                for (int m = 0; m < M; ++m) {
+                    ids_[static_cast<std::size_t>(b) * M + m] = ids[m];
+                    for (int i = 0; i < 8; ++i) {
+                        pos_[(static_cast<std::size_t>(b) * M + m) * 8 + i] = left[8 * m + i];
+                        if (right) quat_[(static_cast<std::size_t>(b) * M + m) * 8 + i] = right[8 * m + i];
+                    }
+                }
+            f_.correct_pixels(M, ids_.data(), pos_.data(), right ? quat_.data() : nullptr, nullptr);
+        }
+        return used;
+    }
+
     // One detection result list stamped t_frame: BatchImuProcessing then ObservationUpdate.
     // Returns the number of predict steps issued.
     template <typename Mode>
     int on_detections(double t_frame, int M, const std::int32_t* ids, const Real* pos, const Real* quat, Mode mode)
     {
-        int used = 0, consumed = 0;
-        for (const Sample& s : buf_) {                      // filter.cpp:493-517
-            if (s.t < t_state_) { ++consumed; continue; }
-            if (s.t > t_frame) break;
-            ++consumed;
-            const Real dt = static_cast<Real>(s.t - t_state_);
-            acc_.assign(static_cast<std::size_t>(B_) * 3, Real(0));
-            gyr_.assign(static_cast<std::size_t>(B_) * 3, Real(0));
-            for (int b = 0; b < B_; ++b)
-                for (int i = 0; i < 3; ++i) { acc_[3 * b + i] = s.accel[i]; gyr_[3 * b + i] = s.gyro[i]; }
-            f_.predict(acc_.data(), gyr_.data(), dt);       // UpdateCovariance + UpdateNominalState
-            t_state_ = s.t;                                 // filter.cpp:516
-            ++used;
-        }
-        buf_.erase(buf_.begin(), buf_.begin() + consumed);  // ClearImuBuffer, filter.cpp:520
+        const int used = advance_to(t_frame);
         if (M > 0) {
             ids_.assign(static_cast<std::size_t>(B_) * M, 0);
             pos_.assign(static_cast<std::size_t>(B_) * M * 3, Real(0));
@@ -88,6 +98,27 @@ public:
     std::size_t buffered() const { return buf_.size(); }
 
 private:
+    // BatchImuProcessing (filter.cpp:483-531): the buffered samples with state time <= t <= t_frame, one predict each
+    int advance_to(double t_frame)
+    {
+        int used = 0, consumed = 0;
+        for (const Sample& s : buf_) {                      // filter.cpp:493-517
+            if (s.t < t_state_) { ++consumed; continue; }
+            if (s.t > t_frame) break;
+            ++consumed;
+            const Real dt = static_cast<Real>(s.t - t_state_);
+            acc_.assign(static_cast<std::size_t>(B_) * 3, Real(0));
+            gyr_.assign(static_cast<std::size_t>(B_) * 3, Real(0));
+            for (int b = 0; b < B_; ++b)
+                for (int i = 0; i < 3; ++i) { acc_[3 * b + i] = s.accel[i]; gyr_[3 * b + i] = s.gyro[i]; }
+            f_.predict(acc_.data(), gyr_.data(), dt);       // UpdateCovariance + UpdateNominalState
+            t_state_ = s.t;                                 // filter.cpp:516
+            ++used;
+        }
+        buf_.erase(buf_.begin(), buf_.begin() + consumed);  // ClearImuBuffer, filter.cpp:520
+        return used;
+    }
+
     Filter& f_;
     int B_;
     double t_state_;

@@ -351,6 +351,8 @@ struct Recorder {
     void predict(const float* a, const float* w, float dt) { std::printf("P %.9g %.9g %.9g %.9g\n", dt, a[0], a[4], w[5]); }
     void correct(int M, const int32_t* ids, const float* pos, const float* quat, int mode, const unsigned char*) {
         std::printf("C %d %d %d %.9g %.9g\n", M, ids[0], mode, pos[4], quat[7]); }
+    void correct_pixels(int M, const int32_t* ids, const float* left, const float* right, const unsigned char*) {
+        std::printf("X %d %d %.9g %.9g %d\n", M, ids[1], left[16 + 9], right ? right[16 + 15] : -1.f, right != nullptr); }
 };
 int main() {
     Recorder r;
@@ -366,7 +368,10 @@ int main() {
         }
         int32_t ids[2] = { frame, 7 };
         float pos[6] = {0, 1, 2, 3, 4.5f, 5}, quat[8] = {1, 0, 0, 0, 0.5f, 0.5f, 0.5f, 0.25f * frame};
-        int used = fb.on_detections(t - 0.0005, 2, ids, pos, quat, 1);
+        float left[16], right[16];
+        for (int i = 0; i < 16; ++i) { left[i] = 0.01f * i + 0.1f * frame; right[i] = -0.02f * i; }
+        int used = (frame % 2) ? fb.on_corner_pixels(t - 0.0005, 2, ids, left, frame == 3 ? nullptr : right)
+                               : fb.on_detections(t - 0.0005, 2, ids, pos, quat, 1);
         std::printf("F %d %zu %.9f\n", used, fb.buffered(), fb.state_time());
     }
 }
@@ -384,6 +389,10 @@ int main() {
         def correct(self, ids, pos, quat, mode):
             got.append("C %d %d %d %.9g %.9g" % (ids.shape[1], ids[0, 0], mode, pos[0, 1, 1], quat[0, 1, 3]))
 
+        def correct_pixels(self, ids, left, right=None):
+            got.append("X %d %d %.9g %.9g %d" % (ids.shape[1], ids[0, 1], left[1, 1, 1], right[1, 1, 7] if right is not None else -1.0,
+                                                 right is not None))
+
     fb = FrameBatcher(Recorder(), 2, 0.0105, True, 40, 10)
     t, k = 0.0, 0
     for frame in range(6):
@@ -392,8 +401,13 @@ int main() {
             fb.set_imu(t, np.array([np.float32(0.1) * np.float32(k), np.float32(1) + np.float32(0.01) * np.float32(k), 2], np.float32),
                        np.array([3, 4, np.float32(0.01) * np.float32(k)], np.float32))
             k += 1
-        used = fb.on_detections(t - 0.0005, [frame, 7], [[0, 1, 2], [3, 4.5, 5]],
-                                [[1, 0, 0, 0], [0.5, 0.5, 0.5, 0.25 * frame]], 1)
+        left = (np.float32(0.01) * np.arange(16, dtype=np.float32) + np.float32(0.1) * np.float32(frame)).reshape(2, 8)
+        right = (np.float32(-0.02) * np.arange(16, dtype=np.float32)).reshape(2, 8)
+        if frame % 2:
+            used = fb.on_corner_pixels(t - 0.0005, [frame, 7], left, None if frame == 3 else right)
+        else:
+            used = fb.on_detections(t - 0.0005, [frame, 7], [[0, 1, 2], [3, 4.5, 5]],
+                                    [[1, 0, 0, 0], [0.5, 0.5, 0.5, 0.25 * frame]], 1)
         got.append("F %d %d %.9f" % (used, fb.buffered, fb.t_state))
     assert got == want
 
