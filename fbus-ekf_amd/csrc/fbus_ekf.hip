@@ -723,7 +723,7 @@ int launch_frame_meas_t(fbus_ekf_t h, int F, const unsigned char* kc, const void
         if (((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right)) & 15) != 0)
             return fail(h, FBUS_ERR_INVALID, "fbus_ekf_frame(s)_meas_fused_dev: left / right must be 16-byte aligned device pointers");
         const int ev = timing_begin(h, FBUS_KERNEL_FRAME, F);
-        h->records_warm = true;
+        h->records_warm = h->warm_after_correct;      // written through (sc1), as the per-call updates: the next predict streams them
         const DevConst<T> dc = make_dc<T>(h);
         launch_frame_meas_k<T, N, D>(h->stream, (T*)h->recs, h->B, F, kc, (const T*)accel, (const T*)gyro, (const T*)dt, dt_per_filter ? 1 : 0,
                                      kind, M, (const int*)ids, (const T*)left, (const T*)right, geometry, mode, h->prm.marker_size,
