@@ -24,6 +24,13 @@
 
 #include <type_traits>
 
+// fp32 ImuUpdate on packed instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue in the slot of one scalar instruction
+// and do two: profiles/r04_issue_rates.txt) -- bit 0: the two rotation increments of the nominal step (full and half angle) as
+// the halves of one pair; bit 1: rows p; bit 2: rows theta; bit 3: the v,v block of rows v.  0 = the scalar forms (A/B builds).
+#ifndef FBUS_X_PACK
+#define FBUS_X_PACK 15
+#endif
+
 namespace fbus {
 
 enum { DIALECT_MATLAB = 0, DIALECT_CPP = 1 };
@@ -141,7 +148,6 @@ __host__ __device__ constexpr bool is_pair(int r, int c)
 {
     return (N % 2 == 0) && c + 1 < N && r <= c && (pidx<N>(r, c) % 2 == 0) && (pidx<N>(r, c + 1) == pidx<N>(r, c) + 1);
 }
-using f32x2 = float __attribute__((ext_vector_type(2)));
 template <typename T, int N> struct PackedMath { static constexpr bool on = false; };
 template <int N> struct PackedMath<float, N> { static constexpr bool on = (N % 2 == 0); };
 
@@ -239,6 +245,56 @@ template <typename T>
 __device__ __forceinline__ void quat_normalize(T* q)
 {
     const T inv = fb_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+
+// ---- the same helpers on register pairs: .x = the full rotation increment (T), .y = the half one (H) ------------------
+// Every half of a packed operation is the scalar operation (same order, same rounding); what differs from the scalar
+// helpers is which products the compiler contracts into FMAs.
+using f32x2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fb_sincos_x_halfx_pk(float x, f32x2& s, f32x2& c)
+{
+    if (__builtin_fabsf(x) <= 0.5f) {
+        const f32x2 xp = { x, 0.5f * x };
+        const f32x2 x2 = xp * xp;
+        s = xp + xp * (x2 * (-1.6666667163e-1f + x2 * (8.3333337680e-3f + x2 * -1.9841270114e-4f)));
+        c = 1.0f + x2 * (-0.5f + x2 * (4.1666667908e-2f + x2 * (-1.3888889225e-3f + x2 * 2.4801587642e-5f)));
+    } else {
+        float s0, c0, s1, c1;
+        sincosf(x, &s0, &c0);
+        sincosf(0.5f * x, &s1, &c1);
+        s = f32x2{ s0, s1 }; c = f32x2{ c0, c1 };
+    }
+}
+__device__ __forceinline__ void quat_mul_pk(const float* p, const f32x2* q, f32x2* o)
+{
+    o[0] = p[0] * q[0] - p[1] * q[1] - p[2] * q[2] - p[3] * q[3];
+    o[1] = p[0] * q[1] + p[1] * q[0] + p[2] * q[3] - p[3] * q[2];
+    o[2] = p[0] * q[2] - p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+    o[3] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+}
+__device__ __forceinline__ void quat_to_rotmat_m_pk(const f32x2* q, f32x2* R)
+{
+    const f32x2 w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z);           R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);           R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);           R[7] = 2 * (y * z + w * x);           R[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void quat_to_rotmat_e_pk(const f32x2* q, f32x2* R)
+{
+    const f32x2 w = q[0], x = q[1], y = q[2], z = q[3];
+    const f32x2 tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const f32x2 twx = tx * w, twy = ty * w, twz = tz * w;
+    const f32x2 txx = tx * x, txy = ty * x, txz = tz * x;
+    const f32x2 tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void quat_normalize_pk(f32x2* q)
+{
+    const f32x2 n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const f32x2 inv = { fb_rsqrt(n2.x), fb_rsqrt(n2.y) };
     q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 
