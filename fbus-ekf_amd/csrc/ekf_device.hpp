@@ -27,8 +27,19 @@
 // fp32 ImuUpdate on packed instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue in the slot of one scalar instruction
 // and do two: profiles/r04_issue_rates.txt) -- bit 0: the two rotation increments of the nominal step (full and half angle) as
 // the halves of one pair; bit 1: rows p; bit 2: rows theta; bit 3: the v,v block of rows v.  0 = the scalar forms (A/B builds).
+// The stages take the mask as their last template argument: pairs want aligned register pairs, and the kernels written for 256
+// registers (two waves per SIMD) or already at 512 take the subset that leaves them without scratch.
 #ifndef FBUS_X_PACK
 #define FBUS_X_PACK 15
+#endif
+#ifndef FBUS_X_PACK_2W
+#define FBUS_X_PACK_2W 9        // frame2_kernel<float> (256 registers): bit 1 costs it 16-24 bytes of scratch
+#endif
+#ifndef FBUS_X_PACK_TEAM
+#define FBUS_X_PACK_TEAM 9      // the team kernels (ekf_team.hpp): all four bits cost frames_team_kernel 48 bytes of scratch
+#endif
+#ifndef FBUS_X_PACK_FMEAS
+#define FBUS_X_PACK_FMEAS 0     // frame_meas_kernel (512 registers around the fp64 fold): bits 1-3 add 12-76 bytes of scratch, bit 0 alone measured -2 %
 #endif
 
 namespace fbus {
@@ -339,6 +350,19 @@ struct PairAcc {
     }
 };
 
+// (P(r,c), P(r,c+1)) as one value.  Meant for aligned storage pairs (is_pair): there it is a register pair as it stands.
+template <int N>
+__device__ __forceinline__ f32x2 ld_pair(const float* P, int r, int c) { return f32x2{ P[pidx<N>(r, c)], P[pidx<N>(r, c + 1)] }; }
+template <int N>
+__device__ __forceinline__ void st_pair(float* P, int r, int c, f32x2 v) { P[pidx<N>(r, c)] = v.x; P[pidx<N>(r, c + 1)] = v.y; }
+// rows (a, b) of a 3 x 3 coefficient block, column by column: what multiplies ONE covariance element on its way into TWO
+// neighbouring outputs
+__device__ __forceinline__ void coef_rows(const float* M, int a, int b, f32x2 (&o)[3])
+{
+#pragma unroll
+    for (int m = 0; m < 3; ++m) o[m] = f32x2{ M[3 * a + m], M[3 * b + m] };
+}
+
 // ================================================================================
 // predict
 // ================================================================================
@@ -373,7 +397,7 @@ __host__ __device__ constexpr int cov_final_before_row(int r)
 
 #define PS(i, j) P[pidx<N>((i), (j))]
 // rows p:  E_p, then the v- and theta-columns of rows p
-template <typename T, int N>
+template <typename T, int N, int PK = FBUS_X_PACK>
 __device__ __forceinline__ void cov_stage_p(T* P, const PredictCoef<T>& k)
 {
     constexpr bool G = (N == 18);
@@ -383,6 +407,37 @@ __device__ __forceinline__ void cov_stage_p(T* P, const PredictCoef<T>& k)
 #pragma unroll
         for (int j = i; j < 3; ++j)
             PS(i, j) += dt * (PS(j, 3 + i) + PS(i, 3 + j)) + dt * dt * PS(3 + i, 3 + j);
+    if constexpr (PackedMath<T, N>::on && (PK & 2)) {
+        // the same operations, two neighbouring columns of a row at a time: the row operation with dt on both halves, the column
+        // operations with rows (1, 2) of A, Bm / rows (0, 1) of Theta on the halves and the covariance element on both
+        f32x2 A12[3], B12[3], T01[3];
+        coef_rows(k.A, 1, 2, A12); coef_rows(k.Bm, 1, 2, B12); coef_rows(k.Th, 0, 1, T01);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            PS(i, 3) += dt * PS(3 + i, 3);
+            if (is_pair<N>(i, 4) && is_pair<N>(3 + i, 4)) st_pair<N>(P, i, 4, ld_pair<N>(P, i, 4) + dt * ld_pair<N>(P, 3 + i, 4));
+            else { PS(i, 4) += dt * PS(3 + i, 4); PS(i, 5) += dt * PS(3 + i, 5); }
+#pragma unroll
+            for (int c = 6; c < N; c += 2) st_pair<N>(P, i, c, ld_pair<N>(P, i, c) + dt * ld_pair<N>(P, 3 + i, c));
+        }
+        // E_v, column v of rows p: P(p,v) += P(p,theta) A' + P(p,ba) Bm' + dt P(p,g)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            PS(c, 3) += k.A[0] * PS(c, 6) + k.A[1] * PS(c, 7) + k.A[2] * PS(c, 8)
+                      + k.Bm[0] * PS(c, 9) + k.Bm[1] * PS(c, 10) + k.Bm[2] * PS(c, 11) + (G ? dt * PS(c, 15) : T(0));
+            f32x2 u = A12[0] * PS(c, 6) + A12[1] * PS(c, 7) + A12[2] * PS(c, 8) + B12[0] * PS(c, 9) + B12[1] * PS(c, 10) + B12[2] * PS(c, 11);
+            if (G) u += dt * ld_pair<N>(P, c, 16);
+            st_pair<N>(P, c, 4, ld_pair<N>(P, c, 4) + u);
+        }
+        // E_theta, column theta of rows p: P(p,theta) = P(p,theta) Th' - dt P(p,bg)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const T o0 = PS(c, 6), o1 = PS(c, 7), o2 = PS(c, 8);
+            st_pair<N>(P, c, 6, T01[0] * o0 + T01[1] * o1 + T01[2] * o2 - dt * ld_pair<N>(P, c, 12));
+            PS(c, 8) = k.Th[6] * o0 + k.Th[7] * o1 + k.Th[8] * o2 - dt * PS(c, 14);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -406,7 +461,7 @@ __device__ __forceinline__ void cov_stage_p(T* P, const PredictCoef<T>& k)
 }
 
 // rows v:  E_v (row part and the symmetric v,v block), then the theta-column of rows v, + Q on the v diagonal
-template <typename T, int N>
+template <typename T, int N, int PK = FBUS_X_PACK>
 __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const T* qd)
 {
     constexpr bool G = (N == 18);
@@ -417,6 +472,8 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
         // D = (P(v,theta) + U_theta/2) A' + (P(v,ba) + U_ba/2) Bm' + dt (P(v,g) + U_g/2) from the PRE-update row i, then
         // P(v_i, theta..) += U(i, :) -- 12 products live at a time instead of 36 (the same operations in the same order per element)
         T D[9];
+        f32x2 A12[3], B12[3];
+        coef_rows(k.A, 1, 2, A12); coef_rows(k.Bm, 1, 2, B12);
         static_for<0, 3>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             T U[NC];
@@ -443,6 +500,32 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
                     for (int c = 0; c < NC; ++c) U[c] += dt * PS(15 + i, 6 + c);
                 }
             }
+            if constexpr (PackedMath<T, N>::on && (PK & 8)) {
+                // t = P(v_i, .) + U(i, .)/2 on the column pairs of the row; D(i, 1), D(i, 2) as the halves of one value (rows (1, 2) of
+                // A and Bm on the halves, t on both), D(i, 0) alone -- the same products in the same order per element
+                T t[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c += 2) {
+                    if (c == 6) continue;                                     // columns bg take no part
+                    if (is_pair<N>(3 + i, 6 + c)) {
+                        const f32x2 r = ld_pair<N>(P, 3 + i, 6 + c) + T(0.5) * f32x2{ U[c], U[c + 1] };
+                        t[c] = r.x; t[c + 1] = r.y;
+                    } else {
+                        t[c] = PS(3 + i, 6 + c) + T(0.5) * U[c]; t[c + 1] = PS(3 + i, 7 + c) + T(0.5) * U[c + 1];
+                    }
+                }
+                T d0 = T(0);
+                f32x2 d12 = { T(0), T(0) };
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    d0 += t[m] * k.A[m];
+                    d0 += t[3 + m] * k.Bm[m];
+                    d12 += t[m] * A12[m];
+                    d12 += t[3 + m] * B12[m];
+                }
+                if (G) { d0 += dt * t[9]; d12 += dt * f32x2{ t[10], t[11] }; }
+                D[3 * i] = d0; D[3 * i + 1] = d12.x; D[3 * i + 2] = d12.y;
+            } else {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 T acc = T(0);
@@ -453,6 +536,7 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
                 }
                 if (G) acc += dt * (PS(3 + i, 15 + j) + T(0.5) * U[9 + j]);
                 D[3 * i + j] = acc;
+            }
             }
             if constexpr (PackedMath<T, N>::on) {
 #pragma unroll
@@ -552,6 +636,16 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
         }
     }
     // E_theta, column theta of rows v: P(v,theta) = P(v,theta) Th' - dt P(v,bg)
+    if constexpr (PackedMath<T, N>::on && (PK & 8)) {
+        f32x2 T01[3];
+        coef_rows(k.Th, 0, 1, T01);
+#pragma unroll
+        for (int c = 3; c < 6; ++c) {
+            const T o0 = PS(c, 6), o1 = PS(c, 7), o2 = PS(c, 8);
+            st_pair<N>(P, c, 6, T01[0] * o0 + T01[1] * o1 + T01[2] * o2 - dt * ld_pair<N>(P, c, 12));
+            PS(c, 8) = k.Th[6] * o0 + k.Th[7] * o1 + k.Th[8] * o2 - dt * PS(c, 14);
+        }
+    } else {
 #pragma unroll
     for (int c = 3; c < 6; ++c) {
         const T o0 = PS(c, 6), o1 = PS(c, 7), o2 = PS(c, 8);
@@ -559,17 +653,65 @@ __device__ __forceinline__ void cov_stage_v(T* P, const PredictCoef<T>& k, const
         for (int i = 0; i < 3; ++i)
             PS(c, 6 + i) = k.Th[3 * i] * o0 + k.Th[3 * i + 1] * o1 + k.Th[3 * i + 2] * o2 - dt * PS(c, 12 + i);
     }
+    }
 #pragma unroll
     for (int i = 3; i < 6; ++i) PS(i, i) += qd[0];
 }
 
+// columns (c, c + 1) of rows theta outside the theta and bg blocks that all three rows hold as an aligned pair
+template <int N>
+__host__ __device__ constexpr bool th_pair_cols(int c)
+{
+    return c >= 9 && (c % 2 == 0) && c + 1 < N && !(c >= 12 && c < 15) && !(c + 1 >= 12 && c + 1 < 15)
+        && is_pair<N>(6, c) && is_pair<N>(7, c) && is_pair<N>(8, c);
+}
 // rows theta:  E_theta on the remaining columns, + Fi Q Fi' (not scaled by dt; ImuUpdate.m:70-73 ; filter.cpp:609-610)
-template <typename T, int N>
+template <typename T, int N, int PK = FBUS_X_PACK>
 __device__ __forceinline__ void cov_stage_th(T* P, const PredictCoef<T>& k, const T* qd)
 {
     const T dt = k.dt;
     const T (&Th)[9] = k.Th;
     T Xn[9], Gm[9];
+    if constexpr (PackedMath<T, N>::on && (PK & 4)) {
+        // columns ba and g of rows theta, two neighbouring columns at a time where the storage holds them as a pair in all the
+        // rows read (columns (10,11) of rows theta; (16,17) of rows theta and bg)
+#pragma unroll
+        for (int c = 9; c < N; ++c) {
+            if (c >= 12 && c < 15) continue;
+            if ((c & 1) && th_pair_cols<N>(c - 1)) continue;                 // done with its left neighbour
+            if (th_pair_cols<N>(c)) {
+                const f32x2 o0 = ld_pair<N>(P, 6, c), o1 = ld_pair<N>(P, 7, c), o2 = ld_pair<N>(P, 8, c);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    f32x2 r = Th[3 * i] * o0 + Th[3 * i + 1] * o1 + Th[3 * i + 2] * o2;
+                    if (is_pair<N>(12 + i, c)) r -= dt * ld_pair<N>(P, 12 + i, c);
+                    else { r.x -= dt * PS(12 + i, c); r.y -= dt * PS(12 + i, c + 1); }
+                    st_pair<N>(P, 6 + i, c, r);
+                }
+            } else {
+                const T o0 = PS(6, c), o1 = PS(7, c), o2 = PS(8, c);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    PS(6 + i, c) = Th[3 * i] * o0 + Th[3 * i + 1] * o1 + Th[3 * i + 2] * o2 - dt * PS(12 + i, c);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // Theta P(theta,theta) and Theta P(theta,bg) - dt P(bg,bg): rows (0, 1) of Theta on the halves, row 2 alone
+        f32x2 T01[3];
+        coef_rows(Th, 0, 1, T01);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x2 g01 = T01[0] * PS(6, 6 + j) + T01[1] * PS(7, 6 + j) + T01[2] * PS(8, 6 + j);
+            Gm[j] = g01.x; Gm[3 + j] = g01.y;
+            Gm[6 + j] = Th[6] * PS(6, 6 + j) + Th[7] * PS(7, 6 + j) + Th[8] * PS(8, 6 + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x2 x01 = T01[0] * PS(6, 12 + j) + T01[1] * PS(7, 12 + j) + T01[2] * PS(8, 12 + j);
+            Xn[j] = x01.x - dt * PS(12, 12 + j); Xn[3 + j] = x01.y - dt * PS(13, 12 + j);
+            Xn[6 + j] = Th[6] * PS(6, 12 + j) + Th[7] * PS(7, 12 + j) + Th[8] * PS(8, 12 + j) - dt * PS(14, 12 + j);
+        }
+    } else {
 #pragma unroll
     for (int c = 9; c < N; ++c) {
         if (c >= 12 && c < 15) continue;
@@ -590,6 +732,7 @@ __device__ __forceinline__ void cov_stage_th(T* P, const PredictCoef<T>& k, cons
         for (int j = 0; j < 3; ++j)
             Xn[3 * i + j] = Th[3 * i] * PS(6, 12 + j) + Th[3 * i + 1] * PS(7, 12 + j) + Th[3 * i + 2] * PS(8, 12 + j)
                           - dt * PS(12 + i, 12 + j);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -608,7 +751,7 @@ __device__ __forceinline__ void cov_stage_th(T* P, const PredictCoef<T>& k, cons
 
 // Nominal part of one ImuUpdate: nom = the 28 nominal + rotation elements (record order).  Fills the coefficient
 // blocks from the PRE-step (carried) rotation (filter.cpp:510 runs UpdateCovariance before UpdateNominalState).
-template <typename T, int N, int DIALECT>
+template <typename T, int N, int DIALECT, int PK = FBUS_X_PACK>
 __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T* gyro, T dt, PredictCoef<T>& k)
 {
     using L = Lay<N>;
@@ -636,6 +779,58 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
     }
 
     // ---- rotation increments (kept small: n, sin/cos) and F(theta,theta) ----------
+    T qT[4], R0[9], RT[9], kv2[3], kv4[3];
+    if constexpr (sizeof(T) == 4 && (PK & 1)) {
+        // fp32: the full increment (T) and the half one (H) are the same operations on two angles -- sin/cos polynomials, quaternion
+        // product, rotation matrix, acceleration in the world frame -- and run as the halves of register pairs
+        T n[3];
+        f32x2 s24, c24;                                             // (s2, s4), (c2, c4)
+        bool small_rate = false;
+        if (DIALECT == DIALECT_MATLAB) {
+            n[0] = w[0] * iwn; n[1] = w[1] * iwn; n[2] = w[2] * iwn;
+            const T dth = wn * fb_abs(dt);
+            fb_sincos_x_halfx_pk(dth * T(0.5), s24, c24);
+            const T s2 = s24.x, c2 = c24.x;
+            const T sa = (dt < T(0) ? -T(2) : T(2)) * s2 * c2, sb = T(2) * s2 * s2;
+            Th[0] = T(1) - sb + sb * n[0] * n[0]; Th[1] = sb * n[0] * n[1] + sa * n[2]; Th[2] = sb * n[0] * n[2] - sa * n[1];
+            Th[3] = sb * n[1] * n[0] - sa * n[2]; Th[4] = T(1) - sb + sb * n[1] * n[1]; Th[5] = sb * n[1] * n[2] + sa * n[0];
+            Th[6] = sb * n[2] * n[0] + sa * n[1]; Th[7] = sb * n[2] * n[1] - sa * n[0]; Th[8] = T(1) - sb + sb * n[2] * n[2];
+        } else {
+            small_rate = !(wn > T(10e-5));
+            const T inv = small_rate ? T(0) : iwn;
+            n[0] = w[0] * inv; n[1] = w[1] * inv; n[2] = w[2] * inv;
+            fb_sincos_x_halfx_pk(wn * dt * T(0.5), s24, c24);
+            Th[0] = T(1);        Th[1] = w[2] * dt;   Th[2] = -w[1] * dt;
+            Th[3] = -w[2] * dt;  Th[4] = T(1);        Th[5] = w[0] * dt;
+            Th[6] = w[1] * dt;   Th[7] = -w[0] * dt;  Th[8] = T(1);
+        }
+        f32x2 dq[4], qq[4], RR[9];
+        if (DIALECT == DIALECT_MATLAB || !small_rate) {
+            dq[0] = c24; dq[1] = n[0] * s24; dq[2] = n[1] * s24; dq[3] = n[2] * s24;
+        } else {                                                    // filter.cpp:553-560
+            const f32x2 hq = { T(0.5), T(0.25) };
+            dq[0] = f32x2{ T(1), T(1) }; dq[1] = hq * dt * w[0]; dq[2] = hq * dt * w[1]; dq[3] = hq * dt * w[2];
+        }
+        quat_mul_pk(q, dq, qq);
+        if (DIALECT == DIALECT_MATLAB) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R0[i] = R[i];             // carried, possibly stale (:46)
+            quat_to_rotmat_m_pk(qq, RR);
+        } else {
+            quat_to_rotmat_e(q, R0);                               // fresh (filter.cpp:542)
+            quat_normalize_pk(qq);
+            quat_to_rotmat_e_pk(qq, RR);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x2 kv = RR[3 * i] * a[0] + RR[3 * i + 1] * a[1] + RR[3 * i + 2] * a[2] + g[i];
+            kv4[i] = kv.x; kv2[i] = kv.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qT[i] = qq[i].x;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) RT[i] = RR[i].x;
+    } else {
     T n[3], s2, c2, s4, c4;
     bool small_rate = false;
     if (DIALECT == DIALECT_MATLAB) {
@@ -663,7 +858,7 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
     }
 
     // ---- quaternion, velocity, position   ImuUpdate.m:42-60 ; filter.cpp:539-581 -----
-    T qT[4], qH[4], R0[9], RH[9], RT[9];
+    T qH[4], RH[9];
     if (DIALECT == DIALECT_MATLAB) {
         const T dqT[4] = { c2, n[0] * s2, n[1] * s2, n[2] * s2 };
         const T dqH[4] = { c4, n[0] * s4, n[1] * s4, n[2] * s4 };
@@ -690,17 +885,21 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
         quat_to_rotmat_e(qH, RH);
         quat_to_rotmat_e(qT, RT);
     }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        kv2[i] = RH[3 * i] * a[0] + RH[3 * i + 1] * a[1] + RH[3 * i + 2] * a[2] + g[i];
+        kv4[i] = RT[3 * i] * a[0] + RT[3 * i + 1] * a[1] + RT[3 * i + 2] * a[2] + g[i];
+    }
+    }
     // RK4-style   ImuUpdate.m:49-60 ; filter.cpp:567-581  (dt / 6: fp32 multiplies by the rounded 1/6 -- 1 ulp, no division sequence)
     const T dt6 = (sizeof(T) == 4) ? dt * T(1.0 / 6.0) : dt / 6;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T kv1 = R0[3 * i] * a[0] + R0[3 * i + 1] * a[1] + R0[3 * i + 2] * a[2] + g[i];
-        const T kv2 = RH[3 * i] * a[0] + RH[3 * i + 1] * a[1] + RH[3 * i + 2] * a[2] + g[i];
-        const T kv4 = RT[3 * i] * a[0] + RT[3 * i + 1] * a[1] + RT[3 * i + 2] * a[2] + g[i];
-        const T kv3 = kv2;
+        const T kv3 = kv2[i];
         const T v0 = v[i];
-        v[i] = v0 + dt6 * (kv1 + 2 * kv2 + 2 * kv3 + kv4);
-        const T kp2 = v0 + kv1 * dt / 2, kp3 = v0 + kv2 * dt / 2, kp4 = v0 + kv3 * dt / 2;   // dt/2 sic
+        v[i] = v0 + dt6 * (kv1 + 2 * kv2[i] + 2 * kv3 + kv4[i]);
+        const T kp2 = v0 + kv1 * dt / 2, kp3 = v0 + kv2[i] * dt / 2, kp4 = v0 + kv3 * dt / 2;   // dt/2 sic
         p[i] = p[i] + dt6 * (v0 + 2 * kp2 + 2 * kp3 + kp4);
     }
     if (DIALECT == DIALECT_MATLAB) quat_normalize(qT);               // ImuUpdate.m:76
@@ -711,14 +910,14 @@ __device__ __forceinline__ void predict_nominal(T* nom, const T* accel, const T*
 }
 
 // One ImuUpdate with everything resident: nom = the 28 nominal + rotation elements, P = packed covariance.
-template <typename T, int N, int DIALECT>
+template <typename T, int N, int DIALECT, int PK = FBUS_X_PACK>
 __device__ __forceinline__ void predict_step(T* nom, T* P, const T* accel, const T* gyro, T dt, const T* qd)
 {
     PredictCoef<T> k;
-    predict_nominal<T, N, DIALECT>(nom, accel, gyro, dt, k);
-    cov_stage_p<T, N>(P, k);
-    cov_stage_v<T, N>(P, k, qd);
-    cov_stage_th<T, N>(P, k, qd);
+    predict_nominal<T, N, DIALECT, PK>(nom, accel, gyro, dt, k);
+    cov_stage_p<T, N, PK>(P, k);
+    cov_stage_v<T, N, PK>(P, k, qd);
+    cov_stage_th<T, N, PK>(P, k, qd);
 }
 
 // ================================================================================

@@ -414,7 +414,7 @@ struct StepPark {
 
 // K ImuUpdates with the record resident in registers (predict_n, fused frame)
 struct NoMidHook { __device__ __forceinline__ void operator()() const {} };
-template <typename T, int N, int DIALECT, typename MID = NoMidHook, typename PARK = NoStepPark>
+template <typename T, int N, int DIALECT, typename MID = NoMidHook, typename PARK = NoStepPark, int PK = FBUS_X_PACK>
 __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* accel, const T* gyro, const T* dt, int dt_stride,
                                               int B, int b, const T* qd, const MID& mid_last = MID(), const PARK& park = PARK())
 {
@@ -433,17 +433,21 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
     for (int k = 0; k < K; ++k) {
         PredictCoef<T> c;
         if constexpr (PARKED) { park.nom_in(nom); }
-        predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, c);
+        predict_nominal<T, N, DIALECT, PK>(nom, cur.a, cur.w, cur.h, c);
         if constexpr (PARKED) { park.nom_out(nom); }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef FBUS_X_IMU_ONCE      // experiment: every step on the first sample -- no memory access inside the loop (what does the sample's latency cost?)
+        if (k + 1 >= K) mid_last();
+#else
         if (k + 1 < K) cur.load(accel, gyro, dt, dt_stride, k + 1, B, b);
         else mid_last();                           // last step: the caller's loads for what follows the predicts
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PARKED) { park.rows_in(P); }
-        cov_stage_p<T, N>(P, c);
+        cov_stage_p<T, N, PK>(P, c);
         if constexpr (PARKED) { park.rows_out(P); __builtin_amdgcn_sched_barrier(0); }
-        cov_stage_v<T, N>(P, c, qd);
-        cov_stage_th<T, N>(P, c, qd);
+        cov_stage_v<T, N, PK>(P, c, qd);
+        cov_stage_th<T, N, PK>(P, c, qd);
         if constexpr (PARKED) { __builtin_amdgcn_sched_barrier(0); }
     }
     if constexpr (PARKED) { park.rows_in(P); park.nom_in(nom); }
@@ -453,7 +457,7 @@ __device__ __forceinline__ void predict_steps(T* nom, T* P, int K, const T* acce
         const T a[3] = { ld_once(accel + o), ld_once(accel + o + 1), ld_once(accel + o + 2) };
         const T w[3] = { ld_once(gyro + o), ld_once(gyro + o + 1), ld_once(gyro + o + 2) };
         const T h = dt_stride ? ld_once(dt + (size_t)k * B + b) : dt[k];
-        predict_step<T, N, DIALECT>(nom, P, a, w, h, qd);
+        predict_step<T, N, DIALECT, PK>(nom, P, a, w, h, qd);
     }
     mid_last();
 #endif
@@ -1069,7 +1073,7 @@ frame2_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, c
     const T* my_pos = pos + (size_t)b * M * 3;
     const T* my_quat = quat + (size_t)b * M * 4;
     const Park park{ lds_mem + threadIdx.x };
-    predict_steps<T, N, DIALECT, NoMidHook, Park>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd, NoMidHook(), park);
+    predict_steps<T, N, DIALECT, NoMidHook, Park, FBUS_X_PACK_2W>(nom, P, K, accel, gyro, dt, dt_stride, B, b, dc.qd, NoMidHook(), park);
     order_fence();
     // the late rows are final as predicted: out to the record now (they return from L2 for joint_apply_late)
     constexpr int E_END = cov_final_before_row<N>(RS);

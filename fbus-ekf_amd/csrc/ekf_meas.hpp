@@ -1617,7 +1617,7 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
     {
         // K ImuUpdates; under the covariance stages of the last one the first marker's image points are requested
         auto first_marker = [&]() __attribute__((always_inline)) { if (M > 0) fetch(0, cur); };
-        predict_steps<T, N, DIALECT>(nom, P, K, accel + (size_t)k0 * B * 3, gyro + (size_t)k0 * B * 3, dt + (size_t)k0 * (dt_stride ? B : 1),
+        predict_steps<T, N, DIALECT, decltype(first_marker), NoStepPark, FBUS_X_PACK_FMEAS>(nom, P, K, accel + (size_t)k0 * B * 3, gyro + (size_t)k0 * B * 3, dt + (size_t)k0 * (dt_stride ? B : 1),
                                      dt_stride, B, b, qd.qd, first_marker);
         k0 += K;
         order_fence();

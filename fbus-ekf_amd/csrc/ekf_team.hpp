@@ -196,7 +196,7 @@ predict_team_kernel(T* __restrict__ recs, int B, const T* __restrict__ accel, co
         constexpr int JOBS = decltype(jobs_)::value;
         load_stage_chunks<T, N, job_stage_mask(JOBS), LD>(rs, lane, P);
         PredictCoef<T> k;
-        predict_nominal<T, N, DIALECT>(nom, a, w, h, k);
+        predict_nominal<T, N, DIALECT, FBUS_X_PACK_TEAM>(nom, a, w, h, k);
         // "No exchange" does not mean "no ordering": a stage reads the PRE-step values of rows another role owns, so no role may
         // store before every role's loads have landed.  One barrier behind the loads (vmcnt(0): the data is in registers);
         // without it the kernel was right at 4096 / 16 384 filters and wrong at 32 768 (block-wise covariance error 3e-2:
@@ -207,17 +207,17 @@ predict_team_kernel(T* __restrict__ recs, int B, const T* __restrict__ accel, co
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr ((JOBS & JOB_P) != 0) {
-            cov_stage_p<T, N>(P, k);
+            cov_stage_p<T, N, FBUS_X_PACK_TEAM>(P, k);
             if (live) store_stage<T, N, 0, ST>(rs, lane, P);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr ((JOBS & JOB_V) != 0) {
-            cov_stage_v<T, N>(P, k, dc.qd);
+            cov_stage_v<T, N, FBUS_X_PACK_TEAM>(P, k, dc.qd);
             if (live) store_stage<T, N, 1, ST>(rs, lane, P);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr ((JOBS & JOB_TH) != 0) {
-            cov_stage_th<T, N>(P, k, dc.qd);
+            cov_stage_th<T, N, FBUS_X_PACK_TEAM>(P, k, dc.qd);
             if (live) store_stage<T, N, 2, ST>(rs, lane, P);
         }
     };
@@ -289,7 +289,7 @@ struct StepXch {
     __device__ __forceinline__ void step_theta(T* P, PredictCoef<T>& k, const T* qd, int t, int K) const
     {
         get_coef((t - 1) & 1, k);
-        cov_stage_th<T, N>(P, k, qd);
+        cov_stage_th<T, N, FBUS_X_PACK_TEAM>(P, k, qd);
         if (t < K) {
 #pragma unroll
             for (int q = 0; q < QT; ++q) put4(t & 1, QC + QVX + q, P + E_T0 + 4 * q);
@@ -317,7 +317,7 @@ struct StepXch {
 #pragma unroll
             for (int i = 9; i < 12; ++i) P[pidx<N>(i, i)] += qd[2];
         }
-        cov_stage_v<T, N>(P, k, qd);
+        cov_stage_v<T, N, FBUS_X_PACK_TEAM>(P, k, qd);
         if (t < K) {
 #pragma unroll
             for (int q = 0; q < QV; ++q) put4(t & 1, QC + q, P + E_V0 + 4 * q);
@@ -340,7 +340,7 @@ struct StepXch {
             }
             if constexpr (DIAG_APART) { T d[4]; get4((t - 1) & 1, QC + QV, d); P[pidx<N>(3, 3)] = d[0]; P[pidx<N>(5, 5)] = d[1]; }
         }
-        cov_stage_p<T, N>(P, k);
+        cov_stage_p<T, N, FBUS_X_PACK_TEAM>(P, k);
     }
 };
 
@@ -371,7 +371,7 @@ predict_n_team_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ 
 #pragma unroll 1
         for (int t = 0; t <= K; ++t) {
             if (t < K) {
-                predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, k);
+                predict_nominal<T, N, DIALECT, FBUS_X_PACK_TEAM>(nom, cur.a, cur.w, cur.h, k);
                 if (t + 1 < K) cur.load(accel, gyro, dt, dt_stride, t + 1, B, b);
                 xch.put_coef(t & 1, k);
             }
@@ -867,7 +867,7 @@ frames_team_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* 
 #pragma unroll 1
             for (int t = 0; t <= K; ++t) {
                 if (t < K) {
-                    predict_nominal<T, N, DIALECT>(nom, cur.a, cur.w, cur.h, k);
+                    predict_nominal<T, N, DIALECT, FBUS_X_PACK_TEAM>(nom, cur.a, cur.w, cur.h, k);
                     if (t + 1 < K) cur.load(fa, fg, fd, dt_stride, t + 1, B, b);
                     xch.put_coef(t & 1, k);
                 } else if (M > 0) {
