@@ -21,6 +21,8 @@ for n in Ns:
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
     d_acc, d_gyr, d_dt = f32(acc), f32(gyr), f32(np.full(KMAX, 0.005))
     with BatchedFilter(B, prm, dialect=dialect, nstate=n, order_streams=False) as flt:
+        if os.environ.get("TEAM_PREDICT"):
+            flt.set_team(int(os.environ["TEAM_PREDICT"]), 1)           # 1 = one-wave kernels, 2 = two roles (predict_n_duo), 4 = four
         flt.set_state(nom, rot, None, prev)
         flt.reset_cov()
         s = torch.cuda.Stream()
@@ -41,5 +43,5 @@ for n in Ns:
         ks, us = np.array([p[0] for p in pts], float), np.array([p[1] for p in pts])
         slope, icpt = np.polyfit(ks, us, 1)
         x = flt.get_state()
-        print(f"{os.path.basename(os.environ.get('FBUS_EKF_LIB', 'libfbus_ekf.so')):18s} N={n} dialect {dialect} B={B}: " +
+        print(f"{os.path.basename(os.environ.get('FBUS_EKF_LIB', 'libfbus_ekf.so')):18s} roles {os.environ.get('TEAM_PREDICT', 'auto')} N={n} dialect {dialect} B={B}: " +
               "  ".join(f"K={k}: {u:7.2f} us" for k, u in pts) + f"   step {slope:.3f} us  in/out {icpt:.2f} us  finite {bool(np.isfinite(x[0]).all())}", flush=True)
