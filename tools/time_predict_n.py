@@ -22,7 +22,7 @@ for n in Ns:
     d_acc, d_gyr, d_dt = f32(acc), f32(gyr), f32(np.full(KMAX, 0.005))
     with BatchedFilter(B, prm, dialect=dialect, nstate=n, order_streams=False) as flt:
         if os.environ.get("TEAM_PREDICT"):
-            flt.set_team(int(os.environ["TEAM_PREDICT"]), 1)           # 1 = one-wave kernels, 2 = two roles (predict_n_duo), 4 = four
+            flt.set_team(int(os.environ["TEAM_PREDICT"]), 1)           # 1 = one-wave kernels, 4 = four roles; 2 = the two-role predict_n of tools/patches/r05_predict_n_duo.diff (without the patch: four)
         flt.set_state(nom, rot, None, prev)
         flt.reset_cov()
         s = torch.cuda.Stream()
