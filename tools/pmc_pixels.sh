@@ -1,7 +1,8 @@
 #!/bin/bash
 # SQ counters of the compute-bound leg (correct_pixels, 16 marker slots, 65 536 filters): two rocprofv3 --pmc passes of
 # `bench.py --only-pixels` (the program itself after `--`), digest -> gpurun_out/pmc_pixels/r03_pixels_sq.json (copy to profiles/).
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"      # the GPU box exports GRAFT_REPO_ROOT; elsewhere: the script's repository
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 export OUT=gpurun_out/pmc_pixels
 mkdir -p $OUT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --only-pixels > $OUT/trace.log 2>&1

@@ -1,7 +1,8 @@
 #!/bin/bash
 # SQ counters of the resident ImuUpdate loop (predict_n, tools/time_predict_n.py) for several library builds:
 #   tools/pmc_predict_n.sh libA.so libB.so ...
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"      # the GPU box exports GRAFT_REPO_ROOT; elsewhere: the script's repository
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 mkdir -p gpurun_out/r05
 for v in "$@"; do
   export FBUS_EKF_LIB=$PWD/$v

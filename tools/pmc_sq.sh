@@ -1,7 +1,8 @@
 #!/bin/bash
 # SQ counter passes for the hot kernels (run on the GPU box via gpurun; the program itself after `--`).
 #   tools/pmc_sq.sh TAG ["extra bench.py arguments"]      e.g.  tools/pmc_sq.sh b262144 "--batch 262144"
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"      # the GPU box exports GRAFT_REPO_ROOT; elsewhere: the script's repository
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 TAG=${1:-a}
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-extra-legs --kernel-timing off ${2:-}"
 export OUT=gpurun_out/pmc_sq_$TAG

@@ -5,10 +5,11 @@
 #   tools/profile_gpu.sh r02_b65536  "--batch 65536 --steps 20 --warmup 5"
 #   tools/profile_gpu.sh r02_b262144 "--batch 262144 --steps 4 --warmup 1"
 #   tools/profile_gpu.sh r03_b1048576 "--batch 1048576 --tile 16 --steps 3 --warmup 1"     (839 MB of records: past the Infinity Cache)
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"      # the GPU box exports GRAFT_REPO_ROOT; elsewhere: the script's repository
 TAG=${1:-r02_b65536}
 ARGS=${2:-"--batch 65536 --steps 20 --warmup 5"}
 ARGS="$ARGS --no-cpu-baseline --no-hbm-leg --no-extra-legs"
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
