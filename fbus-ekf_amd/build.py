@@ -33,6 +33,11 @@ FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "frame": [], "frames": [],
                 "team": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "meas": os.environ.get("FBUS_MEAS_FLAGS", "").split(),
                 "fmeas": os.environ.get("FBUS_FMEAS_FLAGS", "").split(), "msplit": os.environ.get("FBUS_MSPLIT_FLAGS", "").split()}
+# fp64 units.  meas (correct_pixels2 / correct_corners2 <double>, 512 registers + scratch): the max-memory-clause strategy leaves them
+# 28-136 bytes of scratch instead of 136-340 and is 4-11 % faster (profiles/r05_f64_sched.txt); FBUS_F64_FLAGS_<FAMILY> overrides
+F64_FAMILY_FLAGS = {fam: os.environ.get("FBUS_F64_FLAGS_" + fam.upper(),
+                                        "-mllvm -amdgpu-sched-strategy=max-memory-clause" if fam == "meas" else "").split()
+                    for fam in ("predict", "correct", "frame", "meas")}
 TYPES = {"f32": "float", "f64": "double"}
 
 
@@ -54,7 +59,8 @@ def units():
                 out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
                             [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"] +
                             # fp32 only: the fp64 kernels sit at the 512-register limit and spill more under max-ILP
-                            ([] if (os.environ.get("FBUS_NO_FAMILY_FLAGS") or tn != "f32") else FAMILY_FLAGS[fam])))
+                            ([] if (os.environ.get("FBUS_NO_FAMILY_FLAGS") or tn != "f32") else FAMILY_FLAGS[fam]) +
+                            (F64_FAMILY_FLAGS.get(fam, []) if tn == "f64" else [])))
     return out
 
 
