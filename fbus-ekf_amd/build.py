@@ -30,7 +30,7 @@ FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "frames": 5, "team": 6, "mea
 # v_accvgpr traffic), which therefore keeps the default strategy.
 FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "correct": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-                "frame": [], "frames": [],
+                "frame": os.environ.get("FBUS_FRAME_FLAGS", "").split(), "frames": os.environ.get("FBUS_FRAMES_FLAGS", "").split(),
                 "team": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "meas": os.environ.get("FBUS_MEAS_FLAGS", "").split(),
                 "fmeas": os.environ.get("FBUS_FMEAS_FLAGS", "").split(), "msplit": os.environ.get("FBUS_MSPLIT_FLAGS", "").split()}
 # fp64 units.  meas (correct_pixels2 / correct_corners2 <double>, 512 registers + scratch): the max-memory-clause strategy leaves them
