@@ -22,7 +22,10 @@ in HBM before the timed region starts.
 relays their output and exits with their return code; it fails loudly when the box has fewer than N GPUs.
 Under a launcher, WORLD_SIZE must equal --gpus.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (predict): bytes the kernel MOVES per
+Prints ONE COMPACT JSON line (< 6 KB: `compact_line`) on rank 0 -- the contract's keys, `roofline`, `cpu_baseline`, one short block
+each for `fp64` and `north_star` -- and writes the FULL result (every leg described below) to `bench_detail.json` beside this file
+(`--detail-file`) and as one `bench_detail: {...}` line on stderr.  (Round 5 printed the full 20.7 KB object on stdout and the driver
+could not parse it.)  In the full result `roofline` is for the dominant kernel (predict): bytes the kernel MOVES per
 launch (1436 B per filter: 828 read, 608 written -- the predict-invariant covariance tail and ba/bg/g are not
 written back) / its average duration measured with HIP events on the launch stream inside the timed region;
 `achieved_api` prices SURVEY.md 8(d)'s full record round trip (1620 B) instead.  `roofline_hbm_resident` is the
@@ -90,6 +93,9 @@ def parse():
     ap.add_argument("--mode", choices=["stacked", "nearest"], default="stacked")
     ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail-file", default=None,
+                    help="where the FULL result goes (default: bench_detail.json beside bench.py and under gpurun_out/ when that exists); "
+                         "stdout carries the compact line only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1 048 576-filter (HBM-resident) and 262 144-filter roofline legs")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the fp64 leg and the correct_pixels (compute-bound) leg")
@@ -629,6 +635,104 @@ def emit(line):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
 
 
+LINE_LIMIT = 6144                   # the driver's parser lost round 5's 20.7 KB line: the stdout line stays below this
+DETAIL_FILE = "bench_detail.json"   # everything else, beside bench.py (and as one `bench_detail: ...` line on stderr)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _r(x, digits=5):
+    """floats to `digits` significant digits (the line carries numbers, not noise)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The ONE stdout line the driver parses, from the full result `out`: the contract's keys, `roofline` (dominant kernel, with the
+    HBM-resident leg folded in as `hbm_resident`), `cpu_baseline`, and one short block each for `fp64` and `north_star`.  Everything
+    else -- the other legs, per-row notes, launch policy -- is `bench_detail.json`.  Blocks are dropped from the end of `optional`
+    until the line fits LINE_LIMIT (never `roofline` / `cpu_baseline` / `config`)."""
+    head = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    line = {}
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "batch_per_gpu", "total_filters", "markers", "ekf_steps_per_bench_step", "parallelism"))
+    roof = out.get("roofline") or {}
+    r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us", "launches",
+                     "bytes_moved_per_launch", "achieved_api", "frac_api"))
+    hb = out.get("roofline_hbm_resident")
+    if hb:
+        r["hbm_resident"] = _pick(hb, ("batch", "frac", "achieved", "traffic", "avg_launch_us", "frac_of_copy_ceiling"))
+    line["roofline"] = r
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "value_1thread", "path")) if cb else None
+    optional = {}
+    if out.get("correct_kernel"):
+        optional["correct_kernel"] = _pick(out["correct_kernel"], ("kernel", "avg_launch_us", "frac"))
+    for k in ("fused_frame", "fused_window"):
+        if out.get(k):
+            optional[k] = _pick(out[k], ("value", "ms_per_step"))
+    f64 = out.get("fp64")
+    if f64:
+        optional["fp64"] = dict(_pick(f64, ("value", "ms_per_step")),
+                                predict_us=(f64.get("roofline") or {}).get("avg_launch_us"), frac=(f64.get("roofline") or {}).get("frac"),
+                                fused_frame=(f64.get("fused_frame") or {}).get("value"),
+                                fused_frame_pixels_m4=(f64.get("fused_frame_pixels_m4") or {}).get("value"))
+    ns = out.get("north_star_rows")
+    if ns:
+        blk = {}
+        for name in ("pixels_m4", "pixels_m4_stereo", "fused_frame_pixels_m4"):
+            c = ns.get(name)
+            if c:
+                blk[name] = dict(_pick(c, ("value", "ms_per_step")),
+                                 launch_us=c.get("update_avg_launch_us", c.get("frame_avg_launch_us")))
+        optional["north_star"] = blk
+    for k in ("gather_ms", "state_finite"):
+        if k in out:
+            optional[k] = out[k]
+    if out.get("legs_skipped"):
+        optional["legs_skipped"] = [s.split(":")[0] for s in out["legs_skipped"]]
+    optional["detail"] = DETAIL_FILE
+    line.update(optional)
+    line = dict(head, **_r(line))                     # value / ms_per_step at full precision (the driver cross-checks them)
+    text = json.dumps(line, separators=(",", ":"))
+    drop = [k for k in ("legs_skipped", "gather_ms", "correct_kernel", "fused_window", "fused_frame", "fp64", "north_star") if k in line]
+    while len(text) >= LINE_LIMIT and drop:
+        line.pop(drop.pop(0))
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:                       # free text is the only thing left that can be long
+        for blk, key in (("cpu_baseline", "path"), ("cpu_baseline", "sample"), ("config", "workload")):
+            if isinstance(line.get(blk), dict) and isinstance(line[blk].get(key), str):
+                line[blk][key] = line[blk][key][:200]
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit_result(out, detail_path=None):
+    """full result -> bench_detail.json (or --detail-file) + stderr; compact line -> stdout"""
+    detail = json.dumps(out)
+    for path in ([detail_path] if detail_path else [os.path.join(ROOT, DETAIL_FILE), os.path.join(ROOT, "gpurun_out", DETAIL_FILE)]):
+        try:
+            if os.path.isdir(os.path.dirname(os.path.abspath(path))):
+                with open(path, "w") as f:
+                    f.write(detail + "\n")
+        except OSError as e:
+            sys.stderr.write(f"bench.py: could not write {path}: {e}\n")
+    sys.stderr.write("bench_detail: " + detail + "\n")
+    sys.stderr.flush()
+    emit(compact_line(out))
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -874,7 +978,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        emit(json.dumps(out))
+        emit_result(out, args.detail_file)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -194,7 +194,12 @@ correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __res
             for (int i = 0; i < 6; ++i) co[(57 + i) * 64] = cf.m_[i];
             co[63 * 64] = apply ? T(1) : T(0);
         }
-        meas_barrier();                                                // (2) the coefficients are in LDS
+        // (2) the coefficients are in LDS.  (round 6, advisor) vmcnt(0) in front of it: the x_c chunks requested above (SEL_XL) are the
+        // very chunks the updater overwrites and stores behind this barrier (its J rows become G P(J, :)); a barrier that waits for LDS
+        // only would leave "this wave's loads are served before that wave's later stores" to the ~1.5 k instructions the updater runs
+        // first -- the class of failure ekf_team.hpp:200-204 documents.  The loads have been in flight since before the 64 LDS writes.
+        if constexpr (HAS_LATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        meas_barrier();
         if (b < B) applied[b] = apply ? 1 : 0;
         if constexpr (HAS_LATE) {
             if (apply) {

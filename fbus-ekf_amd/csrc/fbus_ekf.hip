@@ -1511,6 +1511,10 @@ int fbus_ekf_frame_meas_fused_dev(fbus_ekf_t h, int K, const void* accel, const 
         if (M > 0 && geometry != FBUS_VIS_CORNERS3D && !right) return FBUS_ERR_INVALID;
         if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     }
+    // (advisor, round 5) on every route, not only the resident one: the per-call updates behind the fall-back routes (fp64 records, team /
+    // split forms, K > 255) refuse unaligned image points AFTER the predicts have run
+    if (M > 0 && ((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right)) & 15) != 0)
+        return fail(h, FBUS_ERR_INVALID, "fbus_ekf_frame_meas_fused_dev: left / right must be 16-byte aligned device pointers");
     if (K > 255) {          // (the resident kernel counts a frame's samples in a byte)
         int rc = launch_predict(h, K, accel, gyro, dt, dt_per_filter);
         if (rc == FBUS_OK && M > 0)
@@ -1548,6 +1552,9 @@ int fbus_ekf_frames_meas_fused_dev(fbus_ekf_t h, int nframes, const int32_t* kco
         if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
     }
     if (nframes == 0) return FBUS_OK;
+    // every frame's arrays start a multiple of 16 bytes behind the first (B M x 32 / 48 bytes x element size): one check covers the window
+    if (M > 0 && ((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right)) & 15) != 0)
+        return fail(h, FBUS_ERR_INVALID, "fbus_ekf_frames_meas_fused_dev: left / right must be 16-byte aligned device pointers");
     // the resident window kernel where the frame form takes the resident kernel (fp32 records, one wave per tile); elsewhere frame by
     // frame through the frame entry point's routes -- the same arithmetic
     if (nframes > 1 && frame_meas_is_resident(h, kind, M, mode))

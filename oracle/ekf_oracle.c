@@ -760,8 +760,9 @@ static void store_state(const fbo_state* s, int n, double* nom, double* rot, dou
  * left camera frame (as fbo_correct_corners), pi = fbv_project_stereo.  H = (d pi / d X) [ -R_IL R' | R_IL [R'(c_w - p)]x ]
  * with d pi / d X by CENTRAL DIFFERENCES of the projection (deliberately not the analytic form the device uses).
  * All visible markers, one linearisation point, noise r_pix per row. */
-int fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_params, int M, const int* ids,
-                       const double* left /*M x 8*/, const double* right /*M x 8 or NULL*/, double size, double r_pix)
+static int correct_pixels_impl(fbo_state* s, const fbo_params* prm, const void* vision_params, int M, const int* ids,
+                               const double* left /*M x 8*/, const double* right /*M x 8 or NULL*/, double size, double r_pix,
+                               int analytic)
 {
     const fbv_params* vp = (const fbv_params*)vision_params;
     const int n = prm->nstate, rows_c = right ? 4 : 2;
@@ -801,10 +802,16 @@ int fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_p
                 }
             /* each camera on its own: a corner outside one camera's view still gives the other camera's rows */
             double uvL[2], uvR[2], Jp[4][3];
-            const int okL = fbv_project_camera(vp, X, 0, uvL);
-            const int okR = right ? fbv_project_camera(vp, X, 1, uvR) : 0;
+            int okL, okR;
+            if (analytic) {                 /* d pi / d X in closed form (vision_oracle.c::fbv_project_camera_jac) */
+                okL = fbv_project_camera_jac(vp, X, 0, uvL, (double*)Jp);
+                okR = right ? fbv_project_camera_jac(vp, X, 1, uvR, (double*)Jp + 6) : 0;
+            } else {
+                okL = fbv_project_camera(vp, X, 0, uvL);
+                okR = right ? fbv_project_camera(vp, X, 1, uvR) : 0;
+            }
             const double eps = 1e-6;
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < 3 && !analytic; ++c) {
                 double Xp[3] = { X[0], X[1], X[2] }, Xm[3] = { X[0], X[1], X[2] }, a[2], b[2];
                 Xp[c] += eps; Xm[c] -= eps;
                 if (okL) {
@@ -835,18 +842,48 @@ int fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_p
     return 1;
 }
 
-void fbo_correct_pixels_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
-                              const void* vision_params, int M, const int* ids, const double* left, const double* right,
-                              double size, double r_pix, int* applied)
+int fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_params, int M, const int* ids,
+                       const double* left, const double* right, double size, double r_pix)
+{
+    return correct_pixels_impl(s, prm, vision_params, M, ids, left, right, size, r_pix, 0);
+}
+
+/* The same update with d pi / d X in CLOSED FORM (round 6): the second, independent pixel oracle.  The central-difference one
+ * above carries the O(eps^2) + O(ulp / eps) error of its differences (1e-10 relative on the rows, up to 1e-7 on the posterior of
+ * a sharply observed state) -- what capped the fp64 device gates at 1e-6; this one is exact to rounding.  The two are
+ * cross-checked against each other on the CPU (tests/test_oracle_pixels_cpu.py). */
+int fbo_correct_pixels_analytic(fbo_state* s, const fbo_params* prm, const void* vision_params, int M, const int* ids,
+                                const double* left, const double* right, double size, double r_pix)
+{
+    return correct_pixels_impl(s, prm, vision_params, M, ids, left, right, size, r_pix, 1);
+}
+
+static void correct_pixels_batch_impl(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                                      const void* vision_params, int M, const int* ids, const double* left, const double* right,
+                                      double size, double r_pix, int* applied, int analytic)
 {
     const int n = prm->nstate;
     for (int b = 0; b < B; ++b) {
         fbo_state s;
         load_state(&s, n, nominal + (size_t)b * 19, rot + (size_t)b * 9, P + (size_t)b * n * n, prev[b]);
-        applied[b] = fbo_correct_pixels(&s, prm, vision_params, M, ids + (size_t)b * M, left + (size_t)b * M * 8,
-                                        right ? right + (size_t)b * M * 8 : NULL, size, r_pix);
+        applied[b] = correct_pixels_impl(&s, prm, vision_params, M, ids + (size_t)b * M, left + (size_t)b * M * 8,
+                                         right ? right + (size_t)b * M * 8 : NULL, size, r_pix, analytic);
         store_state(&s, n, nominal + (size_t)b * 19, rot + (size_t)b * 9, P + (size_t)b * n * n, prev + b);
     }
+}
+
+void fbo_correct_pixels_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                              const void* vision_params, int M, const int* ids, const double* left, const double* right,
+                              double size, double r_pix, int* applied)
+{
+    correct_pixels_batch_impl(B, nominal, rot, P, prev, prm, vision_params, M, ids, left, right, size, r_pix, applied, 0);
+}
+
+void fbo_correct_pixels_analytic_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                                       const void* vision_params, int M, const int* ids, const double* left, const double* right,
+                                       double size, double r_pix, int* applied)
+{
+    correct_pixels_batch_impl(B, nominal, rot, P, prev, prm, vision_params, M, ids, left, right, size, r_pix, applied, 1);
 }
 
 void fbo_correct_corners_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,

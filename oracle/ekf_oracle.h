@@ -134,6 +134,14 @@ int  fbo_correct_pixels(fbo_state* s, const fbo_params* prm, const void* vision_
 void fbo_correct_pixels_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
                               const void* vision_params, int M, const int* ids, const double* left, const double* right,
                               double size, double r_pix, int* applied);
+/* the same update with d pi / d X in closed form (vision_oracle.c::fbv_project_camera_jac, implicit-function theorem on the forward
+ * model) instead of central differences: the second, independent pixel oracle -- exact to rounding, what the fp64 kernels are held
+ * to at 1e-9.  Cross-checked against the central-difference one on the CPU. */
+int  fbo_correct_pixels_analytic(fbo_state* s, const fbo_params* prm, const void* vision_params, int M, const int* ids,
+                                 const double* left, const double* right, double size, double r_pix);
+void fbo_correct_pixels_analytic_batch(int B, double* nominal, double* rot, double* P, int* prev, const fbo_params* prm,
+                                       const void* vision_params, int M, const int* ids, const double* left, const double* right,
+                                       double size, double r_pix, int* applied);
 
 /* ---- init / reset / front door ---- */
 void fbo_init_gravity_bias(int T, const double* accel, const double* gyro, double g[3], double bg[3]);

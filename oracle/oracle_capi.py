@@ -85,6 +85,11 @@ def load(native=False):
     lib.fbo_predict.argtypes = [C.POINTER(FboState), C.POINTER(FboParams), dp, dp, C.c_double]
     lib.fbo_correct_pixels_batch.argtypes = [C.c_int, dp, dp, dp, ip, C.POINTER(FboParams), C.POINTER(FbvParams), C.c_int, ip,
                                              dp, dp, C.c_double, C.c_double, ip]
+    lib.fbo_correct_pixels_analytic_batch.argtypes = lib.fbo_correct_pixels_batch.argtypes
+    lib.fbv_project_camera_jac.argtypes = [C.POINTER(FbvParams), dp, C.c_int, dp, dp]
+    lib.fbv_project_camera_jac.restype = C.c_int
+    lib.fbv_project_camera.argtypes = [C.POINTER(FbvParams), dp, C.c_int, dp]
+    lib.fbv_project_camera.restype = C.c_int
     lib.fbv_project_stereo.argtypes = [C.POINTER(FbvParams), dp, dp, dp]
     lib.fbv_project_stereo.restype = C.c_int
     lib.fbv_refraction_project.argtypes = [C.POINTER(FbvParams), dp, dp]
@@ -212,9 +217,10 @@ class Oracle:
                                            _dp(corners), float(size), mode, _ip(applied))
         return applied
 
-    def correct_pixels(self, nominal, rot, P, prev, ids, left, right, size, r_pix, vision=None):
+    def correct_pixels(self, nominal, rot, P, prev, ids, left, right, size, r_pix, vision=None, analytic=False):
         """pixel-row model (no reference counterpart): left / right (B, M, 8) normalised corner image points, right may be
-        None (left camera only: 2 rows per corner)"""
+        None (left camera only: 2 rows per corner).  analytic: d pi / d X in closed form (fbo_correct_pixels_analytic) instead of
+        central differences"""
         B = nominal.shape[0]
         ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
         M = ids.shape[1]
@@ -222,9 +228,9 @@ class Oracle:
         right = None if right is None else np.ascontiguousarray(right, np.float64).reshape(B, M, 8)
         vp = vision if vision is not None else vision_params()
         applied = np.zeros(B, np.int32)
-        self.lib.fbo_correct_pixels_batch(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), C.byref(vp), M,
-                                          _ip(ids), _dp(left), None if right is None else _dp(right), float(size),
-                                          float(r_pix), _ip(applied))
+        fn = self.lib.fbo_correct_pixels_analytic_batch if analytic else self.lib.fbo_correct_pixels_batch
+        fn(B, _dp(nominal), _dp(rot), _dp(P), _ip(prev), C.byref(self.prm), C.byref(vp), M,
+           _ip(ids), _dp(left), None if right is None else _dp(right), float(size), float(r_pix), _ip(applied))
         return applied
 
     def schedule(self, nominal, rot, P, prev, Ks, reps, accel, gyro, dt, ids, pos, quat, mode=NEAREST):

@@ -358,6 +358,105 @@ int fbv_project_camera(const fbv_params* p, const double Xcam[3], int which, dou
     return fbv_refraction_project(p, XR, uv);
 }
 
+/* ------------------------------------------------------------------------------------------------------------
+ * ANALYTIC Jacobian of the forward projection (round 6: the second pixel oracle, beside the central-difference one of
+ * fbo_correct_pixels).  Written from the forward model above by the implicit-function theorem -- not from the device code:
+ *     F(t; z, rho) = L(t, z) - rho = 0,   L = d_air t + d_glass a0 s / cg + (z - d_air - d_glass) a1 s / cw   (lateral_offset)
+ *     dt = (d rho - L_z dz) / L_t,        L_z = a1 s / cw,   L_t = lateral_offset's dLdt
+ *     z = n . X,  lat = X - z n,  rho = |lat|:   dz = n' dX,   d rho = lat' dX / rho   (lat is orthogonal to n)
+ *     k = t / rho,  D = n + k lat:               dk = dt / rho - t d rho / rho^2,   dD = lat dk + k (I - n n') dX
+ *     uv = (D0, D1) / D2:                        d uv = [ dD0 - uv0 dD2, dD1 - uv1 dD2 ] / D2
+ * On the axis (rho -> 0) k tends to 1 / (d_air + d_glass a0 + z_w a1) and the lat dk term vanishes.
+ * The ray geometry is that of vision.cpp:505-552 run forward.  J = d uv / d Xp, 2 x 3 row-major. */
+int fbv_refraction_project_jac(const fbv_params* p, const double Xp[3], double uv[2], double J[6])
+{
+    if (!fbv_refraction_project(p, Xp, uv)) return 0;
+    const double* n = p->normal;
+    const double a0 = p->n_air / p->n_glass, a1 = p->n_air / p->n_water;
+    const double z = dot3(Xp, n), zw = z - p->d_air - p->d_glass;
+    const double lat[3] = { Xp[0] - z * n[0], Xp[1] - z * n[1], Xp[2] - z * n[2] };
+    const double rho = nrm3(lat);
+    double dD[9];                                   /* dD / dX, 3 x 3 */
+    double k;
+    if (rho > 1e-12 * (1 + fabs(z))) {
+        double t;
+        {   /* the scalar solve of fbv_refraction_project once more (cheap; keeps this function independent of how uv was formed) */
+            t = rho / z;
+            for (int it = 0; it < 60; ++it) {
+                double dL, L = lateral_offset(p, t, z, &dL);
+                double step = (L - rho) / dL;
+                t -= step;
+                if (t < 0) t = 0;
+                if (fabs(step) <= 1e-16 * (1 + t)) break;
+            }
+        }
+        double Lt;
+        (void)lateral_offset(p, t, z, &Lt);
+        const double s = t / sqrt(1 + t * t), cw = sqrt(1 - a1 * a1 * s * s);
+        const double Lz = a1 * s / cw;
+        k = t / rho;
+        for (int j = 0; j < 3; ++j) {
+            const double drho = lat[j] / rho, dz = n[j];
+            const double dt = (drho - Lz * dz) / Lt;
+            const double dk = dt / rho - t * drho / (rho * rho);
+            for (int i = 0; i < 3; ++i) dD[3 * i + j] = lat[i] * dk + k * ((i == j ? 1.0 : 0.0) - n[i] * n[j]);
+        }
+    } else {
+        k = 1.0 / (p->d_air + p->d_glass * a0 + zw * a1);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) dD[3 * i + j] = k * ((i == j ? 1.0 : 0.0) - n[i] * n[j]);
+    }
+    const double D2 = n[2] + k * lat[2];
+    for (int j = 0; j < 3; ++j) {
+        J[j] = (dD[j] - uv[0] * dD[6 + j]) / D2;
+        J[3 + j] = (dD[3 + j] - uv[1] * dD[6 + j]) / D2;
+    }
+    return 1;
+}
+
+/* as fbv_project_camera, with J = d uv / d Xcam (2 x 3): the chain through the axis flip (vision.cpp:597-599) and, for the right
+ * camera, the exact inverse of X_L = R_RL X_R + P_LR (vision.cpp:555-556) */
+int fbv_project_camera_jac(const fbv_params* p, const double Xcam[3], int which, double uv[2], double J[6])
+{
+    const double XL[3] = { -Xcam[0], -Xcam[1], Xcam[2] };
+    const double flip[3] = { -1.0, -1.0, 1.0 };
+    double Jp[6];
+    if (which == 0) {
+        if (!fbv_refraction_project_jac(p, XL, uv, Jp)) return 0;
+        for (int r = 0; r < 2; ++r)
+            for (int j = 0; j < 3; ++j) J[3 * r + j] = Jp[3 * r + j] * flip[j];
+        return 1;
+    }
+    double R_RL[9], tmp[3], P_LR[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += p->R_IL[3 * i + k] * p->R_IR[3 * j + k];
+            R_RL[3 * i + j] = acc;
+        }
+    m3v(R_RL, p->P_RI, tmp);
+    for (int i = 0; i < 3; ++i) P_LR[i] = p->P_LI[i] - tmp[i];
+    const double d[3] = { XL[0] - P_LR[0], XL[1] - P_LR[1], XL[2] - P_LR[2] };
+    const double c0[3] = { R_RL[0], R_RL[3], R_RL[6] }, c1[3] = { R_RL[1], R_RL[4], R_RL[7] }, c2[3] = { R_RL[2], R_RL[5], R_RL[8] };
+    const double det = det3cols(c0, c1, c2);
+    const double XR[3] = { det3cols(d, c1, c2) / det, det3cols(c0, d, c2) / det, det3cols(c0, c1, d) / det };
+    if (!fbv_refraction_project_jac(p, XR, uv, Jp)) return 0;
+    /* inverse of R_RL column by column (Cramer on the unit vectors): Ainv[:, j] = solve(R_RL, e_j) */
+    double Ainv[9];
+    for (int j = 0; j < 3; ++j) {
+        double e[3] = { 0, 0, 0 };
+        e[j] = 1.0;
+        Ainv[j] = det3cols(e, c1, c2) / det; Ainv[3 + j] = det3cols(c0, e, c2) / det; Ainv[6 + j] = det3cols(c0, c1, e) / det;
+    }
+    for (int r = 0; r < 2; ++r)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += Jp[3 * r + k] * Ainv[3 * k + j];
+            J[3 * r + j] = acc * flip[j];
+        }
+    return 1;
+}
+
 /* both cameras; returns 1 only if the point is in view of every camera asked for */
 int fbv_project_stereo(const fbv_params* p, const double Xcam[3], double uvL[2], double uvR[2])
 {

@@ -45,6 +45,9 @@ void fbv_marker_pose(const double corners[12], double pos[3], double quat[4], do
  * Return 0 if the point is behind the port. */
 int fbv_refraction_project(const fbv_params* p, const double Xp[3], double uv[2]);
 int fbv_project_camera(const fbv_params* p, const double Xcam[3], int which /* 0 left, 1 right */, double uv[2]);
+/* analytic Jacobians of the two projections above (J = d uv / d X, 2 x 3 row-major), from the implicit-function theorem */
+int fbv_refraction_project_jac(const fbv_params* p, const double Xp[3], double uv[2], double J[6]);
+int fbv_project_camera_jac(const fbv_params* p, const double Xcam[3], int which, double uv[2], double J[6]);
 int fbv_project_stereo(const fbv_params* p, const double Xcam[3], double uvL[2], double uvR[2] /* may be NULL */);
 
 #ifdef __cplusplus

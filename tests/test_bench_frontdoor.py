@@ -90,12 +90,23 @@ def test_ragged_gather_over_gloo():
 
 
 def _run_bench(extra, env):
-    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-leg", "--no-extra-legs"] + extra,
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and "\"metric\"" in l]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    """runs bench.py; checks the compact stdout line (the driver's view) and returns the FULL result (--detail-file)"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, "detail.json")
+        r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-leg", "--no-extra-legs",
+                            "--detail-file", detail] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{") and "\"metric\"" in l]
+        assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-2000:]
+        assert len(lines[0]) < 6144
+        line = json.loads(lines[0])
+        full = json.load(open(detail))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert line["config"]["workload"] == full["config"]["workload"] and "roofline" in line and "cpu_baseline" in line
+    assert line["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+    return full
 
 
 @pytest.mark.gpu

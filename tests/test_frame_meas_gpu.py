@@ -17,6 +17,8 @@ What is asserted:
     M = 0) give the per-call results too;
   * at the bench's size (65 536 filters): size-independent properties -- fused == per-call on a strided subset, symmetric positive
     definite posterior."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -172,26 +174,44 @@ def test_routes_that_do_not_take_the_fused_kernel():
                 assert np.array_equal(x, y)
 
 
-def test_rejected_calls_leave_the_state_alone():
+@pytest.mark.parametrize("route", ["resident", "auto_team", "fp64"])
+def test_rejected_calls_leave_the_state_alone(route):
+    """every argument is checked before the first launch on EVERY route (advisor, round 5: the alignment check used to sit in the
+    resident route only -- an fp64 handle and a small handle on the automatic team / split route ran the K predicts first)"""
     import torch
     B, M, K = 128, 2, 2
     prm, nom, rot, P, prev, ids, left, right = _scene(B, M, 0, 18, seed=5)
     acc, gyr = synth.imu_samples(0, B, 0, K, nom)
-    dd = _dev(torch, 32)
-    with BatchedFilter(B, prm) as flt:
-        flt.set_team(1, 1)
+    dtype = 64 if route == "fp64" else 32
+    dd = _dev(torch, dtype)
+    with BatchedFilter(B, prm, dtype=dtype) as flt:
+        if route == "resident":
+            flt.set_team(1, 1)
+        elif route == "auto_team":      # 2 tiles: the divided-tail / team forms, i.e. predict_n + the per-call update behind the entry point
+            assert flt.launch_info(capi.INFO_MEAS_SPLIT, M) > 0 or flt.launch_info(capi.INFO_ROLES_MEAS, M) > 1
         flt.set_state(nom, rot, P, prev)
         before = flt.get_state()
         lib, h = flt._lib, flt._h
         a, g, t, i, l = dd(acc), dd(gyr), dd(np.full(K, DT[0])), dd(ids), dd(left)
+        es = dtype // 8
         p = lambda x: x.data_ptr()
         assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, 7, M, p(i), p(l), None, 0, 1, None) == 4      # kind
         assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, capi.MEAS_CORNERS, M, p(i), p(l), None, 0, 1, None) == 1   # no right
-        assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, capi.MEAS_PIXELS, M, p(i), p(l) + 4, None, 0, 1, None) == 1   # alignment
+        assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, capi.MEAS_PIXELS, M, p(i), p(l) + es, None, 0, 1, None) == 1   # alignment
+        assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), p(g), p(t), 0, capi.MEAS_CORNERS, M, p(i), p(l), p(l) + es, 0, 1, None) == 1   # alignment (right)
         assert lib.fbus_ekf_frame_meas_fused_dev(h, K, p(a), None, p(t), 0, capi.MEAS_PIXELS, M, p(i), p(l), None, 0, 1, None) == 1
+        # the window entry point: two frames, image points one element off
+        kc = (ctypes.c_int32 * 2)(1, 1)
+        l2 = dd(np.concatenate([left, left]))
+        i2 = dd(np.concatenate([ids, ids]))
+        assert lib.fbus_ekf_frames_meas_fused_dev(h, 2, kc, p(a), p(g), p(t), 0, capi.MEAS_PIXELS, M, p(i2), p(l2) + es, None, 0, 1, None) == 1
         flt.sync()
         for x, y in zip(flt.get_state(), before):
             assert np.array_equal(x, y)
+        # and the aligned call goes through on the same handle
+        assert lib.fbus_ekf_frames_meas_fused_dev(h, 2, kc, p(a), p(g), p(t), 0, capi.MEAS_PIXELS, M, p(i2), p(l2), None, 0, 1, None) == 0
+        flt.sync()
+        assert not np.array_equal(flt.get_state()[0], before[0])
 
 
 def test_fused_frame_at_the_bench_size():

@@ -1,9 +1,13 @@
 """GPU suite: correct() from corner PIXELS -- the north star's "flat-port refractive stereo reprojection of ArUco corners,
 per-corner 2 x N Jacobians" (`fbus_ekf_correct_pixels`).  No reference counterpart: the reference has only the
 back-projection.  What pins it: the oracle's forward projection inverts the reference-pinned back-projection to 1e-12
-(tests/test_oracle_cpu.py); the oracle's Jacobian rows are CENTRAL DIFFERENCES of that projection while the device's are the
-closed form, so agreement of the two posteriors also checks the analytic d pi / d X; fp64 device == oracle to 1e-7 (the
-finite-difference error of the oracle's rows), fp32 within stated bounds."""
+(tests/test_oracle_cpu.py).  TWO oracles (round 6): `fbo_correct_pixels_analytic`, whose d pi / d X is the implicit-function-theorem
+closed form written from the forward model (oracle/vision_oracle.c::fbv_project_camera_jac) -- the fp64 kernels are held to it at
+1e-9 like every other fp64 kernel --, and `fbo_correct_pixels`, whose rows are CENTRAL DIFFERENCES of the projection (independent of
+any closed form; 1e-6 as in round 5: its own finite-difference error); the two are cross-checked on the CPU
+(tests/test_oracle_pixels_cpu.py).  fp32 within the standard single-step gates.  The covariance form: the kernels' one-shot update
+against the oracle's literal (I - K H) P AND against its Joseph form (I - K H) P (I - K H)' + K R K' (MeasureUpdate.m:101-102 is the
+simple form; north_star names Joseph)."""
 import numpy as np
 import pytest
 
@@ -33,44 +37,68 @@ def _scene(B, M, dialect, seed, noise=5e-4):
     return prm, nom, rot, r32(P), prev, ids, r32(left), r32(right)
 
 
+def _oracle_update(B, dialect, n, nom, rot, P, prev, ids, left, rgt, r_pix, skip=None, analytic=True, cov_form=oc.SIMPLE, vision=None):
+    eng = OracleEngine(B, dialect, n, cov_form=cov_form)
+    eng.set_state(nom, rot, P, prev)
+    keep = eng.get_state()
+    ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, rgt, SIZE, r_pix, vision=vision, analytic=analytic)
+    if skip is not None:
+        now = eng.get_state()
+        for x, y in zip(now, keep):
+            x[skip == 1] = y[skip == 1]
+        eng.set_state(*now)
+        ok[skip == 1] = 0
+    return eng.get_state(), ok
+
+
+F64_TOL = 1e-9          # every fp64 kernel against the oracle (tests/util.py); round 5 held the pixel rows to 1e-6 against the FD oracle
+
+
+@pytest.mark.parametrize("cov_form", [oc.SIMPLE, oc.JOSEPH])
 @pytest.mark.parametrize("stereo", [False, True])
 @pytest.mark.parametrize("dialect", [0, 1])
-def test_correct_pixels_matches_the_oracle(dialect, stereo):
+def test_correct_pixels_matches_the_oracle(dialect, stereo, cov_form, monkeypatch):
     B, M = 320, 4
     prm, nom, rot, P, prev, ids, left, right = _scene(B, M, dialect, seed=11 + dialect)
+    prm.cov_form = cov_form                                        # (selects nothing in the kernels: their one form meets both oracles)
     ids[0] = -1                                                    # nothing visible
     ids[1, :] = 9                                                  # only ids outside the map
     skip = (np.arange(B) % 11 == 5).astype(np.uint8)
     rgt = right if stereo else None
-    eng = OracleEngine(B, dialect, 18)
-    eng.set_state(nom, rot, P, prev)
-    keep = eng.get_state()
-    ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, rgt, SIZE, prm.r_pix)
-    now = eng.get_state()
-    for x, y in zip(now, keep):
-        x[skip == 1] = y[skip == 1]
-    eng.set_state(*now)
-    ok[skip == 1] = 0
-    assert ok[0] == 0 and ok[1] == 0 and ok[2:][skip[2:] == 0].all()
-    # at this batch size the default is the four-role form of correct_pixels2_kernel (the markers divided among four waves per tile,
-    # DESIGN.md 4.3); the one-wave kernel (set_team correct_roles = 1) and the two-role form go through the same gate
-    for dtype, roles in ((64, 0), (32, 0), (32, 1), (32, 2)):
+    want, ok = _oracle_update(B, dialect, 18, nom, rot, P, prev, ids, left, rgt, prm.r_pix, skip, analytic=True, cov_form=cov_form)
+    want_fd, ok_fd = _oracle_update(B, dialect, 18, nom, rot, P, prev, ids, left, rgt, prm.r_pix, skip, analytic=False, cov_form=cov_form)
+    assert ok[0] == 0 and ok[1] == 0 and ok[2:][skip[2:] == 0].all() and np.array_equal(ok, ok_fd)
+    # at this batch size the default is the divided-tail kernel (correct_pixels_split_kernel, csrc/ekf_meas_split.hpp: a solver wave and
+    # an updater wave per tile; fp32, square port); the one-wave kernel (set_team correct_roles = 1), and -- with FBUS_MEAS_SPLIT=0, read
+    # at fbus_ekf_create -- the two- and four-role forms of correct_pixels2_kernel (the markers divided among the waves of a tile, one
+    # tail) go through the same gate
+    for dtype, roles, split in ((64, 0, None), (32, 0, None), (32, 1, None), (32, 2, None), (32, 2, "0"), (32, 0, "0")):
+        if split is not None:
+            monkeypatch.setenv("FBUS_MEAS_SPLIT", split)
+        else:
+            monkeypatch.delenv("FBUS_MEAS_SPLIT", raising=False)
         with BatchedFilter(B, prm, dtype=dtype) as flt:
             flt.set_team(0, roles)
+            if split == "0":
+                assert flt.launch_info(capi.INFO_MEAS_SPLIT, M) == 0 and flt.launch_info(capi.INFO_ROLES_MEAS, M) > 1
             flt.set_state(nom, rot, P, prev)
             flt.correct_pixels(ids, left, rgt, skip)
             got = flt.get_state()
             assert (flt.applied() == ok).all()
         untouched = ok == 0
         assert np.array_equal(got[0][untouched], nom[untouched].astype(got[0].dtype))
-        e = parity_errors(got, eng.get_state())
-        print(f"[parity] correct_pixels dialect {dialect} {'stereo' if stereo else 'left'} fp{dtype} correct_roles {roles}: literal {e['literal']:.2e} "
+        e = parity_errors(got, want)
+        form = "Joseph" if cov_form == oc.JOSEPH else "simple"
+        print(f"[parity] correct_pixels dialect {dialect} {'stereo' if stereo else 'left'} fp{dtype} correct_roles {roles}"
+              f"{' one-tail' if split == '0' else ''} vs {form}-form oracle: literal {e['literal']:.2e} "
               f"sigma-aware {e['sigma']:.2e} ({e['sigma_block']}) plain {e['plain']:.2e} ({e['plain_block']}) cov {e['cov']:.2e} "
               f"cov block-wise {e['cov_block']:.2e}")
         if dtype == 64:
-            # the oracle's rows are central differences (eps = 1e-6 m) of its projection: ~1e-9 relative on H, times the
-            # gain of 32-64 rows at r_pix = 1e-6
-            assert e["literal"] < 1e-6 and e["sigma"] < 1e-6 and e["cov_block"] < 1e-6 and e["asym"] == 0
+            assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["cov"] < F64_TOL and e["cov_block"] < F64_TOL and e["asym"] == 0
+            # and the independent central-difference oracle, to its own error (eps = 1e-6 m: ~1e-9 relative on H, times the gain of
+            # 32-64 rows at r_pix = 1e-6)
+            f = parity_errors(got, want_fd)
+            assert f["literal"] < 1e-6 and f["sigma"] < 1e-6 and f["cov_block"] < 1e-6
         else:
             # (round 4) the single-step gates of every other parity test, un-widened: literal and sigma-aware 1e-5, plain 2e-4,
             # covariance 1e-4 max-norm and 1e-5 block-wise.  32-64 rows at sigma_pix = 1e-3 carry ~50x the information of a marker
@@ -112,7 +140,8 @@ def test_the_fifteen_state_filter_takes_the_same_updates():
         if what == "corners":
             ok = eng.orc.correct_corners(eng.nominal, eng.rot, eng.P, eng.prev, ids, corners, SIZE, capi.MODE_STACKED)
         else:
-            ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, right if "stereo" in what else None, SIZE, prm.r_pix)
+            ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, right if "stereo" in what else None, SIZE, prm.r_pix,
+                                        analytic=True)
         assert ok.all()
         for dtype in (64, 32):
             with BatchedFilter(B, prm, dtype=dtype, nstate=n) as flt:
@@ -126,7 +155,7 @@ def test_the_fifteen_state_filter_takes_the_same_updates():
             e = parity_errors(got, eng.get_state())
             print(f"[parity] N = 15, {what} fp{dtype}: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} cov block-wise {e['cov_block']:.2e}")
             if dtype == 64:
-                assert e["literal"] < 1e-6 and e["sigma"] < 1e-6 and e["cov_block"] < 1e-6 and e["asym"] == 0
+                assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["cov_block"] < F64_TOL and e["asym"] == 0
             else:
                 assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL
                 assert e["cov"] <= COV_TOL and e["cov_block"] <= COV_BLOCK_TOL and e["asym"] == 0
@@ -154,7 +183,7 @@ def test_tilted_port_takes_the_general_normal_path():
         rgt = right if stereo else None
         eng = OracleEngine(B, dialect, 18)
         eng.set_state(nom, rot, P, prev)
-        ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, rgt, SIZE, prm.r_pix, vision=vp)
+        ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, rgt, SIZE, prm.r_pix, vision=vp, analytic=True)
         assert ok.all()
         for dtype in (64, 32):
             with BatchedFilter(B, prm, dtype=dtype) as flt:
@@ -166,7 +195,7 @@ def test_tilted_port_takes_the_general_normal_path():
             print(f"[parity] tilted port, correct_pixels {'stereo' if stereo else 'left'} fp{dtype}: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} "
                   f"cov block-wise {e['cov_block']:.2e}")
             if dtype == 64:
-                assert e["literal"] < 1e-6 and e["sigma"] < 1e-6 and e["cov_block"] < 1e-6
+                assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["cov_block"] < F64_TOL
             else:
                 assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL
     # the corner-row update triangulates through the same port (general form of tri_corners_refractive)
