@@ -59,14 +59,33 @@ def units():
                 out.append((f"{tn}_{n}_{fam}", os.path.join(CSRC, "kernels_tu.hip"),
                             [f"-DFBUS_TU_T={t}", f"-DFBUS_TU_N={n}", f"-DFBUS_TU_FAMILY={code}"] +
                             # fp32 only: the fp64 kernels sit at the 512-register limit and spill more under max-ILP
+                            # FBUS_NO_FAMILY_FLAGS: the flag-free A/B baseline -- for BOTH record types (advisor, round 5)
                             ([] if (os.environ.get("FBUS_NO_FAMILY_FLAGS") or tn != "f32") else FAMILY_FLAGS[fam]) +
-                            (F64_FAMILY_FLAGS.get(fam, []) if tn == "f64" else [])))
+                            (F64_FAMILY_FLAGS.get(fam, []) if (tn == "f64" and not os.environ.get("FBUS_NO_FAMILY_FLAGS")) else [])))
     return out
 
 
-def _stale(obj, src):
+def _base_flags():
+    # -fno-slp-vectorize: the SLP pass packs the unrolled scalar FMAs into v_pk_fma_f32 and pays for it with
+    # ~1.9x more instructions (v_mov / v_accvgpr shuffles to form register pairs) -- measured on the .s
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"] + os.environ.get("FBUS_EXTRA_FLAGS", "").split()
+
+
+def _flags_of(defs):
+    """the flag string an object was / would be compiled with: written next to the object (<obj>.flags) so that a flag change made
+    through the environment (FBUS_EXTRA_FLAGS, FBUS_*_FLAGS, FBUS_NO_FAMILY_FLAGS) invalidates it -- mtimes alone do not"""
+    return " ".join(_base_flags() + list(defs))
+
+
+def _stale(obj, src, defs=None):
     if not os.path.exists(obj):
         return True
+    if defs is not None:
+        try:
+            if open(obj + ".flags").read() != _flags_of(defs):
+                return True
+        except OSError:
+            return True
     t = os.path.getmtime(obj)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in [src, os.path.abspath(__file__)] + HEADERS)
 
@@ -80,7 +99,7 @@ def needs_build():
     if any(os.path.exists(d) and os.path.getmtime(d) > t for d in srcs):
         return True
     # a partial rebuild (--only) links a library that is newer than every source while other objects are still stale
-    return os.path.isdir(OBJDIR) and any(_stale(os.path.join(OBJDIR, name + ".o"), src) for name, src, _ in units()
+    return os.path.isdir(OBJDIR) and any(_stale(os.path.join(OBJDIR, name + ".o"), src, defs) for name, src, defs in units()
                                          if os.path.exists(os.path.join(OBJDIR, name + ".o")))
 
 
@@ -89,17 +108,14 @@ def build(force=False, verbose=False, only=None, jobs=None):
         return OUT
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    # -fno-slp-vectorize: the SLP pass packs the unrolled scalar FMAs into v_pk_fma_f32 and pays for it with
-    # ~1.9x more instructions (v_mov / v_accvgpr shuffles to form register pairs) -- measured on the .s
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"] + \
-        os.environ.get("FBUS_EXTRA_FLAGS", "").split()
+    flags = _base_flags()
     todo = []
     for name, src, defs in units():
         obj = os.path.join(OBJDIR, name + ".o")
         if only and not any(o in name for o in only) and os.path.exists(obj):
             continue
-        if force or _stale(obj, src) or (only and any(o in name for o in only)):
-            todo.append((name, [hipcc()] + flags + defs + ["-c", src, "-o", obj]))
+        if force or _stale(obj, src, defs) or (only and any(o in name for o in only)):
+            todo.append((name, [hipcc()] + flags + defs + ["-c", src, "-o", obj], obj, _flags_of(defs)))
     # the fp64 / fused-frame units take longest: start them first
     todo.sort(key=lambda u: (("f64" in u[0]) * 2 + ("frame" in u[0]) + ("correct" in u[0])), reverse=True)  # "frame" matches "frames" too
     jobs = jobs or int(os.environ.get("FBUS_JOBS", "0")) or min(8, os.cpu_count() or 1)
@@ -112,6 +128,8 @@ def build(force=False, verbose=False, only=None, jobs=None):
             raise RuntimeError(f"{u[0]}: {' '.join(u[1])}\n{r.stderr[-4000:]}")
         if r.stderr.strip() and verbose:
             print(r.stderr[-2000:])
+        with open(u[2] + ".flags", "w") as f:
+            f.write(u[3])
         return u[0]
 
     with ThreadPoolExecutor(max_workers=jobs) as ex:

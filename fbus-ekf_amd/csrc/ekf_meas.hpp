@@ -1485,7 +1485,9 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
 // correct_pixels2_kernel's fold) or from stereo corners (MEAS_CORNERS: correct_corners2_kernel's), then the one-shot update --
 // the reference's BatchImuProcessing + ObservationUpdate (filter.cpp:232-235) with the measurement model of BASELINE.json's
 // north_star in place of the pose rows.  Same device functions in the same order per filter as K predict launches + one
-// correct_pixels / correct_corners launch with one wave per tile: bit-equal to that sequence (tests/test_frame_meas_gpu.py).
+// correct_pixels / correct_corners launch with one wave per tile: equal to that sequence to fp32 rounding (the single-step gate; the
+// predict loop is built with FBUS_X_PACK_FMEAS, the per-call predict with FBUS_X_PACK, and FMA contraction differs between the
+// kernels); the update alone (K = 0) and window-vs-frames ARE bit-equal (tests/test_frame_meas_gpu.py).
 //
 // Registers: the predict loop holds the whole record (28 + 172 values) beside its coefficients; the double-precision fold needs
 // ~390 registers WITHOUT the covariance.  So between the last ImuUpdate and the update the covariance waits outside the register

@@ -153,6 +153,13 @@ struct fbus_ekf {
     // staging for the host-pointer entry points (grown on demand)
     void* stage[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     size_t stage_cap[6] = { 0, 0, 0, 0, 0, 0 };
+    // asynchronous host-pointer entry points (fbus_ekf_predict_async / _correct_async): a ring of pinned staging slots + a copy stream
+    struct AsyncSlot { void* host = nullptr; void* dev = nullptr; size_t cap = 0; hipEvent_t copied = nullptr, done = nullptr; bool busy = false; };
+    static constexpr int ASYNC_SLOTS = 8;
+    AsyncSlot aring[ASYNC_SLOTS];
+    unsigned anext = 0;
+    hipStream_t copy_stream = nullptr;
+    int64_t async_calls = 0, async_waits = 0, async_direct = 0;      // calls, calls that had to wait for a slot, pieces DMA'd in place
     std::string err;
     // timing
     bool timing = false;
@@ -695,8 +702,8 @@ int launch_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* l
 
 // One camera frame with the north star's MeasureUpdate: K predicts + correct_pixels (kind 0) / correct_corners (kind 1).
 // ONE launch (frame_meas_kernel: record resident, covariance parked in LDS across the fold) where the per-call update would run one wave
-// per tile anyway -- fp32 records, more than half a chip of tiles (or fbus_ekf_set_team(., 1)) -- and bit-equal to the per-call
-// sequence there; otherwise predict_n + the per-call update (whose team forms fill a small launch better than one resident wave
+// per tile anyway -- fp32 records, more than half a chip of tiles (or fbus_ekf_set_team(., 1)) -- and equal to the per-call
+// sequence to fp32 rounding there (bit-equal: its update alone, K = 0, and a window to its frames); otherwise predict_n + the per-call update (whose team forms fill a small launch better than one resident wave
 // per tile could; fp64 records: the resident fold + covariance do not fit 512 registers).
 // fused: does this handle take the resident kernel (frame_meas_kernel) for M marker slots of this kind / mode?
 template <typename T>
@@ -774,6 +781,86 @@ int stage_in(fbus_ekf_t h, int slot, const void* host, size_t bytes, const void*
     HIP_TRY(h, hipMemcpyAsync(h->stage[slot], host, bytes, hipMemcpyHostToDevice, h->stream));
     *out = h->stage[slot];
     return FBUS_OK;
+}
+
+// ---- asynchronous host-pointer calls ---------------------------------------------------------------------------------
+// The reference's caller hands one IMU sample at a time to a filter thread and returns at once (FILTER::SetImuData under a mutex,
+// filter.cpp:24-55; BatchImuProcessing issues one predict per sample, :505-516).  The synchronous host-pointer entry points stage
+// pageable memory and wait for the kernel (103 us per predict at 65 536 filters); these do not wait:
+//   * every input array is taken BY VALUE at the call: pageable memory is copied into a pinned ring slot by the calling thread
+//     (the caller's buffer is free again on return), pinned memory (hipHostMalloc / hipHostRegister / fbus_ekf_host_register) is
+//     DMA'd in place (it must stay unchanged until fbus_ekf_async_inputs_consumed / fbus_ekf_sync);
+//   * the H2D copy runs on a copy stream of the handle's, the kernel on the handle's stream behind an event: the copy of call i + 1
+//     overlaps the kernel of call i;
+//   * a slot is reused after ASYNC_SLOTS calls; the call then waits for THAT slot's kernel only (back-pressure, counted).
+// Completion and device-side errors: fbus_ekf_sync, or any host-pointer result (fbus_ekf_get_state, fbus_ekf_get_applied).
+struct AsyncPiece { const void* src; size_t bytes; const void** dev_out; };
+
+bool host_ptr_is_pinned(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (an ordinary malloc'ed pointer)
+    return at.type == hipMemoryTypeHost;
+}
+
+int async_begin(fbus_ekf_t h, AsyncPiece* pieces, int n, fbus_ekf::AsyncSlot** out)
+{
+    if (h->capturing) return fail(h, FBUS_ERR_INVALID, "the asynchronous host-pointer calls cannot be captured into a graph (use the _dev entry points)");
+    if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    fbus_ekf::AsyncSlot& a = h->aring[h->anext++ % fbus_ekf::ASYNC_SLOTS];
+    if (!a.copied) {
+        HIP_TRY(h, hipEventCreateWithFlags(&a.copied, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    }
+    ++h->async_calls;
+    if (a.busy) {                                   // the kernel that read this slot ASYNC_SLOTS calls ago
+        if (hipEventQuery(a.done) != hipSuccess) { ++h->async_waits; HIP_TRY(h, hipEventSynchronize(a.done)); }
+        a.busy = false;
+    }
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (pieces[i].bytes + 255) & ~(size_t)255;
+    if (total > a.cap) {
+        if (a.host) HIP_TRY(h, hipHostFree(a.host));
+        if (a.dev) HIP_TRY(h, hipFree(a.dev));
+        a.host = a.dev = nullptr; a.cap = 0;
+        const size_t cap = (total + (total >> 2) + 65535) & ~(size_t)65535;
+        HIP_TRY(h, hipHostMalloc(&a.host, cap, hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc(&a.dev, cap));
+        a.cap = cap;
+    }
+    // staged pieces first (one contiguous range -> ONE copy), then the pinned ones in place
+    size_t off = 0, staged_end = 0;
+    bool direct[8] = { false, false, false, false, false, false, false, false };
+    for (int i = 0; i < n; ++i) {
+        *pieces[i].dev_out = nullptr;
+        if (!pieces[i].src || pieces[i].bytes == 0) continue;
+        direct[i] = pieces[i].bytes >= 4096 && host_ptr_is_pinned(pieces[i].src);
+        if (direct[i]) continue;
+        std::memcpy((char*)a.host + off, pieces[i].src, pieces[i].bytes);
+        *pieces[i].dev_out = (char*)a.dev + off;
+        off += (pieces[i].bytes + 255) & ~(size_t)255;
+        staged_end = off;
+    }
+    if (staged_end) HIP_TRY(h, hipMemcpyAsync(a.dev, a.host, staged_end, hipMemcpyHostToDevice, h->copy_stream));
+    for (int i = 0; i < n; ++i) {
+        if (!direct[i]) continue;
+        HIP_TRY(h, hipMemcpyAsync((char*)a.dev + off, pieces[i].src, pieces[i].bytes, hipMemcpyHostToDevice, h->copy_stream));
+        *pieces[i].dev_out = (char*)a.dev + off;
+        off += (pieces[i].bytes + 255) & ~(size_t)255;
+        ++h->async_direct;
+    }
+    HIP_TRY(h, hipEventRecord(a.copied, h->copy_stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, a.copied, 0));
+    *out = &a;
+    return FBUS_OK;
+}
+
+int async_end(fbus_ekf_t h, fbus_ekf::AsyncSlot* a, int rc)
+{
+    // (also behind a failed launch: the slot's memory must not be rewritten while the stream may still read it)
+    HIP_TRY(h, hipEventRecord(a->done, h->stream));
+    a->busy = true;
+    return rc;
 }
 
 size_t record_elems(int dtype, int N)
@@ -982,6 +1069,14 @@ int fbus_ekf_destroy(fbus_ekf_t h)
     for (auto& p : h->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto g : h->graphs) if (g) (void)hipGraphExecDestroy(g);
     for (int i = 0; i < 6; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    for (auto& a : h->aring) {
+        if (a.host) (void)hipHostFree(a.host);
+        if (a.dev) (void)hipFree(a.dev);
+        if (a.copied) (void)hipEventDestroy(a.copied);
+        if (a.done) (void)hipEventDestroy(a.done);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_recs && h->recs) (void)hipFree(h->recs);
     if (h->d_applied) (void)hipFree(h->d_applied);
     if (h->d_ema_carry) (void)hipFree(h->d_ema_carry);
@@ -1387,6 +1482,82 @@ int fbus_ekf_predict(fbus_ekf_t h, const void* accel, const void* gyro, const vo
 {
     DeviceGuard guard_(h);
     return fbus_ekf_predict_n(h, 1, accel, gyro, dt, dt_per_filter);
+}
+
+int fbus_ekf_predict_n_async(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
+{
+    DeviceGuard guard_(h);
+    if (!h || !accel || !gyro || !dt || K < 1) return FBUS_ERR_INVALID;
+    const size_t es = esize(h), B = (size_t)h->B;
+    const void *da, *dg, *dd;
+    AsyncPiece pc[3] = { { accel, (size_t)K * B * 3 * es, &da }, { gyro, (size_t)K * B * 3 * es, &dg },
+                         { dt, (size_t)K * (dt_per_filter ? B : 1) * es, &dd } };
+    fbus_ekf::AsyncSlot* a;
+    int rc = async_begin(h, pc, 3, &a);
+    if (rc != FBUS_OK) return rc;
+    return async_end(h, a, launch_predict(h, K, da, dg, dd, dt_per_filter));
+}
+
+int fbus_ekf_predict_async(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter)
+{
+    return fbus_ekf_predict_n_async(h, 1, accel, gyro, dt, dt_per_filter);
+}
+
+int fbus_ekf_correct_async(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || !ids || !pos || !quat || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (mode != FBUS_MODE_NEAREST && mode != FBUS_MODE_STACKED) return FBUS_ERR_UNSUPPORTED;
+    const size_t es = esize(h), B = (size_t)h->B;
+    const void *di, *dp, *dq, *ds;
+    AsyncPiece pc[4] = { { ids, B * M * 4, &di }, { pos, B * M * 3 * es, &dp }, { quat, B * M * 4 * es, &dq }, { skip, skip ? B : 0, &ds } };
+    fbus_ekf::AsyncSlot* a;
+    int rc = async_begin(h, pc, 4, &a);
+    if (rc != FBUS_OK) return rc;
+    return async_end(h, a, launch_correct(h, M, (const int32_t*)di, dp, dq, mode, (const uint8_t*)ds));
+}
+
+int fbus_ekf_correct_pixels_async(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right, const uint8_t* skip)
+{
+    DeviceGuard guard_(h);
+    if (!h || !ids || !left || M < 1 || M > FBUS_MAX_VISIBLE) return FBUS_ERR_INVALID;
+    if (!(h->prm.r_pix > 0)) return fail(h, FBUS_ERR_INVALID, "r_pix must be positive");
+    const size_t es = esize(h), B = (size_t)h->B;
+    const void *di, *dl, *dr, *ds;
+    AsyncPiece pc[4] = { { ids, B * M * 4, &di }, { left, B * M * 8 * es, &dl }, { right, right ? B * M * 8 * es : 0, &dr }, { skip, skip ? B : 0, &ds } };
+    fbus_ekf::AsyncSlot* a;
+    int rc = async_begin(h, pc, 4, &a);
+    if (rc != FBUS_OK) return rc;
+    return async_end(h, a, launch_correct_pixels(h, M, (const int32_t*)di, dl, dr, (const uint8_t*)ds));
+}
+
+int fbus_ekf_async_inputs_consumed(fbus_ekf_t h)
+{
+    DeviceGuard guard_(h);
+    if (!h) return FBUS_ERR_INVALID;
+    if (h->copy_stream) HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+    return FBUS_OK;
+}
+
+int fbus_ekf_async_stats(fbus_ekf_t h, int64_t* calls, int64_t* waits, int64_t* direct_pieces)
+{
+    if (!h) return FBUS_ERR_INVALID;
+    if (calls) *calls = h->async_calls;
+    if (waits) *waits = h->async_waits;
+    if (direct_pieces) *direct_pieces = h->async_direct;
+    return FBUS_OK;
+}
+
+int fbus_ekf_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0) return FBUS_ERR_INVALID;
+    return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? FBUS_OK : ((void)hipGetLastError(), FBUS_ERR_HIP);
+}
+
+int fbus_ekf_host_unregister(void* ptr)
+{
+    if (!ptr) return FBUS_ERR_INVALID;
+    return hipHostUnregister(ptr) == hipSuccess ? FBUS_OK : ((void)hipGetLastError(), FBUS_ERR_HIP);
 }
 
 int fbus_ekf_correct_dev(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode,

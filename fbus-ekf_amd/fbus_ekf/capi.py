@@ -22,7 +22,7 @@ STREAM_OWN = (1 << 64) - 1         # FBUS_STREAM_OWN = (void*)-1
 # fbus_ekf_launch_info (include/fbus_ekf.h)
 (INFO_SIMDS, INFO_ONE_ROUND_FILTERS, INFO_TWO_WAVE_MIN_B, INFO_BIG_RECORDS_MB, INFO_MALL_MB, INFO_L2_KB, INFO_POLICY_BATCH,
  INFO_ROLES_PREDICT, INFO_ROLES_MEAS, INFO_TEAM_FRAMES, INFO_MEAS_SPLIT) = range(11)
-ABI_VERSION = 5                    # FBUS_ABI_VERSION of the header this mirror was written against
+ABI_VERSION = 6                    # FBUS_ABI_VERSION of the header this mirror was written against
 ERR_ABI = 6
 
 
@@ -124,6 +124,14 @@ def load_library():
         "fbus_ekf_correct_corners_dev": ([H, C.c_int, ip, vp, vp, C.c_int, C.c_int, u8p], C.c_int),
         "fbus_ekf_correct_pixels": ([H, C.c_int, ip, vp, vp, u8p], C.c_int),
         "fbus_ekf_correct_pixels_dev": ([H, C.c_int, ip, vp, vp, u8p], C.c_int),
+        "fbus_ekf_predict_async": ([H, vp, vp, vp, C.c_int], C.c_int),
+        "fbus_ekf_predict_n_async": ([H, C.c_int, vp, vp, vp, C.c_int], C.c_int),
+        "fbus_ekf_correct_async": ([H, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
+        "fbus_ekf_correct_pixels_async": ([H, C.c_int, ip, vp, vp, u8p], C.c_int),
+        "fbus_ekf_async_inputs_consumed": ([H], C.c_int),
+        "fbus_ekf_async_stats": ([H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
+        "fbus_ekf_host_register": ([vp, C.c_size_t], C.c_int),
+        "fbus_ekf_host_unregister": ([vp], C.c_int),
         "fbus_ekf_get_applied": ([H, u8p], C.c_int),
         "fbus_ekf_frame_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),
         "fbus_ekf_frame_fused_dev": ([H, C.c_int, vp, vp, vp, C.c_int, C.c_int, ip, vp, vp, C.c_int, u8p], C.c_int),

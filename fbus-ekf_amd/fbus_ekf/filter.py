@@ -218,6 +218,15 @@ class BatchedFilter:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self._lib.fbus_ekf_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)), "comm_init")
 
+    def copy_records(self, dst, dst_device=0, byte_offset=0):
+        """this handle's packed records into device memory `dst` (+ byte_offset) on `dst_device`, on the handle's stream
+        (fbus_ekf_copy_records: the peer-copy form of the gather, what fbus::NodeFilter::gather_to issues per shard).
+        dst: a device tensor or a raw device pointer (int)."""
+        ptr = dst if isinstance(dst, int) else dst.data_ptr()
+        if not isinstance(dst, int):
+            self._keep.append(dst)
+        self._check(self._lib.fbus_ekf_copy_records(self._h, C.c_void_p(ptr + int(byte_offset)), int(dst_device)), "copy_records")
+
     def gather(self, out, bytes_of_rank=None):
         """all ranks' packed records into the device array `out` (uint8, sum of the ranks' record bytes) on every rank"""
         arr = None
@@ -253,6 +262,52 @@ class BatchedFilter:
             raise ValueError("dt must have K or K*B elements")
         rc = self._lib.fbus_ekf_predict_n(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per)
         self._check(rc, "predict_n")
+
+    # ---- the host-pointer calls without the wait (fbus_ekf_*_async) --------------------------------
+    def _host_any(self, x, shape, dtype=None):
+        """numpy array or a CPU torch tensor (pinned tensors are transferred in place by the library)"""
+        if _is_dev(x):
+            if x.is_cuda:
+                raise ValueError("the _async calls take HOST arrays (device arrays go to predict / correct: already asynchronous)")
+            x = x.numpy()              # shares the (possibly pinned) memory
+        return self._host(x, shape, dtype)
+
+    def predict_async(self, accel, gyro, dt, K=1):
+        """fbus_ekf_predict_n_async: host arrays taken by value, nothing waits for the device (results: sync() / get_state())"""
+        B = self.B
+        accel, gyro = self._host_any(accel, (K, B, 3)), self._host_any(gyro, (K, B, 3))
+        dt = np.ascontiguousarray(np.atleast_1d(dt), self.np_dtype)
+        per = 1 if (dt.size == K * B and B > 1) else 0
+        if not per and dt.size != K:
+            raise ValueError("dt must have K or K*B elements")
+        self._check(self._lib.fbus_ekf_predict_n_async(self._h, K, self._p(accel), self._p(gyro), self._p(dt), per), "predict_n_async")
+
+    def correct_async(self, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):
+        B = self.B
+        ids = np.ascontiguousarray(ids.numpy() if _is_dev(ids) else ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        pos, quat = self._host_any(pos, (B, M, 3)), self._host_any(quat, (B, M, 4))
+        skip = None if skip is None else self._host(skip, (B,), np.uint8)
+        self._check(self._lib.fbus_ekf_correct_async(self._h, M, self._p(ids), self._p(pos), self._p(quat), mode, self._p(skip)), "correct_async")
+
+    def correct_pixels_async(self, ids, left, right=None, skip=None):
+        B = self.B
+        ids = np.ascontiguousarray(ids, np.int32).reshape(B, -1)
+        M = ids.shape[1]
+        left = self._host_any(left, (B, M, 8))
+        right = None if right is None else self._host_any(right, (B, M, 8))
+        skip = None if skip is None else self._host(skip, (B,), np.uint8)
+        self._check(self._lib.fbus_ekf_correct_pixels_async(self._h, M, self._p(ids), self._p(left), self._p(right), self._p(skip)),
+                    "correct_pixels_async")
+
+    def async_inputs_consumed(self):
+        """every H2D copy of the _async calls so far is done: pinned input arrays may be rewritten"""
+        self._check(self._lib.fbus_ekf_async_inputs_consumed(self._h), "async_inputs_consumed")
+
+    def async_stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.fbus_ekf_async_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "async_stats")
+        return {"calls": a.value, "waits": b.value, "direct_pieces": c.value}
 
     # ---- correct == MeasureUpdate -----------------------------------------------------
     def correct(self, ids, pos, quat, mode=capi.MODE_NEAREST, skip=None):

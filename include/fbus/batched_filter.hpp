@@ -71,6 +71,20 @@ public:
                  const uint8_t* skip = nullptr)
     { check(fbus_ekf_correct(h_, M, ids, pos, quat, int(mode), skip), "correct"); }
 
+    // ---- (round 6) the same host-pointer calls without the wait: arrays taken by value (pageable: copied into a pinned ring of the
+    //      handle's on return; pinned: in place, unchanged until inputs_consumed() / sync()), nothing waits for the device -- one call
+    //      per IMU sample as FILTER::SetImuData / BatchImuProcessing issue them (filter.cpp:24-55,505-516)
+    void predict_async(const Real* accel, const Real* gyro, Real dt)
+    { check(fbus_ekf_predict_async(h_, accel, gyro, &dt, 0), "predict_async"); }
+    void predict_n_async(int K, const Real* accel, const Real* gyro, const Real* dt, bool dt_per_filter = false)
+    { check(fbus_ekf_predict_n_async(h_, K, accel, gyro, dt, dt_per_filter), "predict_n_async"); }
+    void correct_async(int M, const int32_t* ids, const Real* pos, const Real* quat, Mode mode = Mode::Nearest,
+                       const uint8_t* skip = nullptr)
+    { check(fbus_ekf_correct_async(h_, M, ids, pos, quat, int(mode), skip), "correct_async"); }
+    void correct_pixels_async(int M, const int32_t* ids, const Real* left, const Real* right = nullptr, const uint8_t* skip = nullptr)
+    { check(fbus_ekf_correct_pixels_async(h_, M, ids, left, right, skip), "correct_pixels_async"); }
+    void inputs_consumed() { check(fbus_ekf_async_inputs_consumed(h_), "async_inputs_consumed"); }
+
     // ---- hot path, device pointers (no copies, asynchronous until sync()) ----------------------------
     void predict_dev(const Real* accel, const Real* gyro, const Real* dt, bool dt_per_filter = false)
     { check(fbus_ekf_predict_dev(h_, accel, gyro, dt, dt_per_filter), "predict_dev"); }

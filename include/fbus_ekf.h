@@ -110,7 +110,7 @@ int fbus_params_validate(const fbus_params* prm, char* msg, size_t msg_len);
  *   3  round 3: FBUS_ERR_ABI, create_checked, team kernels (fbus_ekf_set_team), fbus_ekf_gather
  *   2  round 2: r_pix in fbus_params, set_stream(NULL) = legacy default stream
  *   1  round 1 */
-#define FBUS_ABI_VERSION 5
+#define FBUS_ABI_VERSION 6
 int fbus_ekf_abi_version(void);
 size_t fbus_params_size(void);
 
@@ -232,6 +232,35 @@ int fbus_ekf_predict_dev(fbus_ekf_t h, const void* accel, const void* gyro, cons
 int fbus_ekf_predict_n(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
 int fbus_ekf_predict_n_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
 
+/* ---- (round 6) the same host-pointer signatures WITHOUT the wait -------------- */
+/* Replaces the same calls as fbus_ekf_predict / _predict_n / _correct / _correct_pixels, as the reference's caller issues them: one
+ * call per IMU sample / camera frame that returns at once (FILTER::SetImuData hands the sample to the filter thread under a mutex,
+ * filter.cpp:24-55; BatchImuProcessing then runs one predict per sample, :505-516; SetDetectionResult copies the detections,
+ * :61-65).  Arguments, checks, arithmetic and results are those of the synchronous entry points; what differs:
+ *   - every HOST array is taken by value at the call.  Pageable memory is copied into a pinned ring slot of the handle's by the
+ *     calling thread -- the caller's buffer is free again on return.  Memory that is already pinned (hipHostMalloc, hipHostRegister,
+ *     fbus_ekf_host_register below; pieces of >= 4 KiB) is transferred IN PLACE and must stay unchanged until
+ *     fbus_ekf_async_inputs_consumed() or fbus_ekf_sync() returns;
+ *   - nothing waits for the device: the H2D copy runs on a copy stream, the kernel on the handle's stream behind it, so the copy of
+ *     call i + 1 overlaps the kernel of call i.  The ring has 8 slots; the ninth call in flight waits for the first one's kernel
+ *     (back-pressure; counted by fbus_ekf_async_stats);
+ *   - completion and device-side errors surface at fbus_ekf_sync() or at any host-pointer result (fbus_ekf_get_state,
+ *     fbus_ekf_get_applied), which are unchanged.  Not capturable into a HIP graph (FBUS_ERR_INVALID between graph_begin / _end).
+ * Measured (tools/host_api_rate.py). */
+int fbus_ekf_predict_async(fbus_ekf_t h, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
+int fbus_ekf_predict_n_async(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter);
+int fbus_ekf_correct_async(fbus_ekf_t h, int M, const int32_t* ids, const void* pos, const void* quat, int mode, const uint8_t* skip);
+int fbus_ekf_correct_pixels_async(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right /* may be NULL */,
+                                  const uint8_t* skip);
+/* every H2D copy issued so far has completed: pinned input arrays handed to the _async calls may be rewritten (cheaper than
+ * fbus_ekf_sync: does not wait for the kernels) */
+int fbus_ekf_async_inputs_consumed(fbus_ekf_t h);
+/* counters since create: _async calls, calls that had to wait for a ring slot, input pieces transferred in place (any may be NULL) */
+int fbus_ekf_async_stats(fbus_ekf_t h, int64_t* calls, int64_t* waits, int64_t* direct_pieces);
+/* page-lock / release a host range for in-place transfers (hipHostRegister / hipHostUnregister for callers without HIP headers) */
+int fbus_ekf_host_register(void* ptr, size_t bytes);
+int fbus_ekf_host_unregister(void* ptr);
+
 /* ---- correct == MeasureUpdate ---------------------------------------------- */
 /* Replaces: State = MeasureUpdate(State, visionMeas[8xM], markerMap, cameraInfo)
  * (matlab/MeasureUpdate.m:37) and FILTER::ObservationUpdate (filter.cpp:622-754)
@@ -279,8 +308,10 @@ int fbus_ekf_frame_fused_dev(fbus_ekf_t h, int K, const void* accel, const void*
  * (FBUS_MEAS_CORNERS: fbus_ekf_correct_corners_dev with its geometry and mode) -- in place of the pose rows: K predicts
  * (matlab/ImuUpdate.m:36-82 ; filter.cpp:505-516) and the update (matlab/MeasureUpdate.m:84-102 with the reprojection rows of the
  * flat-port model, vision.cpp:496-599 run forward) in ONE launch, the record resident in registers / LDS in between.  Same
- * arithmetic and results as K fbus_ekf_predict_dev calls + one fbus_ekf_correct_pixels_dev / _corners_dev call (bit-equal where
- * that update runs one wave per tile: more than half a chip of tiles, or fbus_ekf_set_team(h, ., 1)); smaller launches and fp64
+ * arithmetic as K fbus_ekf_predict_dev calls + one fbus_ekf_correct_pixels_dev / _corners_dev call, and equal results TO FP32
+ * ROUNDING (the single-step gate of tests/util.py: which product of an a b + c d becomes an FMA differs between the specialised
+ * kernels); bit-equal are the update alone (K = 0) to the per-call update and a window to its sequence of frames -- where that
+ * update runs one wave per tile: more than half a chip of tiles, or fbus_ekf_set_team(h, ., 1).  Smaller launches and fp64
  * records run as fbus_ekf_predict_n_dev + the per-call update.  M = 0: predicts only.  left / right: 16-byte aligned. */
 enum { FBUS_MEAS_PIXELS = 0, FBUS_MEAS_CORNERS = 1 };
 int fbus_ekf_frame_meas_fused_dev(fbus_ekf_t h, int K, const void* accel, const void* gyro, const void* dt, int dt_per_filter,
@@ -395,7 +426,10 @@ int fbus_ekf_timing_read(fbus_ekf_t h, int kernel, double* total_ms, int64_t* la
  * all rows of all visible markers at one linearisation point, folded into the 6x6 information matrix; the update is the one-shot
  * form  P(J,:) <- G P(J,:),  P_rr -= x_a' S^-1 x_c  (symmetric by construction, nothing cancels on the rows the measurement
  * shrinks).  fbus_params::cov_form DOES NOT APPLY to this entry point nor to fbus_ekf_correct_corners: FBUS_COV_JOSEPH selects
- * nothing here (the one-shot form already has what Joseph's form is chosen for); it governs fbus_ekf_correct only.
+ * nothing here (the one-shot form already has what Joseph's form is chosen for); it governs fbus_ekf_correct only.  The one form
+ * is checked against BOTH forms of the oracle -- (I - K H) P, MeasureUpdate.m:101-102, and Joseph's (I - K H) P (I - K H)' + K R K',
+ * what north_star names: fp64 records 1e-9, fp32 the standard gates (tests/test_pixels_gpu.py::test_correct_pixels_matches_the_oracle,
+ * tests/test_vision_gpu.py::test_correct_from_stereo_corners_matches_oracle).
  * left / right must be 16-byte aligned (any allocation is): the slots are fetched with 16-byte loads, FBUS_ERR_INVALID otherwise.
  * ids (B, M), left / right (B, M, 8) = x0 y0 .. x3 y3 (the column layout of corners.txt, vision.cpp:111-119). */
 int fbus_ekf_correct_pixels(fbus_ekf_t h, int M, const int32_t* ids, const void* left, const void* right /* may be NULL */,

@@ -122,7 +122,7 @@ def test_config3_correct_16384_filters_4_markers(dialect, mode):
 def test_config3_correct_from_refracted_stereo_corners(mode):
     """the flat-port refraction model in front of MeasureUpdate: stereo corner pixels of the water recording (perturbed)
     -> refractive triangulation on the device -> 12 corner rows per marker.  fp64 device == fp64 oracle chain;
-    fp32 device within 10x the single-step bounds (the triangulated corners carry ~2e-6 m of fp32 rounding)."""
+    fp32 device within the standard single-step gate (round 5: the triangulation computes in double, 1.7e-7 measured)."""
     B, M, size, dialect = 16384, 4, 0.117, 1
     prm = capi.default_params(dialect)
     prm.marker_size = size

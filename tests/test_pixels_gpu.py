@@ -94,7 +94,13 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo, cov_form, monkeypatc
               f"sigma-aware {e['sigma']:.2e} ({e['sigma_block']}) plain {e['plain']:.2e} ({e['plain_block']}) cov {e['cov']:.2e} "
               f"cov block-wise {e['cov_block']:.2e}")
         if dtype == 64:
-            assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["cov"] < F64_TOL and e["cov_block"] < F64_TOL and e["asym"] == 0
+            # Against the Joseph-form oracle everything holds 1e-9 (measured: literal 3e-13, block-wise covariance 5e-13).  Against the
+            # oracle's LITERAL (I - K H) P the state and the max-norm covariance do too, the block-wise covariance figure does not -- and it
+            # is the ORACLE that is off: 32-64 rows at sigma_pix = 1e-3 shrink the pose variances by four decades, and (I - K H) P
+            # subtracts nearly equal numbers there (block-wise 7e-10 left, 2e-8 stereo in double; the oracle's own two forms differ by
+            # as much, tests/test_oracle_pixels_cpu.py), which the one-shot form G P(J,:) and Joseph's form never do.
+            assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["cov"] < F64_TOL and e["asym"] == 0
+            assert e["cov_block"] < (F64_TOL if cov_form == oc.JOSEPH else 1e-6)
             # and the independent central-difference oracle, to its own error (eps = 1e-6 m: ~1e-9 relative on H, times the gain of
             # 32-64 rows at r_pix = 1e-6)
             f = parity_errors(got, want_fd)
@@ -155,7 +161,10 @@ def test_the_fifteen_state_filter_takes_the_same_updates():
             e = parity_errors(got, eng.get_state())
             print(f"[parity] N = 15, {what} fp{dtype}: literal {e['literal']:.2e} sigma-aware {e['sigma']:.2e} cov block-wise {e['cov_block']:.2e}")
             if dtype == 64:
-                assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["cov_block"] < F64_TOL and e["asym"] == 0
+                # (corner rows: r_pos = 1e-3 m leaves (I - K H) P well conditioned, 1e-9 holds; reprojection rows: the oracle's literal form
+                # cancels -- see test_correct_pixels_matches_the_oracle, which holds the kernel to the Joseph-form oracle at 1e-9)
+                assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["asym"] == 0
+                assert e["cov_block"] < (F64_TOL if what == "corners" else 1e-6)
             else:
                 assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL
                 assert e["cov"] <= COV_TOL and e["cov_block"] <= COV_BLOCK_TOL and e["asym"] == 0
@@ -181,7 +190,7 @@ def test_tilted_port_takes_the_general_normal_path():
     rot, P, left, right = r32(synth.q2R(nom[:, 6:10]).reshape(B, 9)), r32(P), r32(left), r32(right)
     for stereo in (False, True):
         rgt = right if stereo else None
-        eng = OracleEngine(B, dialect, 18)
+        eng = OracleEngine(B, dialect, 18, cov_form=oc.JOSEPH)       # (the form whose block-wise covariance is good to 1e-9 in double)
         eng.set_state(nom, rot, P, prev)
         ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, rgt, SIZE, prm.r_pix, vision=vp, analytic=True)
         assert ok.all()

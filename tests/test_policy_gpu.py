@@ -244,3 +244,117 @@ def test_shards_of_a_job_above_one_round_equal_the_single_handle_bit_for_bit():
             d = np.abs(gathered[2].astype(np.float64) - single[2]).max() / np.abs(single[2]).max()
             print(f"[shards] un-pinned shards of 73 728 filters against the single handle: bit-equal {same}, max |d P| / max |P| {d:.2e}")
             assert d < 1e-6              # (the one-wave forms against the <= 256-register forms: to an ulp, not to the bit)
+
+
+def test_config4_partition_262144_filters_as_eight_shards_of_32768():
+    """BASELINE config 4 -- 262 144 filters sharded over 8 GPUs, 200 Hz IMU + 30 Hz stereo, 4 markers -- as its PARTITION on one device
+    (round 6; no 8-GPU box in any round): the eight contiguous shards of 32 768 filters (fbus_ekf/shard.py) run one after
+    the other as eight handles with the policy batch set to the job's total, step 0.1 s of the mixed schedule each (7 / 7 / 6 per-call
+    ImuUpdates, a stacked 4-marker MeasureUpdate behind each run: 23 EKF steps per filter, ImuUpdate.m:36-82 / MeasureUpdate.m:37-103)
+    plus one fused camera frame, and are gathered by fbus_ekf_copy_records (the peer-copy form of the gather, what
+    fbus::NodeFilter::gather_to issues per shard) into the record buffer of a whole-batch handle.
+    Asserted: the gathered records == the single 262 144-filter handle's BIT FOR BIT (records, and the unpacked state); on EVERY filter
+    the posterior is finite, symmetric, has a positive diagonal and a unit quaternion; positive definite on a strided subset; the fp64
+    oracle on a strided subset through the free-running window gate.  What stays untested is the 8-GPU hardware run itself."""
+    import torch
+    from fbus_ekf import shard
+    from util import assert_window_parity
+    total, world, M = 262144, 8, 4
+    pattern = (7, 7, 6)
+    Kt = sum(pattern)
+    prm = capi.default_params(0)
+    nom, rot, _, prev = synth.initial_state(0, total, list(prm.p0_diag), 18, with_cov=False)
+    nom, rot = _r32(nom), _r32(rot)
+    acc, gyr = synth.imu_samples(0, total, 0, Kt, nom)
+    acc, gyr = _r32(acc), _r32(gyr)
+    frames = [synth.marker_frame(0, total, f, M, nom, prm) for f in range(len(pattern) + 1)]
+    ids = np.stack([f[0] for f in frames]); pos = _r32(np.stack([f[1] for f in frames])); quat = _r32(np.stack([f[2] for f in frames]))
+    dev = torch.device("cuda:0")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    d_dt = torch.full((max(pattern),), float(DT[0]), dtype=torch.float32, device=dev)
+
+    def job(flt, lo, hi):
+        flt.set_state(nom[lo:hi], rot[lo:hi], None, prev[lo:hi])
+        flt.reset_cov()
+        a, g = f32(acc[:, lo:hi]), f32(gyr[:, lo:hi])
+        i, p, q = torch.from_numpy(np.ascontiguousarray(ids[:, lo:hi])).to(dev), f32(pos[:, lo:hi]), f32(quat[:, lo:hi])
+        torch.cuda.synchronize()
+        k = 0
+        for f, K in enumerate(pattern):                                  # per-call API: one launch per EKF step
+            for j in range(K):
+                flt.predict(a[k + j], g[k + j], d_dt[:1])
+            flt.correct(i[f], p[f], q[f], capi.MODE_STACKED)
+            k += K
+        flt.frame(a[:3], g[:3], d_dt[:3], i[3], p[3], q[3], capi.MODE_STACKED, fused=True)      # and one fused camera frame
+        flt.sync()
+
+    with BatchedFilter(total, prm) as single, BatchedFilter(total, prm) as whole:
+        if single.launch_info(capi.INFO_SIMDS) != 1024:
+            pytest.skip("thresholds of the 1024-SIMD device")
+        assert total >= single.launch_info(capi.INFO_TWO_WAVE_MIN_B)                            # the job runs the <= 256-register forms
+        job(single, 0, total)
+        ref = single.get_state()
+        ptr, bpf, tot = single.records()
+        assert bpf == 800 and tot == total * 800
+        rec_single = torch.empty(tot, dtype=torch.uint8, device=dev)
+        single.copy_records(rec_single, 0)
+        single.sync()
+        wptr, _, wtot = whole.records()
+        sizes = shard.record_bytes_of_ranks(total, world, bpf)
+        assert sum(sizes) == wtot == tot
+        off = 0
+        for r in range(world):
+            lo, hi = shard.shard_range(total, r, world)
+            assert (lo, hi) == (r * 32768, (r + 1) * 32768) and sizes[r] == 32768 * 800
+            with BatchedFilter(hi - lo, prm) as flt:
+                assert hi - lo < flt.launch_info(capi.INFO_TWO_WAVE_MIN_B)                      # left alone a shard would take the one-wave forms
+                flt.set_policy_batch(total)
+                assert flt.launch_info(capi.INFO_POLICY_BATCH) == total
+                job(flt, lo, hi)
+                flt.copy_records(wptr, 0, byte_offset=off)
+                flt.sync()
+            off += sizes[r]
+        rec_whole = torch.empty(tot, dtype=torch.uint8, device=dev)
+        whole.copy_records(rec_whole, 0)
+        whole.sync()
+        assert torch.equal(rec_whole, rec_single), "gathered shard records differ from the single handle's"
+        got = whole.get_state()
+    for name, a, b in zip(("nominal", "rot", "P", "prev"), got, ref):
+        assert np.array_equal(a, b), f"config 4 partition differs from the single handle in {name}"
+    # size-independent properties on EVERY filter
+    g_nom, g_rot, g_P = got[0], got[1], got[2]
+    assert np.isfinite(g_nom).all() and np.isfinite(g_rot).all() and np.isfinite(g_P).all()
+    assert np.abs(np.linalg.norm(g_nom[:, 6:10].astype(np.float64), axis=1) - 1).max() < 1e-6
+    assert np.array_equal(g_P, np.swapaxes(g_P, 1, 2))
+    assert (np.einsum("bii->bi", g_P) > 0).all()
+    sub = np.concatenate([np.arange(0, total, 1499), np.arange(total - 3, total), np.arange(32768 - 2, 32768 + 2)])
+    Ps = g_P[sub].astype(np.float64)
+    dg = np.sqrt(np.einsum("bii->bi", Ps))
+    assert np.linalg.eigvalsh(Ps / (dg[:, :, None] * dg[:, None, :])).min() > 0
+    # the oracle on the strided subset (27 steps without re-seeding: the window gate) -- twice: fp64 throughout, and with its RECORD rounded
+    # to fp32 after every step (the floor of tests/util.py::assert_window_parity: what an exact-arithmetic filter with fp32 records loses;
+    # the first run of this test read literal 1.02e-5 against the 1e-5 of a window)
+    from util import parity_errors
+
+    def oracle_run(fp32_records):
+        eng = OracleEngine(len(sub), 0, 18)
+        P0 = np.broadcast_to(np.diag(np.repeat(np.array(list(prm.p0_diag)), 3)), (len(sub), 18, 18)).copy()
+        eng.set_state(nom[sub], rot[sub], P0, prev[sub])
+
+        def q():
+            if fp32_records:
+                eng.nominal[...] = _r32(eng.nominal); eng.rot[...] = _r32(eng.rot); eng.P[...] = _r32(eng.P)
+        k = 0
+        for f, K in enumerate(pattern):
+            for j in range(K):
+                eng.predict(acc[k + j][sub], gyr[k + j][sub], DT); q()
+            eng.correct(ids[f][sub], pos[f][sub], quat[f][sub], capi.MODE_STACKED); q()
+            k += K
+        for j in range(3):
+            eng.predict(acc[j][sub], gyr[j][sub], DT); q()
+        eng.correct(ids[3][sub], pos[3][sub], quat[3][sub], capi.MODE_STACKED); q()
+        return eng.get_state()
+
+    ref64 = oracle_run(False)
+    floor = parity_errors(oracle_run(True), ref64)
+    assert_window_parity([x[sub] for x in got], ref64, f"config 4 partition, {len(sub)} of {total} filters", 0, 18, floor=floor)

@@ -149,23 +149,31 @@ def window_literal_tol(dialect, nstate):
     return WINDOW_LITERAL_TOL_CPP18 if (dialect == 1 and nstate == 18) else STATE_TOL
 
 
-FLOOR_FACTOR = 3.0
+# (round 6) 1.5, down from 3.0.  tools/emul_pixel_window_fields.py (profiles/r06_window_fields.txt) rounds ONE field group of the oracle's
+# record at a time on the window test's own inputs: the position alone accounts for the floor (1.14e-4 of 1.16e-4, N = 18 left camera),
+# and with p and v kept in double the rest of an fp32 record still leaves 3.8e-5 .. 5.6e-5 (carried rotation 3.6e-5, covariance
+# 1.4e-5 .. 6.5e-5, quaternion 6e-6 .. 2.6e-5): no record with an fp32 covariance reaches 1e-5 in these windows, so the wider-p record
+# was not built and the gate stays floor-relative -- at 1.5 x the floor (largest kernel / floor ratio measured: 1.24 on the literal figure),
+# with the ratio printed.
+FLOOR_FACTOR = 1.5
 
 
 def assert_window_parity(got, ref, what, dialect, nstate, verbose=True, prev=True, floor=None):
     """THE gate of free-running windows (fp32 kernels against the fp64 oracle, or two fp32 kernel forms against each other).
     `floor` (optional): parity_errors of the fp64 ORACLE run with fp32 RECORDS (the record rounded to fp32 after every step, exact
     arithmetic inside the steps) against the fp64 oracle on the same inputs -- what the test computed on the CPU.  Where that floor
-    exceeds a standard bound, the bound becomes FLOOR_FACTOR x the floor: a kernel is held to the north star's figures or to three
+    exceeds a standard bound, the bound becomes FLOOR_FACTOR x the floor: a kernel is held to the north star's figures or to 1.5
     times what an exact-arithmetic filter with its record type loses, whichever is larger (camera frames a few IMU samples apart whose
     reprojection rows pin the position to 1e-4 m differentiate the fp32 position's 6e-8 m quantum into the velocity)."""
     e = parity_errors(got, ref)
     fl = floor or {}
     tol = lambda name, std: max(std, FLOOR_FACTOR * fl.get(name, 0.0))
     if verbose:
+        ratio = lambda name: (e[name] / fl[name]) if fl.get(name) else float("nan")
         print(f"[parity] {what}: literal {e['literal']:.2e}  sigma-aware {e['sigma']:.2e} ({e['sigma_block']})  "
               f"plain per-block {e['plain']:.2e} ({e['plain_block']})  cov {e['cov']:.2e}  cov block-wise {e['cov_block']:.2e}" +
-              (f"   [fp32-record floor: literal {fl['literal']:.2e} sigma-aware {fl['sigma']:.2e} plain {fl['plain']:.2e} cov block-wise {fl['cov_block']:.2e}]"
+              (f"   [fp32-record floor: literal {fl['literal']:.2e} sigma-aware {fl['sigma']:.2e} plain {fl['plain']:.2e} cov block-wise {fl['cov_block']:.2e};"
+               f" kernel / floor: literal {ratio('literal'):.2f} sigma-aware {ratio('sigma'):.2f} plain {ratio('plain'):.2f} cov block-wise {ratio('cov_block'):.2f}]"
                if floor else ""))
     lit = tol("literal", window_literal_tol(dialect, nstate))
     assert e["literal"] <= lit, f"{what}: literal state rel err {e['literal']:.3g} > {lit:g}"
