@@ -54,8 +54,8 @@ STEPS_PER_PATTERN = sum(PATTERN) + len(PATTERN)         # 23 EKF steps per filte
 PATTERNS_PER_STEP = 10              # one bench step = 1 s of sensor time = 30 camera frames
 STEPS_PER_BENCH_STEP = STEPS_PER_PATTERN * PATTERNS_PER_STEP      # 230 EKF steps per filter
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PIXELS_SQ = "r05_pixels_sq.json"
-PROFILE_ROUND = 5                   # only profiles/r05_* digests are quoted as `traffic` (collected on this round's kernels)
+PIXELS_SQ = "r06_pixels_sq.json"
+PROFILE_ROUND = 6                   # only profiles/r06_* digests are quoted as `traffic` (collected on this round's kernels)
 # packed record round trip + inputs (what the per-call API implies)
 PREDICT_BYTES_API = 2 * 796 + 28
 CORRECT_BYTES_API = lambda M: 2 * 796 + 32 * M
@@ -140,7 +140,7 @@ def launch_ranks(args):
 # helpers
 # ------------------------------------------------------------------------------------------------
 def pmc_traffic(batch, args, world, kernel="predict"):
-    """HBM-side bytes per launch of a kernel from THIS round's committed rocprofv3 PMC passes (profiles/r05_digest_b<batch>.json,
+    """HBM-side bytes per launch of a kernel from THIS round's committed rocprofv3 PMC passes (profiles/r06_digest_b<batch>.json,
     written by tools/profile_digest.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE doubled on gfx950 as
     MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself.  The digest is only quoted when it was taken
     on THIS configuration (batch, dialect, markers, mode, eager launches, one GPU) and in THIS round (PROFILE_ROUND: a digest of an
@@ -479,7 +479,7 @@ def fp64_leg(torch, dev, local_rank, args, capi):
 
 
 def _pixels_sq_profile():
-    """this round's committed SQ-counter digest of the pixel-row kernel (tools/r5_pixels_prof.sh -> profiles/r05_pixels_sq.json)"""
+    """this round's committed SQ-counter digest of the pixel-row kernel (tools/pixels_prof.sh -> profiles/r06_pixels_sq.json)"""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", PIXELS_SQ)))
     except Exception:
@@ -500,7 +500,7 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
     noise (synth.pixel_wall_scene), filters at rest.  Reported per case: EKF steps/s, ms per bench step, launch time of the update
     (HIP events on the handle's stream), its algorithmic bytes (2 x 796 + 68 M) and their fraction of 8 TB/s, and --
     these kernels are VALU-bound, that fraction is not what limits them -- the VALU issue fraction = wave-level VALU instructions of
-    one launch (SQ_INSTS_VALU, committed rocprofv3 pass profiles/r05_pixels_sq.json) / (launch time x SIMDs x clock / 4)."""
+    one launch (SQ_INSTS_VALU, committed rocprofv3 pass profiles/r06_pixels_sq.json) / (launch time x SIMDs x clock / 4)."""
     from fbus_ekf import BatchedFilter, synth
     torch.cuda.empty_cache()
     out = {}

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--dtype", type=int, default=32)
     ap.add_argument("--roles", type=int, default=0)
     ap.add_argument("--corners", action="store_true", help="fbus_ekf_correct_corners_dev (refractive, stacked) instead of the pixel rows")
+    ap.add_argument("--fused-k0", action="store_true", help="the same update through fbus_ekf_frame_meas_fused_dev with K = 0 (frame_meas_kernel: "
+                                                            "record loaded up front, covariance parked in LDS across the fold)")
     args = ap.parse_args()
     import torch
     from fbus_ekf import BatchedFilter, capi, synth
@@ -41,16 +43,19 @@ def main():
                     flt.sync(); flt.timing_enable(True); flt.timing_reset()
                 flt.set_state(nom, rot, None, prev0)
                 flt.reset_cov()
-                if args.corners:
+                if args.fused_k0:
+                    flt.frame_meas(None, None, None, d_ids, d_left, d_right if stereo else None, capi.MEAS_CORNERS if args.corners else capi.MEAS_PIXELS,
+                                   capi.VIS_REFRACTIVE, capi.MODE_STACKED)
+                elif args.corners:
                     flt.correct_corners(d_ids, d_left, d_right, capi.VIS_REFRACTIVE, capi.MODE_STACKED)
                 else:
                     flt.correct_pixels(d_ids, d_left, d_right if stereo else None)
-            ms, n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
+            ms, n = flt.timing_read(capi.KERNEL_FRAME if args.fused_k0 else capi.KERNEL_CORRECT_CORNERS)
             flt.timing_enable(False)
             g = flt.get_state()
             ok = bool(np.isfinite(g[0]).all() and np.isfinite(g[2]).all())
             rows = nvis * (16 if stereo else 8)
-            print(f"{'correct_corners' if args.corners else 'correct_pixels'} fp{args.dtype} B {B} slots {args.slots} ({nvis:.1f} in view, {rows:.0f} rows) {'stereo' if stereo else 'left'}: "
+            print(f"{'frame_meas K=0 ' if args.fused_k0 else ''}{'correct_corners' if args.corners else 'correct_pixels'} fp{args.dtype} B {B} slots {args.slots} ({nvis:.1f} in view, {rows:.0f} rows) {'stereo' if stereo else 'left'}: "
                   f"{ms / n * 1e3:.1f} us per launch, applied {float(flt.applied().mean()):.3f}, finite {ok}, "
                   f"posterior sigma_p {float(np.sqrt(g[2][:, 0, 0]).mean()):.2e}", flush=True)
 
