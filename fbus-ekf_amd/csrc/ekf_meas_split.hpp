@@ -179,6 +179,7 @@ correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __res
         // left no registers for them; they arrive while the coefficients go to LDS and the workgroup meets)
         if constexpr (HAS_LATE) {
             load_cov_chunks<T, N, 0, C_E, SEL_XL>(rs, lane, P);
+            order_fence();                                             // (the x_c chunks FIRST: barrier (2) waits for them by count)
             load_chunks<T, N, CN + C_E, RC::NCH, AUX_NT>(rs, lane, P + E0);
         }
         order_fence();
@@ -197,8 +198,11 @@ correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __res
         // (2) the coefficients are in LDS.  (round 6, advisor) vmcnt(0) in front of it: the x_c chunks requested above (SEL_XL) are the
         // very chunks the updater overwrites and stores behind this barrier (its J rows become G P(J, :)); a barrier that waits for LDS
         // only would leave "this wave's loads are served before that wave's later stores" to the ~1.5 k instructions the updater runs
-        // first -- the class of failure ekf_team.hpp:200-204 documents.  The loads have been in flight since before the 64 LDS writes.
-        if constexpr (HAS_LATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // first -- the class of failure ekf_team.hpp:200-204 documents.
+        // Vector memory returns in order: once at most the LATE chunk loads (requested behind them, and stored by nobody else) are
+        // outstanding, the x_c loads have been served -- the late chunks keep flying across the barrier (a full vmcnt(0) here cost
+        // 1.6-2 us at config 3's size: 18.6 / 21.4 us left / stereo, against 15.9-16.1 / 18.2-18.7 with this count; tools/run_configs.py).
+        if constexpr (HAS_LATE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RC::NCH - (CN + C_E)) : "memory");
         meas_barrier();
         if (b < B) applied[b] = apply ? 1 : 0;
         if constexpr (HAS_LATE) {
