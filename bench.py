@@ -454,6 +454,18 @@ def fp64_leg(torch, dev, local_rank, args, capi):
            "note": "per-call API, fp64 kernels (the reference's own arithmetic: same device functions instantiated for double, 1600-byte records)"}
     w.flt.close()
     del w
+    # (round 6) the north star's own update through the fp64 kernels: per call, and one ENTRY-POINT call per camera frame
+    # (fbus_ekf_frame_meas_fused_dev with fp64 records = fbus_ekf_predict_n_dev + the per-call update: two launches per frame instead of
+    # K + 1 -- the one-launch form does not exist for fp64 records)
+    ns = north_star_rows_leg(torch, dev, local_rank, args, capi, B=args.batch, steps=2, warmup=1, dtype=64,
+                             only=("pixels_m4", "fused_frame_pixels_m4"))
+    for name in ("pixels_m4", "fused_frame_pixels_m4"):
+        if name in ns:
+            blk[name] = ns[name]
+    if "fused_frame_pixels_m4" in blk:
+        blk["fused_frame_pixels_m4"]["launch"] = ("fbus_ekf_frame_meas_fused_dev on fp64 records: predict_n (K resident steps) + the per-call update = TWO "
+                                                  "launches per camera frame (no one-launch form for fp64: 86 KiB of LDS per wave would be needed)")
+        blk["fused_frame_pixels_m4"]["vs_per_call"] = blk["fused_frame_pixels_m4"]["value"] / blk["pixels_m4"]["value"]
     # the fp64 kernels past the Infinity Cache: 524 288 filters = 839 MB of 1600-byte records, two input patterns of 168 MB
     # (the fp32 leg of the same name holds 1 048 576 filters: the same bytes)
     if not args.no_hbm_leg and args.batch < MID_LEG_BATCH:
@@ -486,7 +498,7 @@ def _pixels_sq_profile():
         return None
 
 
-def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, warmup=1, hbm_resident=False):
+def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, warmup=1, hbm_resident=False, dtype=32, only=None):
     """The north star's OWN MeasureUpdate -- flat-port refractive stereo reprojection of the ArUco corners, per-corner 2 x N
     Jacobians (fbus_ekf_correct_pixels_dev, csrc/ekf_meas.hpp) -- in the headline's mixed workload: the same 200 Hz + 30 Hz
     schedule (7 / 7 / 6 per-call predicts, then a camera frame; one bench step = 1 s of sensor time = 230 EKF steps per filter)
@@ -505,7 +517,8 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
     torch.cuda.empty_cache()
     out = {}
     prof = _pixels_sq_profile()
-    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    npdt, tdt = (np.float32, torch.float32) if dtype == 32 else (np.float64, torch.float64)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, npdt)).to(dev)          # (the record / input type of this leg)
     if hbm_resident:
         # past the Infinity Cache: 524 288 filters = 419 MB of records (+ 67 MB of image points per camera); what a VALU-bound update and
         # the memory-bound predicts between the frames do when nothing stays cache-resident from launch to launch
@@ -518,6 +531,8 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
              ("fused_window_pixels_m4", 4, "pixels", 18, False, "window"))
     if hbm_resident:
         cases = (("pixels_m4", 4, "pixels", 18, False, False), ("fused_frame_pixels_m4", 4, "pixels", 18, False, True))
+    if only is not None:
+        cases = tuple(c for c in cases if c[0] in only)
     scenes = {}
     for name, slots, kind, nstate, stereo, fused in cases:
         size = 0.15
@@ -529,7 +544,7 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
         prm, nom, rot, ids, left, right = scenes[slots]
         acc, gyr = synth.imu_samples(0, B, 0, sum(PATTERN), nom)
         d_acc, d_gyr = f32(acc), f32(gyr)
-        d_dt = torch.full((max(PATTERN),), 0.005, dtype=torch.float32, device=dev)
+        d_dt = torch.full((max(PATTERN),), 0.005, dtype=tdt, device=dev)
         d_ids, d_left, d_right = torch.from_numpy(ids).to(dev), f32(left), f32(right)
         if fused == "window":
             # one launch per 0.1 s pattern x 10: a bench step as ONE window of 30 frames (200 IMU samples) -- the same frame's image points
@@ -537,12 +552,12 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
             nfr = len(PATTERN) * PATTERNS_PER_STEP
             w_kc = list(PATTERN) * PATTERNS_PER_STEP
             w_acc, w_gyr = d_acc.repeat(PATTERNS_PER_STEP, 1, 1), d_gyr.repeat(PATTERNS_PER_STEP, 1, 1)
-            w_dt = torch.full((sum(w_kc),), 0.005, dtype=torch.float32, device=dev)
+            w_dt = torch.full((sum(w_kc),), 0.005, dtype=tdt, device=dev)
             w_ids, w_left = d_ids.unsqueeze(0).repeat(nfr, 1, 1).contiguous(), d_left.unsqueeze(0).repeat(nfr, 1, 1, 1).contiguous()
             w_right = d_right.unsqueeze(0).repeat(nfr, 1, 1, 1).contiguous() if stereo else None
         nvis = float((ids >= 0).sum(axis=1).mean())
         prev0 = np.zeros(B, np.int32)
-        with BatchedFilter(B, prm, device=local_rank, order_streams=False, nstate=nstate) as flt:
+        with BatchedFilter(B, prm, device=local_rank, order_streams=False, nstate=nstate, dtype=dtype) as flt:
             flt.set_state(nom, rot, None, prev0)
             flt.reset_cov()
             torch.cuda.synchronize()
@@ -579,9 +594,14 @@ def north_star_rows_leg(torch, dev, local_rank, args, capi, B=65536, steps=3, wa
             applied = float(flt.applied().mean())
             finite = bool(np.isfinite(flt.get_state()[0]).all())
             us = u_ms / max(u_n, 1) * 1e3
+            if fused and u_n == 0:                                # fp64 records: the entry point ran predict_n + the per-call update (two launches)
+                pn_ms, pn_n = flt.timing_read(capi.KERNEL_PREDICT_N)
+                c_ms, c_n = flt.timing_read(capi.KERNEL_CORRECT_CORNERS)
+                u_n = c_n
+                us = (pn_ms + c_ms) / max(c_n, 1) * 1e3
             rows = nvis * ((16 if stereo else 8) if kind == "pixels" else 12)
-            rec_b = 4 * (27 + nstate * (nstate + 1) // 2 + 1)
-            bytes_api = 2 * rec_b + 68 * slots      # record round trip + the slot's image points
+            rec_b = (dtype // 8) * (27 + nstate * (nstate + 1) // 2 + 1)
+            bytes_api = 2 * rec_b + (4 + 8 * dtype // 4) * slots      # record round trip + the slot's image points (68 B per slot in fp32)
             blk = {"value": B * STEPS_PER_BENCH_STEP * steps / el, "unit": "EKF steps/s", "ms_per_step": el / steps * 1e3, "steps": steps,
                    "batch": B, "nstate": nstate, "marker_slots": slots, "markers_in_view_mean": nvis, "rows_per_filter_and_frame": rows,
                    "camera": ("stereo" if stereo else "left") if kind == "pixels" else "stereo (triangulated)",
@@ -686,6 +706,7 @@ def compact_line(out):
         optional["fp64"] = dict(_pick(f64, ("value", "ms_per_step")),
                                 predict_us=(f64.get("roofline") or {}).get("avg_launch_us"), frac=(f64.get("roofline") or {}).get("frac"),
                                 fused_frame=(f64.get("fused_frame") or {}).get("value"),
+                                pixels_m4=(f64.get("pixels_m4") or {}).get("value"),
                                 fused_frame_pixels_m4=(f64.get("fused_frame_pixels_m4") or {}).get("value"))
     ns = out.get("north_star_rows")
     if ns:

@@ -556,7 +556,7 @@ def test_frame_window_equals_a_sequence_of_fused_frames(dialect, mode):
             if dtype == 64:
                 assert max(e["literal"], e["sigma"], e["plain"], e["cov"]) <= 1e-9 and e["cov_block"] <= 1e-11
             else:
-                # tests/util.py's window gate: literal 1e-5 (C++ dialect, N = 18: the stated 5e-5 -- util.py); here the block-wise
+                # tests/util.py's window gate: literal 1e-5 (C++ dialect, N = 18: the stated 3e-5 -- util.py); here the block-wise
                 # covariance even meets its single-step bound
                 assert_window_parity(sa, eng.get_state(), f"frame window d{dialect} mode {mode} fp32 (gate)", dialect, 18, verbose=False)
                 assert e["cov_block"] <= COV_BLOCK_TOL

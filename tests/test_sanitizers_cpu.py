@@ -93,6 +93,10 @@ assert lib.fbus_ekf_correct_dev(null, 4, None, None, None, 0, None) == 1
 assert lib.fbus_ekf_set_team(null, 0, 0) == 1 and lib.fbus_ekf_gather(null, None, None) == 1
 assert lib.fbus_ekf_comm_unique_id(None) == 1 and lib.fbus_ekf_comm_destroy(null) == 1
 assert lib.fbus_ekf_records(null, None, None, None) == 1 and lib.fbus_ekf_sync(null) == 1
+assert lib.fbus_ekf_predict_async(null, None, None, None, 0) == 1 and lib.fbus_ekf_predict_n_async(null, 3, None, None, None, 0) == 1
+assert lib.fbus_ekf_correct_async(null, 4, None, None, None, 0, None) == 1 and lib.fbus_ekf_correct_pixels_async(null, 4, None, None, None, None) == 1
+assert lib.fbus_ekf_async_inputs_consumed(null) == 1 and lib.fbus_ekf_async_stats(null, None, None, None) == 1
+assert lib.fbus_ekf_host_register(None, 0) == 1 and lib.fbus_ekf_host_unregister(None) == 1
 assert lib.fbus_ekf_destroy(null) == 0
 assert lib.fbus_status_string(6).decode().startswith("caller and library")
 print("host-asan driver ok")

@@ -140,7 +140,7 @@ F64_TOL = 1e-9
 #             can meet 1e-5 there; the Matlab dialect (7e-6 measured) and every N = 15 case (3e-7) do.  Single steps re-seeded
 #             from the oracle meet 1e-5 in every dialect (assert_parity).
 #   sigma     <= WINDOW_TOL (1e-4), plain <= PLAIN_WINDOW_TOL, cov <= COV_TOL (1e-4), cov-block <= 10 x COV_BLOCK_TOL
-WINDOW_LITERAL_TOL_CPP18 = 5e-5
+WINDOW_LITERAL_TOL_CPP18 = 3e-5          # (round 6: 5e-5 until then; largest measured 2.53e-5, profiles/r06_parity_table.txt -- the kernels are deterministic)
 WINDOW_COV_BLOCK_TOL = 10 * COV_BLOCK_TOL
 
 
