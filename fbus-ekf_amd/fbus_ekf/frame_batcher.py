@@ -18,6 +18,16 @@ class FrameBatcher:
         self.flt, self.B, self.t_state = flt, int(batch), float(state_time)
         self.ema, self.max_buffer, self.trim, self.dtype = bool(ema), int(max_buffer), int(trim), dtype
         self.buf = []                                   # (t, accel[3], gyro[3])
+        self.use_async = False                          # set_async(True): predict_async / correct_async / correct_pixels_async where the filter has them
+
+    def set_async(self, on):
+        """(round 6) queue the calls through the filter's *_async members (fbus_ekf_*_async: arguments by value, nothing waits for the
+        device); results through get_state() are bit-equal to the synchronous sequence"""
+        self.use_async = bool(on)
+
+    def _call(self, name, *args):
+        fn = getattr(self.flt, name + "_async", None) if self.use_async else None
+        return (fn or getattr(self.flt, name))(*args)
 
     def set_imu(self, t, accel, gyro):
         """FILTER::SetImuData (filter.cpp:24-55)"""
@@ -37,7 +47,7 @@ class FrameBatcher:
         ids = np.asarray(ids, np.int32).reshape(-1)
         if ids.size:
             M = ids.size
-            self.flt.correct(np.tile(ids, (self.B, 1)), np.tile(np.asarray(pos, self.dtype).reshape(1, M, 3), (self.B, 1, 1)),
+            self._call("correct", np.tile(ids, (self.B, 1)), np.tile(np.asarray(pos, self.dtype).reshape(1, M, 3), (self.B, 1, 1)),
                              np.tile(np.asarray(quat, self.dtype).reshape(1, M, 4), (self.B, 1, 1)), mode)
         return used
 
@@ -49,7 +59,7 @@ class FrameBatcher:
         if ids.size:
             M = ids.size
             rgt = None if right is None else np.tile(np.asarray(right, self.dtype).reshape(1, M, 8), (self.B, 1, 1))
-            self.flt.correct_pixels(np.tile(ids, (self.B, 1)), np.tile(np.asarray(left, self.dtype).reshape(1, M, 8), (self.B, 1, 1)), rgt)
+            self._call("correct_pixels", np.tile(ids, (self.B, 1)), np.tile(np.asarray(left, self.dtype).reshape(1, M, 8), (self.B, 1, 1)), rgt)
         return used
 
     def _advance_to(self, t_frame):
@@ -63,7 +73,7 @@ class FrameBatcher:
                 break
             consumed += 1
             dt = self.dtype(ts - self.t_state)
-            self.flt.predict(np.tile(a, (self.B, 1)), np.tile(w, (self.B, 1)), float(dt))
+            self._call("predict", np.tile(a, (self.B, 1)), np.tile(w, (self.B, 1)), float(dt))
             self.t_state = ts                           # filter.cpp:516
             used += 1
         del self.buf[:consumed]                         # ClearImuBuffer, filter.cpp:520

@@ -11,6 +11,10 @@
 //                         ObservationUpdate  :622-754      -> Filter::correct (marker choice + hysteresis run
 //                                                          inside the kernel)
 //   on_corner_pixels()  the same pass with the detected markers' corner pixels -> Filter::correct_pixels (north star)
+// (round 6) set_async(true): the same calls through Filter::predict_async / correct_async / correct_pixels_async where the filter has
+// them (fbus::BatchedFilter does: fbus_ekf_*_async, arguments taken by value, nothing waits for the device) -- on_detections() then
+// returns as soon as the frame's steps are queued, as the reference's callers do (SetImuData / SetDetectionResult hand the data over and
+// return, filter.cpp:24-65); results by get_state() are unchanged and bit-equal to the synchronous sequence.
 // Pure sequencing: no filter arithmetic happens here.  `Filter` is fbus::BatchedFilter<Real> (or anything with
 // the same predict/correct members, which is how the CPU test drives it with a recorder).  All B filters of the
 // handle receive the same sensor stream (B hypotheses of one robot); for independent streams call the batched
@@ -67,7 +71,7 @@ public:
                         if (right) quat_[(static_cast<std::size_t>(b) * M + m) * 8 + i] = right[8 * m + i];
                     }
                 }
-            f_.correct_pixels(M, ids_.data(), pos_.data(), right ? quat_.data() : nullptr, nullptr);
+            do_correct_pixels(f_, M, ids_.data(), pos_.data(), right ? quat_.data() : nullptr, 0);
         }
         return used;
     }
@@ -88,16 +92,34 @@ public:
                     for (int i = 0; i < 3; ++i) pos_[(static_cast<std::size_t>(b) * M + m) * 3 + i] = pos[3 * m + i];
                     for (int i = 0; i < 4; ++i) quat_[(static_cast<std::size_t>(b) * M + m) * 4 + i] = quat[4 * m + i];
                 }
-            f_.correct(M, ids_.data(), pos_.data(), quat_.data(), mode, nullptr);
+            do_correct(f_, M, ids_.data(), pos_.data(), quat_.data(), mode, 0);
         }
         return used;
     }
 
+    void set_async(bool on) { async_ = on; }
+    bool async() const { return async_; }
     double state_time() const { return t_state_; }
     void set_state_time(double t) { t_state_ = t; }         // after an init / reset (filter.cpp:378,465)
     std::size_t buffered() const { return buf_.size(); }
 
 private:
+    // the asynchronous member where the filter type has one AND set_async(true) was called, the synchronous one otherwise
+    // (overload ranking: int beats long, so the first form is taken whenever it compiles)
+    template <class F> auto do_predict(F& f, const Real* a, const Real* g, Real dt, int) -> decltype(f.predict_async(a, g, dt), void())
+    { if (async_) f.predict_async(a, g, dt); else f.predict(a, g, dt); }
+    template <class F> void do_predict(F& f, const Real* a, const Real* g, Real dt, long) { f.predict(a, g, dt); }
+    template <class F, typename Mode>
+    auto do_correct(F& f, int M, const std::int32_t* ids, const Real* pos, const Real* quat, Mode mode, int)
+        -> decltype(f.correct_async(M, ids, pos, quat, mode, nullptr), void())
+    { if (async_) f.correct_async(M, ids, pos, quat, mode, nullptr); else f.correct(M, ids, pos, quat, mode, nullptr); }
+    template <class F, typename Mode>
+    void do_correct(F& f, int M, const std::int32_t* ids, const Real* pos, const Real* quat, Mode mode, long) { f.correct(M, ids, pos, quat, mode, nullptr); }
+    template <class F> auto do_correct_pixels(F& f, int M, const std::int32_t* ids, const Real* l, const Real* r, int)
+        -> decltype(f.correct_pixels_async(M, ids, l, r, nullptr), void())
+    { if (async_) f.correct_pixels_async(M, ids, l, r, nullptr); else f.correct_pixels(M, ids, l, r, nullptr); }
+    template <class F> void do_correct_pixels(F& f, int M, const std::int32_t* ids, const Real* l, const Real* r, long) { f.correct_pixels(M, ids, l, r, nullptr); }
+
     // BatchImuProcessing (filter.cpp:483-531): the buffered samples with state time <= t <= t_frame, one predict each
     int advance_to(double t_frame)
     {
@@ -111,7 +133,7 @@ private:
             gyr_.assign(static_cast<std::size_t>(B_) * 3, Real(0));
             for (int b = 0; b < B_; ++b)
                 for (int i = 0; i < 3; ++i) { acc_[3 * b + i] = s.accel[i]; gyr_[3 * b + i] = s.gyro[i]; }
-            f_.predict(acc_.data(), gyr_.data(), dt);       // UpdateCovariance + UpdateNominalState
+            do_predict(f_, acc_.data(), gyr_.data(), dt, 0);    // UpdateCovariance + UpdateNominalState
             t_state_ = s.t;                                 // filter.cpp:516
             ++used;
         }
@@ -123,6 +145,7 @@ private:
     int B_;
     double t_state_;
     bool ema_;
+    bool async_ = false;
     std::size_t max_, trim_;
     std::vector<Sample> buf_;
     std::vector<Real> acc_, gyr_, pos_, quat_;

@@ -268,6 +268,7 @@ int main(int argc, char** argv) {
     auto ids = rd<int32_t>(d + "/ids.bin", M); auto pos = rd<float>(d + "/pos.bin", M * 3), quat = rd<float>(d + "/quat.bin", M * 4);
     flt.set_state(nom.data(), rot.data(), P.data(), prev.data());
     fbus::FrameBatcher<float, F> fb(flt, B, 0.0);
+    fb.set_async(argc > 2);                          // (round 6) the same sequence through fbus_ekf_*_async: queued, not waited for
     double t = 0.0;
     int k = 0, used = 0;
     for (int frame = 0; frame < 2; ++frame) {
@@ -289,6 +290,10 @@ int main(int argc, char** argv) {
     r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     out = np.fromfile(tmp_path / "out.bin", np.float32)
+    # the asynchronous front door (FrameBatcher::set_async: fbus_ekf_predict_async / _correct_async per sample / frame): the same bytes
+    ra = subprocess.run([str(exe), str(tmp_path), "async"], capture_output=True, text=True)
+    assert ra.returncode == 0 and ra.stdout == r.stdout, ra.stdout + ra.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "out.bin", np.uint8), out.view(np.uint8)), "asynchronous front door != synchronous"
     c_nom, c_rot, c_P = out[:B * 19].reshape(B, 19), out[B * 19:B * 28].reshape(B, 9), out[B * 28:B * 352].reshape(B, 18, 18)
     c_prev = np.fromfile(tmp_path / "out.bin", np.int32)[B * 352:]
 
@@ -326,6 +331,22 @@ int main(int argc, char** argv) {
             ok = eng.correct(np.tile(ids0, (B, 1)), np.tile(pos0, (B, 1, 1)), np.tile(quat0, (B, 1, 1)), 0)
             py.correct(np.tile(ids0, (B, 1)), np.tile(pos0, (B, 1, 1)), np.tile(quat0, (B, 1, 1)), 0)
         p_nom, p_rot, p_P, p_prev = py.get_state()
+    # (round 6) the Python twin of the front door with set_async(True): every step queued through fbus_ekf_*_async, bit-equal
+    from fbus_ekf import FrameBatcher
+    with BatchedFilter(B, prm) as pa:
+        pa.set_state(nom, rot, P, prev)
+        fbp = FrameBatcher(pa, B, 0.0)
+        fbp.set_async(True)
+        ta, ka = 0.0, 0
+        for frame in range(2):
+            for _ in range(11 if frame else 12):
+                ta += 0.005
+                fbp.set_imu(ta, imu_a[ka], imu_w[ka])
+                ka += 1
+            fbp.on_detections(ta - 0.001, ids0, pos0, quat0, 0)
+        assert pa.async_stats()["calls"] == used + 2
+        a_nom, _, a_P, a_prev = pa.get_state()
+    assert np.array_equal(a_nom, p_nom) and np.array_equal(a_P, p_P) and np.array_equal(a_prev, p_prev)
     assert r.stdout.strip() == f"used {used} buffered {len(buf)}"
     # C++ mirror == Python mirror, call for call (same library, same launches)
     assert np.array_equal(c_nom, p_nom.astype(np.float32)) and np.array_equal(c_P, p_P.astype(np.float32))
