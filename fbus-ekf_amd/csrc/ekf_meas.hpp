@@ -1081,6 +1081,9 @@ __device__ __forceinline__ void meas_solve_update(T* P, const PixAcc& acc, const
 }
 
 // the tail both per-call measurement kernels share: the sums -> information matrix -> 6 x 6 stage -> update -> injection -> stores
+// (Round 6 tried two things around it, both measured slower and kept as patches only: the covariance through LDS while the fold runs --
+// gfx950's direct-to-LDS 16-byte loads, requested at the top of the kernel or behind the last marker's fetch, tools/patches/
+// r06_meas_lds_prefetch.diff -- and the left camera's markers two at a time, tools/patches/r06_meas_pair.diff; EXPERIMENTS -1.5.)
 template <typename T, int N>
 __device__ __forceinline__ void meas_update_tail(const __amdgpu_buffer_rsrc_t rs, unsigned lane, const PixAcc& acc, const double* Rd, double w,
                                                  int new_prev, T* gpark /* fp64 records: this lane's column of 36 x 64 values in LDS */)
@@ -1174,85 +1177,6 @@ __device__ __forceinline__ void meas_update_tail(const __amdgpu_buffer_rsrc_t rs
     store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);
 }
 
-// ---- (round 6, MEASURED AND NOT KEPT: the switch below is 0) the covariance on its way in WHILE the fold runs: direct-to-LDS loads ----
-// The one-wave fp32 kernels hold ~390 registers of doubles during the fold: there is no room for the covariance, so it is requested
-// BEHIND the fold.  gfx950 has 16-byte buffer loads that write LDS directly (buffer_load_dwordx4 ... lds: no VGPR, the wave's 64 lanes
-// land lane-major in 1 KiB -- exactly a record tile's chunk; tools/exp_lds_dma.hip confirms the layout on the device).  With the switch
-// on, the chunks ImuUpdate can change (N = 18: 33 of 43, N = 15: all 31 -- what frame_meas_kernel parks: 33 KiB per wave, 37.5 KiB with
-// the marker table, four workgroups per CU) are requested in front of the fold and read back from LDS behind it, the predict-invariant
-// tail (10 chunks) from L2 under the 6 x 6 stage.  Bit-equal to meas_update_tail (the GPU suite passes either way).
-// Alternating A/B at 65 536 filters (profiles/r06_meas_prefetch_ab.txt): 16 slots left 65.8 / 67.1 us against 64.6 / 65.3 without, stereo
-// 107.6 / 103.9 against 101.5 / 102.0, 4 slots stereo 46.4 / 44.8 against 41.6 / 42.0, corners +-1: SLOWER.  The load behind the fold was
-// already hidden -- the 6 x 6 stage needs only the chunks of P(J, J), which arrive first, and direct_update follows ~3 us later -- while
-// 33 KiB per wave requested by all four waves of a CU at the top of the kernel stand in front of the p, q, R chunks and the marker
-// fetches the fold is waiting for (vector memory returns in order), and the covariance makes an extra trip through LDS.
-#ifndef FBUS_X_MEAS_LDS_PREFETCH
-#define FBUS_X_MEAS_LDS_PREFETCH 0
-#endif
-template <typename T, int N>
-constexpr int meas_prefetch_chunks() { return Rec<T, N>::CH_VAR_END - Rec<T, N>::CH_NOM; }
-
-template <typename T, int N>
-__device__ __forceinline__ void meas_prefetch_cov(const __amdgpu_buffer_rsrc_t rs, unsigned lane, u32x4* park_mem)
-{
-    using RC = Rec<T, N>;
-    constexpr int PCH = meas_prefetch_chunks<T, N>();
-    const unsigned off = lane * 16u;
-#pragma unroll
-    for (int i = 0; i < PCH; ++i) {
-        const int c = RC::CH_NOM + i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(park_mem + i * 64), 16, off + (c & 3) * 1024u,
-                                                 (c >> 2) * 4096, 0, AUX_NT);
-    }
-}
-
-// meas_update_tail for fp32 records whose first PCH covariance chunks wait in LDS (meas_prefetch_cov)
-template <typename T, int N>
-__device__ __forceinline__ void meas_update_tail_lds(const __amdgpu_buffer_rsrc_t rs, unsigned lane, const PixAcc& acc, const double* Rd, double w,
-                                                     int new_prev, const u32x4* park /* this lane's slot of chunk 0 */)
-{
-    static_assert(sizeof(T) == 4, "fp32 records");
-    using L = Lay<N>;
-    using RC = Rec<T, N>;
-    constexpr int EPC = RC::EPC, PCH = meas_prefetch_chunks<T, N>();
-    T P[RC::NCOVP];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the prefetch (requested a whole fold ago) and the last marker fetch
-#pragma unroll
-    for (int c = 0; c < PCH; ++c) {
-        const u32x4 v = park[c * 64];
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int k = 0; k < EPC; ++k) P[c * EPC + k] = e[k];
-    }
-    order_fence();
-    // the predict-invariant tail: from L2 / the Infinity Cache, under the 6 x 6 stage
-    if constexpr (RC::CH_VAR_END < RC::NCH) load_chunks<T, N, RC::CH_VAR_END, RC::NCH, AUX_NT>(rs, lane, P + PCH * EPC);
-    double Lam[21], bv[6];
-    acc.finish(Rd, w, Lam, bv);
-    T dx[N];
-    {
-        T G[36], Sinv[21], m[6];
-        {
-            double PJJ[36];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) PJJ[6 * i + j] = (double)P[pidx<N>(jcol(i), jcol(j))];
-            info_solve<T>(Lam, bv, PJJ, G, Sinv, m);
-        }
-        RegCoef<T> cf;
-        cf.set(G, Sinv, m);
-        direct_update<T, N>(P, dx, cf);
-    }
-    T nom[L::NNOM];
-    load_chunks<T, N, 0, RC::CH_NOM>(rs, lane, nom);
-    inject<T, N>(nom, dx);
-    if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
-    store_chunks<T, N, 0, RC::CH_PQ, FBUS_X_CORRECT_ST>(rs, lane, nom);
-    store_chunks<T, N, RC::CH_PQR, RC::CH_NOM, FBUS_X_CORRECT_ST>(rs, lane, nom + L::NPQR);
-    store_chunks<T, N, RC::CH_NOM, RC::NCH, FBUS_X_CORRECT_ST>(rs, lane, P);
-}
-
 // Marker map of the pixel fold in LDS: id -> slot (the table of the other kernels) and the double-precision corner frame of
 // every slot.
 struct alignas(16) MeasLDS {
@@ -1286,9 +1210,6 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     constexpr int PART_N = NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1, GPARK_N = sizeof(T) == 8 ? 36 * 64 : 1;
     __shared__ double part_mem[PART_N > GPARK_N ? PART_N : GPARK_N];
     T* gpark_mem = reinterpret_cast<T*>(part_mem);
-    // (round 6) fp32, one wave per tile: the covariance chunks ImuUpdate can change come in through LDS while the fold runs
-    constexpr bool PREFETCH = FBUS_X_MEAS_LDS_PREFETCH && sizeof(T) == 4 && NR == 1;
-    __shared__ u32x4 park_mem[PREFETCH ? meas_prefetch_chunks<T, N>() * 64 : 1];
     struct Meas { int id; T l[8], r[8]; };
     const bool stereo = right != nullptr;
     // the id and the 8 (+ 8) image coordinates of marker slot i: 16-byte loads (a slot's 8 coordinates are 32 / 64 contiguous bytes)
@@ -1328,7 +1249,6 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         order_fence();
         load_chunks<T, N, 0, RC::CH_PQR>(rs, lane, pqr);
         order_fence();
-        if constexpr (PREFETCH) { meas_prefetch_cov<T, N>(rs, lane, park_mem); order_fence(); }
 #pragma unroll
         for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; if (i < NI) di[i] = vi[q]; }
 #pragma unroll
@@ -1381,11 +1301,8 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
             nfold += part[PixAcc::NVAL * 64];
         }
     }
-    // (a wave must not end with direct-to-LDS loads in flight: its LDS may belong to the next workgroup by the time they land)
-    if constexpr (PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
-    if constexpr (PREFETCH) meas_update_tail_lds<T, N>(rs, lane, acc, Rd, 1.0 / r_pix, -1, park_mem + lane);
-    else meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pix, -1, gpark_mem + lane);
+    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pix, -1, gpark_mem + lane);
     applied[b] = 1;
 }
 
@@ -1417,9 +1334,6 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
     constexpr int PART_N = NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1, GPARK_N = sizeof(T) == 8 ? 36 * 64 : 1;
     __shared__ double part_mem[PART_N > GPARK_N ? PART_N : GPARK_N];
     T* gpark_mem = reinterpret_cast<T*>(part_mem);
-    // (round 6) fp32, one wave per tile: the covariance chunks ImuUpdate can change come in through LDS while the fold runs
-    constexpr bool PREFETCH = FBUS_X_MEAS_LDS_PREFETCH && sizeof(T) == 4 && NR == 1;
-    __shared__ u32x4 park_mem[PREFETCH ? meas_prefetch_chunks<T, N>() * 64 : 1];
     struct Meas { int id; T l[12], r[8]; };
     const bool c3d = geometry == VIS_CORNERS3D;
     const int lw = c3d ? 12 : 8;
@@ -1482,7 +1396,6 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
         order_fence();
         load_chunks<T, N, 0, RC::CH_PQR>(rs, lane, pqr);
         order_fence();
-        if constexpr (PREFETCH) { meas_prefetch_cov<T, N>(rs, lane, park_mem); order_fence(); }
 #pragma unroll
         for (int q = 0; q < PI; ++q) { const int i = threadIdx.x + q * NT; if (i < NI) di[i] = vi[q]; }
 #pragma unroll
@@ -1563,11 +1476,9 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
             nfold += part[PixAcc::NVAL * 64];
         }
     }
-    if constexpr (PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (see correct_pixels2_kernel)
     if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
     acc.expand_const(mc.NI);
-    if constexpr (PREFETCH) meas_update_tail_lds<T, N>(rs, lane, acc, Rd, 1.0 / r_pos, new_prev, park_mem + lane);
-    else meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pos, new_prev, gpark_mem + lane);
+    meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pos, new_prev, gpark_mem + lane);
     applied[b] = 1;
 }
 
