@@ -299,12 +299,17 @@ __device__ __forceinline__ void filter_pil(const double* R, const double* P_IL, 
 // refractinfo.yml:10-13: normal_vector 0 0 1).  Then z = X_z, the lateral offset is (X_x, X_y, 0), D_z = 1 (no division), and in the
 // row  a = alpha e'M + beta n'M + k (M_r - uv_r M_z)  the two k uv_r M_z terms cancel: a = c1 e_r (e'M) + k M_r - c2 e_r M_z --
 // ~60 of ~360 instructions per corner less.  Any other normal takes the general form (tests/test_pixels_gpu.py: a tilted port).
-template <int NCAM, typename T, bool NZ>
+// NK, K0 (round 6): the corners K0 .. K0 + NK - 1 of the marker only (NK = 4, K0 = 0: all of them).  The stereo fold of the one-wave
+// kernels takes a marker as two passes of two corners x two cameras (pixel_fold_marker_stereo_halves): four projections in lock step, the
+// left-camera fold's working set, instead of eight -- the eight-projection stage spilled ~300 v_accvgpr moves per marker (EXPERIMENTS -1.7:
+// 2388 -> 2161 instructions per marker in the compiled loop, 16 slots stereo 100-102 -> 93-96 us).
+template <int NCAM, typename T, bool NZ, int NK = 4, int K0 = 0>
 __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, const double* R, const double* pil,
                                                   const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size)
 {
+    static_assert(NK >= 1 && K0 >= 0 && K0 + NK <= 4, "corners of one marker");
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;           // Newton steps behind v_rsq_f64 / v_rcp_f64
-    constexpr int NP = 4 * NCAM;
+    constexpr int NP = NK * NCAM;
     double ru[4][3], rAx[3], rAy[3];
     {
         double u0[3], ru0[3];
@@ -344,11 +349,11 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
                 MAy[i] = M[3 * i] * rAy[0] + M[3 * i + 1] * rAy[1] + M[3 * i + 2] * rAy[2];
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                X[0 * NCAM + c][i] = X0[i];
-                X[1 * NCAM + c][i] = X0[i] + MAy[i];
-                X[2 * NCAM + c][i] = X0[i] + MAy[i] + MAx[i];
-                X[3 * NCAM + c][i] = X0[i] + MAx[i];
+            for (int k = 0; k < NK; ++k) {
+                const int kk = K0 + k;                   // corner 0: X0, 1: X0 + MAy, 2: (X0 + MAy) + MAx, 3: X0 + MAx
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    X[k * NCAM + c][i] = kk == 0 ? X0[i] : (kk == 1 ? X0[i] + MAy[i] : (kk == 2 ? X0[i] + MAy[i] + MAx[i] : X0[i] + MAx[i]));
             }
         }
         if constexpr (NZ) {
@@ -464,7 +469,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         // a_r = vis (c1 e_r (e'M) + k M_r - c2 e_r M_z)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const int k = q / NCAM, c = q % NCAM;
+            const int k = K0 + q / NCAM, c = q % NCAM;
             const double* M = c ? mc.McR : mc.McL;
             const T* y = c ? yr : yl;
             const double c1v = (iLt[q] - kk[q]) * vis[q], c2v = c2[q] * vis[q], kv = kk[q] * vis[q];
@@ -497,7 +502,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         // rows: J_r = alpha e' + beta n' + k g',  g = (unit_r - uv_r unit_z) / D_z;  a = (J_r Mc)' masked by visibility
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const int k = q / NCAM, c = q % NCAM;
+            const int k = K0 + q / NCAM, c = q % NCAM;
             const double* M = c ? mc.McR : mc.McL;
             const double* nM = c ? mc.nMR : mc.nML;
             const T* y = c ? yr : yl;
@@ -516,13 +521,13 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
     if constexpr (NCAM == 1) {
         // two rows per corner: straight into the sums (PixAcc::add_row)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NK; ++k)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) acc.add_row(a[k][r], res[k][r], ru[k]);
+            for (int r = 0; r < 2; ++r) acc.add_row(a[k][r], res[k][r], ru[K0 + k]);
     } else {
-        double Np[4][6], np[4][3];
+        double Np[NK][6], np[NK][3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) Np[k][i] = 0.0;
 #pragma unroll
@@ -533,7 +538,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NK; ++k) {
                     const double* ar = a[k * NCAM + c][r];
                     Np[k][0] += ar[0] * ar[0]; Np[k][1] += ar[0] * ar[1]; Np[k][2] += ar[0] * ar[2];
                     Np[k][3] += ar[1] * ar[1]; Np[k][4] += ar[1] * ar[2]; Np[k][5] += ar[2] * ar[2];
@@ -541,9 +546,21 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
                     for (int j = 0; j < 3; ++j) np[k][j] += ar[j] * res[k * NCAM + c][r];
                 }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc.add_corner(Np[k], np[k], ru[k]);
+        for (int k = 0; k < NK; ++k) acc.add_corner(Np[k], np[k], ru[K0 + k]);
     }
 }
+
+// one marker, both cameras, as two passes of two corners each (see NK, K0 above): the same projections, rows and sums, corner by corner
+// in the same order -- bit-equal to pixel_fold_marker<2, T, NZ>
+template <typename T, bool NZ>
+__device__ __forceinline__ void pixel_fold_marker_stereo_halves(PixAcc& acc, const double* p, const double* R, const double* pil,
+                                                                const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size)
+{
+    pixel_fold_marker<2, T, NZ, 2, 0>(acc, p, R, pil, mc, mkc, yl, yr, size);
+    order_fence();
+    pixel_fold_marker<2, T, NZ, 2, 2>(acc, p, R, pil, mc, mkc, yl, yr, size);
+}
+
 
 // ---- correct() from stereo CORNERS: triangulation through the port in double, 3 position-type rows per corner ----------------
 // vision.cpp:496-599 for the four corners of one marker (the arithmetic of vision_device.hpp::refraction_corner, in double and
@@ -1189,7 +1206,7 @@ struct alignas(16) MeasLDS {
 // linearisation point.  One filter per lane; NR waves ("roles") per 64-filter tile divide the markers among themselves
 // (role r folds markers r, r + NR, ...; their sums meet in LDS, in role order) and role 0 applies the update.
 // =================================================================================
-template <typename T, int N, int NR, bool NZ>
+template <typename T, int N, int NR, bool NZ, int CAM = 0>
 __global__ void __launch_bounds__(64 * NR)
 correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict__ ids, const T* __restrict__ left,
                        const T* __restrict__ right, double size, double r_pix, const unsigned char* __restrict__ skip,
@@ -1210,8 +1227,10 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
     constexpr int PART_N = NR > 1 ? (NR - 1) * (PixAcc::NVAL + 1) * 64 : 1, GPARK_N = sizeof(T) == 8 ? 36 * 64 : 1;
     __shared__ double part_mem[PART_N > GPARK_N ? PART_N : GPARK_N];
     T* gpark_mem = reinterpret_cast<T*>(part_mem);
-    struct Meas { int id; T l[8], r[8]; };
-    const bool stereo = right != nullptr;
+    // CAM: 0 = left camera or stereo by the right pointer (one kernel for both), 1 = left camera only, 2 = stereo only: compiled
+    // apart, the left-camera kernel carries neither the second camera's image points nor the stereo fold's register pressure
+    struct Meas { int id; T l[8], r[CAM == 1 ? 1 : 8]; };
+    const bool stereo = CAM == 0 ? right != nullptr : CAM == 2;
     // the id and the 8 (+ 8) image coordinates of marker slot i: 16-byte loads (a slot's 8 coordinates are 32 / 64 contiguous bytes)
     auto fetch = [&](int i, Meas& mm) __attribute__((always_inline)) {
         const size_t o = (size_t)bc * M + i;
@@ -1221,11 +1240,16 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         const u32x4* pr = reinterpret_cast<const u32x4*>((stereo ? right : left) + o * 8);
 #pragma unroll
         for (int c = 0; c < 8 / EP; ++c) {
-            const u32x4 vl = pl[c], vr = pr[c];
+            const u32x4 vl = pl[c];
             const T* el = reinterpret_cast<const T*>(&vl);
-            const T* er = reinterpret_cast<const T*>(&vr);
 #pragma unroll
-            for (int k = 0; k < EP; ++k) { mm.l[c * EP + k] = el[k]; mm.r[c * EP + k] = er[k]; }
+            for (int k = 0; k < EP; ++k) mm.l[c * EP + k] = el[k];
+            if constexpr (CAM != 1) {
+                const u32x4 vr = pr[c];
+                const T* er = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+                for (int k = 0; k < EP; ++k) mm.r[c * EP + k] = er[k];
+            }
         }
     };
     Meas cur, nxt;
@@ -1276,7 +1300,9 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
             double mk[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-            if (stereo) pixel_fold_marker<2, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+            if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
+            else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+            else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
             else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
             nfold += 1.0;
         }
@@ -1504,7 +1530,7 @@ correct_corners2_kernel(T* __restrict__ recs, int B, int M, const int* __restric
 // =================================================================================
 template <typename T> struct QDiag { T qd[4]; };      // (MEAS_PIXELS / MEAS_CORNERS: ekf_launch.hpp)
 
-template <typename T, int N, int DIALECT, int KIND, bool NZ, bool WINDOW = false>
+template <typename T, int N, int DIALECT, int KIND, bool NZ, bool WINDOW = false, int CAM = 0>
 __global__ void __launch_bounds__(64)
 frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* __restrict__ accel, const T* __restrict__ gyro,
                   const T* __restrict__ dt, int dt_stride, int M, const int* __restrict__ ids, const T* __restrict__ left,
@@ -1526,10 +1552,11 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
     __shared__ MeasLDS tbl;
     __shared__ u32x4 park_mem[PCH * 64];
     u32x4* park = park_mem + lane;
-    const bool stereo = right != nullptr;
+    // CAM (pixel rows): 0 = left camera or stereo by the right pointer, 1 = left camera only, 2 = stereo only (correct_pixels2_kernel's)
+    const bool stereo = (KIND == MEAS_PIXELS && CAM != 0) ? CAM == 2 : right != nullptr;
     const bool c3d = KIND == MEAS_CORNERS && geometry == VIS_CORNERS3D;
     const int lw = c3d ? 12 : 8;
-    struct Meas { int id; T l[KIND == MEAS_CORNERS ? 12 : 8], r[8]; };
+    struct Meas { int id; T l[KIND == MEAS_CORNERS ? 12 : 8], r[(KIND == MEAS_PIXELS && CAM == 1) ? 1 : 8]; };
     // the id and the image coordinates of marker slot i (16-byte loads; the layouts of correct_pixels2 / correct_corners2_kernel)
     auto fetch = [&](int i, Meas& mm) __attribute__((always_inline)) {
         const size_t o = (fo + (size_t)bc) * M + i;
@@ -1540,11 +1567,16 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
         if constexpr (KIND == MEAS_PIXELS) {
 #pragma unroll
             for (int c = 0; c < 8 / EP; ++c) {
-                const u32x4 vl = pl[c], vr = pr[c];
+                const u32x4 vl = pl[c];
                 const T* el = reinterpret_cast<const T*>(&vl);
-                const T* er = reinterpret_cast<const T*>(&vr);
 #pragma unroll
-                for (int k = 0; k < EP; ++k) { mm.l[c * EP + k] = el[k]; mm.r[c * EP + k] = er[k]; }
+                for (int k = 0; k < EP; ++k) mm.l[c * EP + k] = el[k];
+                if constexpr (CAM != 1) {
+                    const u32x4 vr = pr[c];
+                    const T* er = reinterpret_cast<const T*>(&vr);
+#pragma unroll
+                    for (int k = 0; k < EP; ++k) mm.r[c * EP + k] = er[k];
+                }
             }
         } else {
 #pragma unroll
@@ -1661,7 +1693,9 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
                 double mk[9];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-                if (stereo) pixel_fold_marker<2, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+                if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
+                else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+                else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
                 else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
                 nfold += 1.0;
             }

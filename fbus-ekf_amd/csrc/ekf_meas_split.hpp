@@ -131,7 +131,7 @@ correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __res
                 double mk[9];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-                if (stereo) pixel_fold_marker<2, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
+                if (stereo) pixel_fold_marker_stereo_halves<T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
                 else pixel_fold_marker<1, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
                 nfold += 1.0;
             }

@@ -237,9 +237,20 @@ void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
         else hipLaunchKernelGGL((correct_pixels2_kernel<T, N, NR, false>), dim3(tiles), dim3(64 * NR), 0, s, recs, B, M, ids, left, \
                                 right, size, r_pix, skip, applied, id2slot, mc);                                         \
     } while (0)
-    if (roles >= 3) FBUS_LAUNCH_PX(4);
-    else if (roles == 2) FBUS_LAUNCH_PX(2);
-    else FBUS_LAUNCH_PX(1);
+    if (roles >= 3) { FBUS_LAUNCH_PX(4); return; }
+    if (roles == 2) { FBUS_LAUNCH_PX(2); return; }
+    if constexpr (sizeof(T) == 4) {
+        // (round 6) one wave per tile, square port, fp32 records -- the full-chip production case: the left-camera and the stereo update as
+        // kernels of their own (CAM = 1 / 2: neither carries the other's image points and register pressure; EXPERIMENTS -1.7)
+        if (nz) {
+            if (right) hipLaunchKernelGGL((correct_pixels2_kernel<T, N, 1, true, 2>), dim3(tiles), dim3(64), 0, s, recs, B, M, ids, left, right,
+                                          size, r_pix, skip, applied, id2slot, mc);
+            else hipLaunchKernelGGL((correct_pixels2_kernel<T, N, 1, true, 1>), dim3(tiles), dim3(64), 0, s, recs, B, M, ids, left, right, size,
+                                    r_pix, skip, applied, id2slot, mc);
+            return;
+        }
+    }
+    FBUS_LAUNCH_PX(1);
 #undef FBUS_LAUNCH_PX
 }
 template <typename T, int N, int D>
@@ -285,17 +296,26 @@ void launch_frame_meas_k(hipStream_t s, T* recs, int B, int F, const unsigned ch
     // the port square to the camera (the reference's configuration): the shorter fold / triangulation, as the per-call launchers choose
     const bool nz = (kind == MEAS_PIXELS) ? (mc.n[0] == 0.0 && mc.n[1] == 0.0 && mc.n[2] == 1.0)
                                           : (vc.nrm[0] == 0.0 && vc.nrm[1] == 0.0 && vc.nrm[2] == 1.0);
-#define FBUS_LAUNCH_FM(KIND, NZF)                                                                                        \
+#define FBUS_LAUNCH_FM(KIND, NZF, CAM)                                                                                   \
     do {                                                                                                                 \
-        if (F > 1) hipLaunchKernelGGL((frame_meas_kernel<T, N, D, KIND, NZF, true>), dim3(tiles), dim3(64), 0, s, recs, B, F, kc, accel, \
+        if (F > 1) hipLaunchKernelGGL((frame_meas_kernel<T, N, D, KIND, NZF, true, CAM>), dim3(tiles), dim3(64), 0, s, recs, B, F, kc, accel, \
                                       gyro, dt, dt_stride, M, ids, left, right, geometry, mode, size, r_meas, switch_thres, skip, \
                                       applied, id2slot, mc, vc, vct, q);                                                 \
-        else hipLaunchKernelGGL((frame_meas_kernel<T, N, D, KIND, NZF, false>), dim3(tiles), dim3(64), 0, s, recs, B, F, kc, accel, \
+        else hipLaunchKernelGGL((frame_meas_kernel<T, N, D, KIND, NZF, false, CAM>), dim3(tiles), dim3(64), 0, s, recs, B, F, kc, accel, \
                                 gyro, dt, dt_stride, M, ids, left, right, geometry, mode, size, r_meas, switch_thres, skip,  \
                                 applied, id2slot, mc, vc, vct, q);                                                       \
     } while (0)
-    if (kind == MEAS_PIXELS) { if (nz) FBUS_LAUNCH_FM(MEAS_PIXELS, true); else FBUS_LAUNCH_FM(MEAS_PIXELS, false); }
-    else                     { if (nz) FBUS_LAUNCH_FM(MEAS_CORNERS, true); else FBUS_LAUNCH_FM(MEAS_CORNERS, false); }
+    // (round 6) pixel rows, square port: the left-camera and the stereo frame as kernels of their own (CAM = 1 / 2, as correct_pixels2_kernel)
+    if (kind == MEAS_PIXELS) {
+        if (nz) {
+            // stereo and the left-camera WINDOW as kernels of their own (CAM = 2 / 1: +2-3 % / +2-5 %); the single left-camera frame keeps
+            // the combined kernel (the left-only one measured 1 % slower there: profiles/r06_meas_cam_ab.txt)
+            if (right) FBUS_LAUNCH_FM(MEAS_PIXELS, true, 2);
+            else if (F > 1) FBUS_LAUNCH_FM(MEAS_PIXELS, true, 1);
+            else FBUS_LAUNCH_FM(MEAS_PIXELS, true, 0);
+        } else FBUS_LAUNCH_FM(MEAS_PIXELS, false, 0);
+    }
+    else                     { if (nz) FBUS_LAUNCH_FM(MEAS_CORNERS, true, 0); else FBUS_LAUNCH_FM(MEAS_CORNERS, false, 0); }
 #undef FBUS_LAUNCH_FM
 }
 #define FBUS_INST(D)                                                                                                   \
