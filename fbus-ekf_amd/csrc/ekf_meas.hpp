@@ -856,70 +856,13 @@ struct RegCoef {
         for (int i = 0; i < 6; ++i) m_[i] = M_[i];
     }
 };
+template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES = 3>
+__device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf);
+// (round 6) the whole covariance = the part form over the full storage range: ONE body (below) for every kernel that applies the update
 template <typename T, int N, typename COEF>
 __device__ __forceinline__ void direct_update(T* P, T* dx, const COEF& cf)
 {
-#define PS(i, j) P[pidx<N>((i), (j))]
-    constexpr int NR_ = N - 6;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        T s = PS(i, jcol(0)) * cf.m(0);
-#pragma unroll
-        for (int k = 1; k < 6; ++k) s += PS(i, jcol(k)) * cf.m(k);
-        dx[i] = s;
-    }
-    // the block outside J, column by column: t = Sinv x_c, then P(a, c) -= x_a . t for the columns a <= c (the x are still the old ones)
-#pragma unroll
-    for (int c = 0; c < NR_; ++c) {
-        T t[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            T s = cf.S(0, i) * PS(jcol(0), rcol(c));
-#pragma unroll
-            for (int j = 1; j < 6; ++j) s += cf.S(j, i) * PS(jcol(j), rcol(c));
-            t[i] = s;
-        }
-#pragma unroll
-        for (int a = 0; a <= c; ++a) {
-            T s = PS(jcol(0), rcol(a)) * t[0];
-#pragma unroll
-            for (int k = 1; k < 6; ++k) s += PS(jcol(k), rcol(a)) * t[k];
-            PS(rcol(a), rcol(c)) -= s;
-        }
-    }
-    // the J x J block from the old values (upper triangle of G P_JJ), then the J x r columns in place
-    {
-        T nj[21];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) {
-                T s = cf.G(i, 0) * PS(jcol(0), jcol(j));
-#pragma unroll
-                for (int k = 1; k < 6; ++k) s += cf.G(i, k) * PS(jcol(k), jcol(j));
-                nj[lidx(i, j)] = s;
-            }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) PS(jcol(i), jcol(j)) = nj[lidx(i, j)];
-    }
-#pragma unroll
-    for (int c = 0; c < NR_; ++c) {
-        T x[6], y[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) x[j] = PS(jcol(j), rcol(c));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            T s = cf.G(i, 0) * x[0];
-#pragma unroll
-            for (int j = 1; j < 6; ++j) s += cf.G(i, j) * x[j];
-            y[i] = s;
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) PS(jcol(i), rcol(c)) = y[i];
-    }
-#undef PS
+    direct_update_part<T, N, 0, Lay<N>::NP, true, COEF, 3>(P, dx, cf);
 }
 
 // ---- the update in two PARTS of the packed covariance (round 5) ----------------------------------------------------------------
@@ -969,6 +912,20 @@ __device__ __forceinline__ void load_cov_chunks(__amdgpu_buffer_rsrc_t rs, unsig
     });
 }
 
+#ifndef FBUS_X_PACK_UPDATE
+#define FBUS_X_PACK_UPDATE 1
+#endif
+// coef * x + acc on a register pair as ONE fused operation per half, spelled out: which products of a sum the compiler contracts into
+// FMAs differs from kernel to kernel for the packed form (the fused frame's update and the per-call update stopped agreeing bit for bit
+// when this was left to it), and the explicit fma is what the scalar form's contraction gives
+__device__ __forceinline__ f32x2 pk_fma(float coef, f32x2 x, f32x2 acc) { return __builtin_elementwise_fma(f32x2{ coef, coef }, x, acc); }
+// ... and the scalar chains of the update the same way: s = a0 b0, then s = fma(a_k, b_k, s) -- in `a0 b0 + a1 b1` either product may be the
+// one the compiler fuses, and it chose differently in different kernels once the update had one body for all of them
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// columns rcol(c), rcol(c + 1) outside J are neighbours that start on an even state index: an aligned storage pair in every row above them
+template <int N>
+constexpr bool upd_pair_head(int c) { return c + 1 < N - 6 && rcol(c) % 2 == 0 && rcol(c + 1) == rcol(c) + 1; }
 // which elements of the three groups of direct_update lie in the storage range [LO, HI)
 template <int N, int LO, int HI> constexpr bool in_part(int i, int j) { return pidx<N>(i, j) >= LO && pidx<N>(i, j) < HI; }
 template <int N, int LO, int HI> constexpr bool part_any_rr(int c) { bool a_ = false; for (int a = 0; a <= c; ++a) a_ = a_ || in_part<N, LO, HI>(rcol(a), rcol(c)); return a_; }
@@ -981,7 +938,7 @@ template <int N, int LO, int HI> constexpr bool part_all_jr(int c) { bool a_ = t
 // element it touches, in the same order.  P is the full-size array; every element of the J rows / columns that the touched elements
 // need must be loaded (x_c = P(J, c)); WANT_DX: dx = P(:, J) m as well (needs all of the J rows).  PHASES: 1 = the block outside J
 // (reads S^-1), 2 = the J rows (reads G), 3 = both -- the fp64 tail runs them one after the other with only that phase's coefficients live.
-template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES = 3>
+template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES>
 __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
 {
 #define PS(i, j) P[pidx<N>((i), (j))]
@@ -992,20 +949,60 @@ __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
         for (int i = 0; i < N; ++i) {
             T s = PS(i, jcol(0)) * cf.m(0);
 #pragma unroll
-            for (int k = 1; k < 6; ++k) s += PS(i, jcol(k)) * cf.m(k);
+            for (int k = 1; k < 6; ++k) s = fma_t(PS(i, jcol(k)), cf.m(k), s);
             dx[i] = s;
         }
     }
+    // (round 6) fp32, pair-aligned storage: two neighbouring columns (c, c + 1) of the block outside J / of the J rows at a time on packed
+    // instructions (v_pk_mul / v_pk_fma_f32: two columns per issue slot) -- every element sees the operations of the scalar form in the
+    // same order (each half of a packed operation IS the scalar operation), so the results are the scalar form's bit for bit
+    constexpr bool PK = PackedMath<T, N>::on && FBUS_X_PACK_UPDATE;
     // the block outside J, column by column: t = Sinv x_c, then P(a, c) -= x_a . t for the columns a <= c (the x are still the old ones)
     static_for<0, NR_>([&](auto c_) {
         constexpr int c = decltype(c_)::value;
-        if constexpr (part_any_rr<N, LO, HI>(c) && (PHASES & 1)) {
+        constexpr bool head = PK && upd_pair_head<N>(c), tail = PK && c >= 1 && upd_pair_head<N>(c - 1);
+        if constexpr (tail) {
+            // (done with column c - 1)
+        } else if constexpr (head && (PHASES & 1) && (part_any_rr<N, LO, HI>(c) || part_any_rr<N, LO, HI>(c + 1))) {
+            if constexpr (sizeof(T) == 4) {
+                f32x2 xv[6], tv[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) xv[j] = f32x2{ PS(jcol(j), rcol(c)), PS(jcol(j), rcol(c + 1)) };
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    f32x2 sv = cf.S(0, i) * xv[0];
+#pragma unroll
+                    for (int j = 1; j < 6; ++j) sv = pk_fma(cf.S(j, i), xv[j], sv);
+                    tv[i] = sv;
+                }
+                static_for<0, c + 2>([&](auto a_) {
+                    constexpr int a = decltype(a_)::value;
+                    constexpr bool in0 = a <= c && INR(rcol(a), rcol(c)), in1 = INR(rcol(a), rcol(c + 1));
+                    if constexpr (a <= c && (in0 || in1)) {
+                        f32x2 sv = PS(jcol(0), rcol(a)) * tv[0];
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) sv = pk_fma(PS(jcol(k), rcol(a)), tv[k], sv);
+                        if constexpr (in0 && in1 && is_pair<N>(rcol(a), rcol(c))) {
+                            st_pair<N>(P, rcol(a), rcol(c), ld_pair<N>(P, rcol(a), rcol(c)) - sv);
+                        } else {
+                            if constexpr (in0) PS(rcol(a), rcol(c)) -= sv.x;
+                            if constexpr (in1) PS(rcol(a), rcol(c + 1)) -= sv.y;
+                        }
+                    } else if constexpr (a == c + 1 && in1) {
+                        T sc = PS(jcol(0), rcol(a)) * tv[0].y;
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) sc = __builtin_fmaf(PS(jcol(k), rcol(a)), tv[k].y, sc);
+                        PS(rcol(a), rcol(c + 1)) -= sc;
+                    }
+                });
+            }
+        } else if constexpr (part_any_rr<N, LO, HI>(c) && (PHASES & 1)) {
             T t[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 T s = cf.S(0, i) * PS(jcol(0), rcol(c));
 #pragma unroll
-                for (int j = 1; j < 6; ++j) s += cf.S(j, i) * PS(jcol(j), rcol(c));
+                for (int j = 1; j < 6; ++j) s = fma_t(cf.S(j, i), PS(jcol(j), rcol(c)), s);
                 t[i] = s;
             }
             static_for<0, c + 1>([&](auto a_) {
@@ -1013,7 +1010,7 @@ __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
                 if constexpr (INR(rcol(a), rcol(c))) {
                     T s = PS(jcol(0), rcol(a)) * t[0];
 #pragma unroll
-                    for (int k = 1; k < 6; ++k) s += PS(jcol(k), rcol(a)) * t[k];
+                    for (int k = 1; k < 6; ++k) s = fma_t(PS(jcol(k), rcol(a)), t[k], s);
                     PS(rcol(a), rcol(c)) -= s;
                 }
             });
@@ -1029,7 +1026,7 @@ __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
             for (int j = i; j < 6; ++j) {
                 T s = cf.G(i, 0) * PS(jcol(0), jcol(j));
 #pragma unroll
-                for (int k = 1; k < 6; ++k) s += cf.G(i, k) * PS(jcol(k), jcol(j));
+                for (int k = 1; k < 6; ++k) s = fma_t(cf.G(i, k), PS(jcol(k), jcol(j)), s);
                 nj[lidx(i, j)] = s;
             }
 #pragma unroll
@@ -1040,7 +1037,26 @@ __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
     }
     static_for<0, NR_>([&](auto c_) {
         constexpr int c = decltype(c_)::value;
-        if constexpr (part_any_jr<N, LO, HI>(c) && (PHASES & 2)) {
+        constexpr bool head = PK && upd_pair_head<N>(c), tail = PK && c >= 1 && upd_pair_head<N>(c - 1);
+        if constexpr (tail) {
+            // (done with column c - 1)
+        } else if constexpr (head && (PHASES & 2) && (part_any_jr<N, LO, HI>(c) || part_any_jr<N, LO, HI>(c + 1))) {
+            static_assert(part_all_jr<N, LO, HI>(c) && part_all_jr<N, LO, HI>(c + 1), "a pair of columns of the J rows must lie in one part");
+            if constexpr (sizeof(T) == 4) {
+                f32x2 xv[6], yv[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) xv[j] = f32x2{ PS(jcol(j), rcol(c)), PS(jcol(j), rcol(c + 1)) };
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    f32x2 sv = cf.G(i, 0) * xv[0];
+#pragma unroll
+                    for (int j = 1; j < 6; ++j) sv = pk_fma(cf.G(i, j), xv[j], sv);
+                    yv[i] = sv;
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { PS(jcol(i), rcol(c)) = yv[i].x; PS(jcol(i), rcol(c + 1)) = yv[i].y; }
+            }
+        } else if constexpr (part_any_jr<N, LO, HI>(c) && (PHASES & 2)) {
             static_assert(part_all_jr<N, LO, HI>(c), "a column of the J rows must lie in one part");
             T x[6], y[6];
 #pragma unroll
@@ -1049,7 +1065,7 @@ __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
             for (int i = 0; i < 6; ++i) {
                 T s = cf.G(i, 0) * x[0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) s += cf.G(i, j) * x[j];
+                for (int j = 1; j < 6; ++j) s = fma_t(cf.G(i, j), x[j], s);
                 y[i] = s;
             }
 #pragma unroll
