@@ -856,13 +856,15 @@ struct RegCoef {
         for (int i = 0; i < 6; ++i) m_[i] = M_[i];
     }
 };
-template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES = 3>
+template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES = 3, bool PKON = true>
 __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf);
-// (round 6) the whole covariance = the part form over the full storage range: ONE body (below) for every kernel that applies the update
-template <typename T, int N, typename COEF>
+// (round 6) the whole covariance = the part form over the full storage range: ONE body (below) for every kernel that applies the update.
+// PKON = false: the same operations without the packed column pairs (bit-equal: every half of a packed operation is the scalar one) --
+// the frame-window kernels, which sit at 512 registers, spill 28-212 bytes with the pairs and nothing without
+template <typename T, int N, typename COEF, bool PKON = true>
 __device__ __forceinline__ void direct_update(T* P, T* dx, const COEF& cf)
 {
-    direct_update_part<T, N, 0, Lay<N>::NP, true, COEF, 3>(P, dx, cf);
+    direct_update_part<T, N, 0, Lay<N>::NP, true, COEF, 3, PKON>(P, dx, cf);
 }
 
 // ---- the update in two PARTS of the packed covariance (round 5) ----------------------------------------------------------------
@@ -938,7 +940,7 @@ template <int N, int LO, int HI> constexpr bool part_all_jr(int c) { bool a_ = t
 // element it touches, in the same order.  P is the full-size array; every element of the J rows / columns that the touched elements
 // need must be loaded (x_c = P(J, c)); WANT_DX: dx = P(:, J) m as well (needs all of the J rows).  PHASES: 1 = the block outside J
 // (reads S^-1), 2 = the J rows (reads G), 3 = both -- the fp64 tail runs them one after the other with only that phase's coefficients live.
-template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES>
+template <typename T, int N, int LO, int HI, bool WANT_DX, typename COEF, int PHASES, bool PKON>
 __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
 {
 #define PS(i, j) P[pidx<N>((i), (j))]
@@ -956,7 +958,7 @@ __device__ __forceinline__ void direct_update_part(T* P, T* dx, const COEF& cf)
     // (round 6) fp32, pair-aligned storage: two neighbouring columns (c, c + 1) of the block outside J / of the J rows at a time on packed
     // instructions (v_pk_mul / v_pk_fma_f32: two columns per issue slot) -- every element sees the operations of the scalar form in the
     // same order (each half of a packed operation IS the scalar operation), so the results are the scalar form's bit for bit
-    constexpr bool PK = PackedMath<T, N>::on && FBUS_X_PACK_UPDATE;
+    constexpr bool PK = PKON && PackedMath<T, N>::on && FBUS_X_PACK_UPDATE;
     // the block outside J, column by column: t = Sinv x_c, then P(a, c) -= x_a . t for the columns a <= c (the x are still the old ones)
     static_for<0, NR_>([&](auto c_) {
         constexpr int c = decltype(c_)::value;
@@ -1094,7 +1096,7 @@ struct CoefG {
 
 // the sums -> information matrix -> 6 x 6 stage (double) -> one-shot update of the resident covariance; dx = the error state
 // (the resident kernels; meas_update_tail below holds the same statements in place)
-template <typename T, int N>
+template <typename T, int N, bool PKON = true>
 __device__ __forceinline__ void meas_solve_update(T* P, const PixAcc& acc, const double* Rd, double w, T* dx)
 {
     double Lam[21], bv[6];
@@ -1110,7 +1112,7 @@ __device__ __forceinline__ void meas_solve_update(T* P, const PixAcc& acc, const
     }
     RegCoef<T> cf;
     cf.set(G, Sinv, m);
-    direct_update<T, N>(P, dx, cf);
+    direct_update<T, N, RegCoef<T>, PKON>(P, dx, cf);
 }
 
 // the tail both per-call measurement kernels share: the sums -> information matrix -> 6 x 6 stage -> update -> injection -> stores
@@ -1795,7 +1797,7 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
     }
     if constexpr (KIND == MEAS_CORNERS) acc.expand_const(mc.NI);
     T dx[N];
-    meas_solve_update<T, N>(P, acc, Rd, 1.0 / r_meas, dx);
+    meas_solve_update<T, N, !WINDOW && NZ>(P, acc, Rd, 1.0 / r_meas, dx);      // (packed pairs: the one-frame square-port kernels)
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     if constexpr (!WINDOW) {
