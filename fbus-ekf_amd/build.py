@@ -28,7 +28,7 @@ FAMILIES = {"predict": 1, "correct": 2, "frame": 3, "frames": 5, "team": 6, "mea
 # but its own independent instructions to cover dependent-issue stalls (predict 13.4 -> 13.05 us, stacked correct
 # 23.0 -> 21.6 us, headline +3.5 %), and lengthens the fused frame kernel (-2.8 %: more live registers, more
 # v_accvgpr traffic), which therefore keeps the default strategy.
-FAMILY_FLAGS = {"predict": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+FAMILY_FLAGS = {"predict": os.environ.get("FBUS_PREDICT_FLAGS", "-mllvm -amdgpu-sched-strategy=max-ilp").split(),
                 "correct": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                 "frame": os.environ.get("FBUS_FRAME_FLAGS", "").split(), "frames": os.environ.get("FBUS_FRAMES_FLAGS", "").split(),
                 "team": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "meas": os.environ.get("FBUS_MEAS_FLAGS", "").split(),

@@ -500,9 +500,12 @@ constexpr int PARK_NOM_CHUNKS = 4;
 #ifndef FBUS_X_PARK_NOM_F64
 #define FBUS_X_PARK_NOM_F64 14
 #endif
+#ifndef FBUS_X_PREDICT_TWO
+#define FBUS_X_PREDICT_TWO 0
+#endif
 template <typename T> constexpr int park_nom_chunks() { return sizeof(T) == 8 ? FBUS_X_PARK_NOM_F64 : PARK_NOM_CHUNKS; }
 template <typename T, int N, int DIALECT, bool MULTI, int LD = AUX_NT, int ST = FBUS_X_PREDICT_ST, bool PARK = false>
-__global__ void __launch_bounds__(BLOCK, (PARK && sizeof(T) == 4) ? 2 : 1)
+__global__ void __launch_bounds__(BLOCK, (sizeof(T) == 4 && (PARK || (!MULTI && FBUS_X_PREDICT_TWO))) ? 2 : 1)
 predict_kernel(T* __restrict__ recs, int B, int K, const T* __restrict__ accel, const T* __restrict__ gyro,
                const T* __restrict__ dt, int dt_stride, DevConst<T> dc)
 {
