@@ -303,9 +303,12 @@ __device__ __forceinline__ void filter_pil(const double* R, const double* P_IL, 
 // kernels takes a marker as two passes of two corners x two cameras (pixel_fold_marker_stereo_halves): four projections in lock step, the
 // left-camera fold's working set, instead of eight -- the eight-projection stage spilled ~300 v_accvgpr moves per marker (EXPERIMENTS -1.7:
 // 2388 -> 2161 instructions per marker in the compiled loop, 16 slots stereo 100-102 -> 93-96 us).
+// wgt (round 6): 1 for a marker of the map, 0 for a slot whose id is not in it -- the callers fold EVERY slot (with slot 0's frame for the
+// unknown ones, rows of weight 0) instead of branching around the fold per lane: the divergent branch cost ~70 instructions per marker
+// (exec-mask bookkeeping and zero-initialised merge values for the 27 sums) and saved work only when all 64 filters of a wave skip.
 template <int NCAM, typename T, bool NZ, int NK = 4, int K0 = 0>
 __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, const double* R, const double* pil,
-                                                  const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size)
+                                                  const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size, double wgt = 1.0)
 {
     static_assert(NK >= 1 && K0 >= 0 && K0 + NK <= 4, "corners of one marker");
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;           // Newton steps behind v_rsq_f64 / v_rcp_f64
@@ -382,7 +385,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             ok[q] = (zwq[q] > 0.0) && (r2[q] < klim * zwq[q] * zwq[q]);
-            vis[q] = ok[q] ? 1.0 : 0.0;
+            vis[q] = ok[q] ? wgt : 0.0;
             r2s[q] = ok[q] ? r2[q] : 0.0;
             const double zs = ok[q] ? zwq[q] : 1.0;
             Wd[q] = zs * mc.a1;
@@ -554,11 +557,12 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
 // in the same order -- bit-equal to pixel_fold_marker<2, T, NZ>
 template <typename T, bool NZ>
 __device__ __forceinline__ void pixel_fold_marker_stereo_halves(PixAcc& acc, const double* p, const double* R, const double* pil,
-                                                                const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size)
+                                                                const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size,
+                                                                double wgt = 1.0)
 {
-    pixel_fold_marker<2, T, NZ, 2, 0>(acc, p, R, pil, mc, mkc, yl, yr, size);
+    pixel_fold_marker<2, T, NZ, 2, 0>(acc, p, R, pil, mc, mkc, yl, yr, size, wgt);
     order_fence();
-    pixel_fold_marker<2, T, NZ, 2, 2>(acc, p, R, pil, mc, mkc, yl, yr, size);
+    pixel_fold_marker<2, T, NZ, 2, 2>(acc, p, R, pil, mc, mkc, yl, yr, size, wgt);
 }
 
 
@@ -1314,15 +1318,18 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         fetch(i + NR < M ? i + NR : M - 1, nxt);                // always a fresh load (no conditional merge of the two records)
         const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
         const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
-        if (slot >= 0) {
+        {
+            // every slot is folded; one whose id is not in the map with slot 0's frame and weight 0 (see pixel_fold_marker)
+            const double wgt = slot >= 0 ? 1.0 : 0.0;
+            const int sl = slot >= 0 ? slot : 0;
             double mk[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-            if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
-            else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-            else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-            else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
-            nfold += 1.0;
+            for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[sl * MKC_STRIDE + q];
+            if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+            else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
+            else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
+            else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+            nfold += wgt;
         }
         cur = nxt;
     }
@@ -1707,15 +1714,17 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
             fetch(i + 1 < M ? i + 1 : M - 1, nxt);
             const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
             const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
-            if (slot >= 0) {
+            {
+                const double wgt = slot >= 0 ? 1.0 : 0.0;            // (every slot is folded: see pixel_fold_marker)
+                const int sl = slot >= 0 ? slot : 0;
                 double mk[9];
 #pragma unroll
-                for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-                if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
-                else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-                else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-                else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
-                nfold += 1.0;
+                for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[sl * MKC_STRIDE + q];
+                if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+                else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
+                else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
+                else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+                nfold += wgt;
             }
             cur = nxt;
         }

@@ -127,13 +127,15 @@ correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __res
             fetch(i + NR < M ? i + NR : M - 1, nxt);
             const bool ok = cur.id >= 0 && cur.id <= FBUS_MAX_MARKER_ID;
             const int slot = ok ? (int)tbl.id2slot[ok ? cur.id : 0] : -1;
-            if (slot >= 0) {
+            {
+                const double wgt = slot >= 0 ? 1.0 : 0.0;            // (every slot is folded: see pixel_fold_marker)
+                const int sl = slot >= 0 ? slot : 0;
                 double mk[9];
 #pragma unroll
-                for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[slot * MKC_STRIDE + q];
-                if (stereo) pixel_fold_marker_stereo_halves<T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size);
-                else pixel_fold_marker<1, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size);
-                nfold += 1.0;
+                for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[sl * MKC_STRIDE + q];
+                if (stereo) pixel_fold_marker_stereo_halves<T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
+                else pixel_fold_marker<1, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+                nfold += wgt;
             }
             cur = nxt;
         }
