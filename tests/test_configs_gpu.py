@@ -257,9 +257,10 @@ def test_config5_sixteen_slots_fp32_against_fp64():
             # starts from: after 7 fp32 predicts the carried rotation is off by 3.5e-7 and p by ~1e-7 m, h(x) by 3e-7 m, and
             # the gain of 84 stacked rows from position to velocity is ~17 / s -- 5e-6 m/s, i.e. 1.2e-5 of sigma_v.  Exact
             # fp64 arithmetic on the fp32-ROUNDED predicted state already shows 1.5e-6 / 3.7e-5 over 4000 filters
-            # (tools/emul_config5_quantisation.py).  Hence 3x / 5x on the maximum over all 65 536 filters; the strided subset
+            # (tools/emul_config5_quantisation.py).  Hence 1.5x / 2x (3x / 5x until round 6) on the maximum over all 65 536 filters; the strided subset
             # against the oracle (below) meets the un-multiplied single-step gates.
-            gates = ((0, "one frame", 3 * STATE_TOL, 5 * PLAIN_TOL, COV_BLOCK_TOL, STATE_TOL),
+            # (round 6: 1.5x / 2x, down from 3x / 5x -- measured 9.8e-6 sigma-aware, 2.7e-4 plain; the kernels are deterministic)
+            gates = ((0, "one frame", 1.5 * STATE_TOL, 2 * PLAIN_TOL, COV_BLOCK_TOL, STATE_TOL),
                      (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL, STATE_TOL))
             # ... and the fp32 kernels against the ORACLE directly on the strided subset (not only against the fp64 kernels)
             assert_parity([x[sub] for x in res[32][0]], eng.get_state(), 32, "config 5 pose rows, fp32 device vs oracle, one frame")
@@ -269,12 +270,11 @@ def test_config5_sixteen_slots_fp32_against_fp64():
             # covariance 2e-7), and the fp32 kernels against the ORACLE on the strided subset meet them un-multiplied (next
             # line).  The maximum over all 65 536 filters of fp32 against fp64 after 7 fp32 PREDICTS + the 144-row update is what
             # the pose form's comment above describes -- the fp32 nominal state the update starts from, times the gain of 144
-            # rows -- and gets the pose form's multipliers (3x / 5x; literal 2e-5: measured 1.1e-5, round 3: 1.4e-5 under a 5e-5 gate).
-            # (eight chained fp32 steps without re-seeding: literal 4.6e-6; the sigma-aware velocity figure reads 1.04e-5 -- the 144-row
-            # gain on the fp32 predicted state, see the pose form's comment -- and gets 2x)
-            assert_parity([x[sub] for x in res[32][0]], eng.get_state(), 32, "config 5 corner rows, fp32 device vs oracle, one frame",
-                          state_tol=2 * STATE_TOL)
-            gates = ((0, "one frame", 3 * STATE_TOL, 5 * PLAIN_TOL, COV_BLOCK_TOL, 2e-5),
+            # rows -- and gets multipliers of its own (3x / 4x; literal 1.5e-5: measured 1.06e-5, round 3: 1.4e-5 under a 5e-5 gate).
+                        # (round 6: the subset against the oracle through the un-multiplied gate -- measured 8.8e-6 --, the maximum over all filters at
+            # literal 1.5e-5 / 3x / 4x: measured 1.06e-5 / 2.3e-5 / 6.3e-4)
+            assert_parity([x[sub] for x in res[32][0]], eng.get_state(), 32, "config 5 corner rows, fp32 device vs oracle, one frame")
+            gates = ((0, "one frame", 3 * STATE_TOL, 4 * PLAIN_TOL, COV_BLOCK_TOL, 1.5e-5),
                      (1, "1 s (30 frames)", WINDOW_TOL, PLAIN_WINDOW_TOL, 10 * COV_BLOCK_TOL, STATE_TOL))
         for i, name, st, pl, cb, lit in gates:
             _properties(res[32][i], f"config 5 {form} {name}", psd_stride=97)

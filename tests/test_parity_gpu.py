@@ -724,7 +724,7 @@ def test_sixteen_marker_slots_stacked():
             flt.correct(ids16, pos16, quat16, 1)
             ok = eng.correct(ids16, pos16, quat16, 1)
             assert ok.all() and (flt.applied() == 1).all()
-            _check(flt, eng, dtype, "16 slots stacked", state_tol=STATE_TOL * 3)    # 84 rows at one linearisation point
+            _check(flt, eng, dtype, "16 slots stacked")    # 84 rows at one linearisation point: the standard gate (round 6; measured 4.2e-7, rounds 2-5 allowed 3x)
 
 
 def test_long_run_stability_and_degenerate_inputs():
