@@ -1325,10 +1325,18 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
             double mk[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[sl * MKC_STRIDE + q];
-            if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
-            else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
-            else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
-            else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+            // the image points of a slot that carries no marker of the map may be anything (padding is the caller's: NaN included), and
+            // 0 x NaN would poison the sums: such a slot is folded with zeros
+            constexpr int NRR = sizeof(cur.r) / sizeof(T);
+            T yl_[8], yr_[NRR];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) yl_[k] = slot >= 0 ? cur.l[k] : T(0);
+#pragma unroll
+            for (int k = 0; k < NRR; ++k) yr_[k] = slot >= 0 ? cur.r[k] : T(0);
+            if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
+            else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
+            else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
+            else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
             nfold += wgt;
         }
         cur = nxt;
@@ -1720,10 +1728,16 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
                 double mk[9];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[sl * MKC_STRIDE + q];
-                if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
-                else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
-                else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
-                else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+                constexpr int NRR = sizeof(cur.r) / sizeof(T);          // (a slot without a marker of the map: zeros for its image points)
+                T yl_[8], yr_[NRR];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) yl_[k] = slot >= 0 ? cur.l[k] : T(0);
+#pragma unroll
+                for (int k = 0; k < NRR; ++k) yr_[k] = slot >= 0 ? cur.r[k] : T(0);
+                if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
+                else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
+                else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
+                else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
                 nfold += wgt;
             }
             cur = nxt;

@@ -133,8 +133,11 @@ correct_pixels_split_kernel(T* __restrict__ recs, int B, int M, const int* __res
                 double mk[9];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) mk[q] = tbl.mkc[sl * MKC_STRIDE + q];
-                if (stereo) pixel_fold_marker_stereo_halves<T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.r, size, wgt);
-                else pixel_fold_marker<1, T, true>(acc, pd, Rd, pil, mc, mk, cur.l, cur.l, size, wgt);
+                T yl_[8], yr_[8];                                     // (a slot without a marker of the map: zeros for its image points)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { yl_[k] = slot >= 0 ? cur.l[k] : T(0); yr_[k] = slot >= 0 ? cur.r[k] : T(0); }
+                if (stereo) pixel_fold_marker_stereo_halves<T, true>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
+                else pixel_fold_marker<1, T, true>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
                 nfold += wgt;
             }
             cur = nxt;

@@ -344,3 +344,45 @@ def test_config5_128_reprojection_rows_at_full_batch():
                   f"plain {e['plain']:.2e} cov {e['cov']:.2e} cov block-wise {e['cov_block']:.2e}")
             # the single-step gates, un-widened (round 3: 5e-5 / 1e-4 / 5e-3; measured now 8e-9 / 8e-8 / 1.2e-7)
             assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["cov"] <= COV_TOL and e["cov_block"] <= COV_BLOCK_TOL
+
+
+@pytest.mark.parametrize("route", ["one_wave", "split", "one_tail_roles", "fused", "fp64"])
+def test_padding_of_absent_slots_may_be_anything(route, monkeypatch):
+    """Slots without a marker of the map (id -1, or an id outside it) are ignored whatever their image points hold -- NaN included.
+    (Round 6 folds every slot with a weight instead of branching around it: 0 x NaN must not reach the sums.)  The same call with zeros
+    and with NaN / huge values in those slots: bit-equal results and flags, on every kernel route."""
+    import torch
+    B, M = 192, 4
+    prm, nom, rot, P, prev, ids, left, right = _scene(B, M, 0, seed=71)
+    ids[:, 3] = -1                                                   # an absent slot in every filter
+    ids[::3, 1] = 9                                                  # an id outside the map in every third
+    ids[5, :] = -1                                                   # nothing at all
+    junk_l, junk_r = left.copy(), right.copy()
+    bad = (ids < 0) | (ids == 9)
+    junk_l[bad] = np.nan
+    junk_r[bad] = 1e30
+    junk_r[5] = np.nan
+    dtype = 64 if route == "fp64" else 32
+    if route == "one_tail_roles":
+        monkeypatch.setenv("FBUS_MEAS_SPLIT", "0")
+    out = []
+    for l, r in ((left, right), (junk_l, junk_r)):
+        for stereo in (False, True):
+            with BatchedFilter(B, prm, dtype=dtype) as flt:
+                if route in ("one_wave", "fused", "fp64"):
+                    flt.set_team(1, 1)
+                flt.set_state(nom, rot, P, prev)
+                if route == "fused":
+                    tt = torch.float32
+                    dev = torch.device("cuda:0")
+                    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if np.asarray(a).dtype.kind in "iu" else \
+                        torch.from_numpy(np.ascontiguousarray(a, np.float64)).to(dev).to(tt)
+                    flt.frame_meas(None, None, None, d(ids), d(l), d(r) if stereo else None, capi.MEAS_PIXELS, capi.VIS_REFRACTIVE, capi.MODE_STACKED)
+                    flt.sync()
+                else:
+                    flt.correct_pixels(ids, l, r if stereo else None)
+                out.append((flt.get_state(), flt.applied()))
+    for (sa, oka), (sb, okb) in zip(out[:2], out[2:]):
+        assert np.array_equal(oka, okb) and oka[5] == 0 and oka.sum() >= B - 2
+        for x, y in zip(sa, sb):
+            assert np.isfinite(np.asarray(y, np.float64)).all() and np.array_equal(x, y)
