@@ -24,7 +24,7 @@ Under a launcher, WORLD_SIZE must equal --gpus.
 
 Prints ONE COMPACT JSON line (< 6 KB: `compact_line`) on rank 0 -- the contract's keys, `roofline`, `cpu_baseline`, one short block
 each for `fp64` and `north_star` -- and writes the FULL result (every leg described below) to `bench_detail.json` beside this file
-(`--detail-file`) and as one `bench_detail: {...}` line on stderr.  (Round 5 printed the full 20.7 KB object on stdout and the driver
+(`--detail-file`; `--detail-stderr` also prints it as one `bench_detail: {...}` line on stderr).  (Round 5 printed the full 20.7 KB object on stdout and the driver
 could not parse it.)  In the full result `roofline` is for the dominant kernel (predict): bytes the kernel MOVES per
 launch (1436 B per filter: 828 read, 608 written -- the predict-invariant covariance tail and ba/bg/g are not
 written back) / its average duration measured with HIP events on the launch stream inside the timed region;
@@ -93,6 +93,7 @@ def parse():
     ap.add_argument("--mode", choices=["stacked", "nearest"], default="stacked")
     ap.add_argument("--dialect", choices=["matlab", "cpp"], default="matlab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail-stderr", action="store_true", help="also print the full result as one `bench_detail: {...}` line on stderr")
     ap.add_argument("--detail-file", default=None,
                     help="where the FULL result goes (default: bench_detail.json beside bench.py and under gpurun_out/ when that exists); "
                          "stdout carries the compact line only")
@@ -739,17 +740,25 @@ def compact_line(out):
     return text
 
 
-def emit_result(out, detail_path=None):
-    """full result -> bench_detail.json (or --detail-file) + stderr; compact line -> stdout"""
+def emit_result(out, detail_path=None, detail_stderr=False):
+    """full result -> bench_detail.json (or --detail-file) [+ stderr with --detail-stderr]; compact line -> stdout"""
     detail = json.dumps(out)
+    written = []
     for path in ([detail_path] if detail_path else [os.path.join(ROOT, DETAIL_FILE), os.path.join(ROOT, "gpurun_out", DETAIL_FILE)]):
         try:
             if os.path.isdir(os.path.dirname(os.path.abspath(path))):
                 with open(path, "w") as f:
                     f.write(detail + "\n")
+                written.append(path)
         except OSError as e:
             sys.stderr.write(f"bench.py: could not write {path}: {e}\n")
-    sys.stderr.write("bench_detail: " + detail + "\n")
+    written = ", ".join(written)
+    # stderr: where the full result went (the whole object only on request: a 20 KB line in front of the one the driver parses is a
+    # risk not worth taking, and the committed copy is profiles/rNN_bench_detail.json)
+    if detail_stderr:
+        sys.stderr.write("bench_detail: " + detail + "\n")
+    else:
+        sys.stderr.write(f"bench.py: full result ({len(detail)} bytes) -> {written or 'nowhere (no writable path)'}\n")
     sys.stderr.flush()
     emit(compact_line(out))
 
@@ -999,7 +1008,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        emit_result(out, args.detail_file)
+        emit_result(out, args.detail_file, args.detail_stderr)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
