@@ -68,6 +68,8 @@ struct MeasConst {
     double NI[6];                   // R_IL' R_IL (symmetric: 00 01 02 11 12 22): the N' of a corner's three position rows
     double n[3];                    // port normal
     double a0, a1, d_air, d_glass;  // n_air / n_glass, n_air / n_water
+    float st[8];                    // (round 6) constants of the fp32 start of the port equation (ekf_meas.hpp::port_start_f32):
+                                    // a1, a1^2, 1 - a1^2, 1 - a0^2, d_air, d_glass a0, (d_air + d_glass a0) / a1, 0
     const double* mkc;              // [FBUS_MAX_MARKERS][MKC_STRIDE]
 };
 

@@ -102,50 +102,92 @@ __device__ __forceinline__ void md_rcp_n(const double (&x)[NQ], double (&y)[NQ])
 }
 
 // the port equation  rho = L(t) = d_air t + d_glass tan(theta_glass) + zw tan(theta_water),  t = tan(theta_air)   (vision_device.hpp)
-// with s = sin(theta_air) = t r, r = (1 + t^2)^-1/2, icg = 1 / cos(theta_glass) = (1 - a0^2 s^2)^-1/2, icw likewise, G = d_glass a0,
-// W = zw a1:   L = d_air t + s (G icg + W icw),   L' = d_air + r^3 (G icg^3 + W icw^3),
-//              L'' = 3 r^5 ( -t (G icg^3 + W icw^3) + s r (G a0^2 icg^5 + W a1^2 icw^5) )   (< 0: L is concave)
-// dt: HALLEY's step  -2 f L' / (2 L'^2 - f L''),  f = L - rho  (cubic convergence; tests/test_port_solver_cpu.py).  The denominator is
-// kept >= L'^2 (far below the root f L'' > 0 could eat it: the step then is at most twice Newton's).
+// IN THE TANGENT (round 6): sin(theta_m) = a_m sin(theta_air) gives tan(theta_m) = a_m t / sqrt(1 + (1 - a_m^2) t^2), so with
+// x_g = 1 + (1 - a0^2) t^2, x_w = 1 + (1 - a1^2) t^2, i_g = x_g^-1/2, i_w = x_w^-1/2, G = d_glass a0, W = zw a1:
+//     L   = t (d_air + G i_g + W i_w)
+//     L'  = d_air + G i_g^3 + W i_w^3                          (d/dt [t x^-1/2] = x^-3/2)
+//     L'' = -3 t ((1 - a0^2) G i_g^5 + (1 - a1^2) W i_w^5)     (< 0: L is concave)
+//     L_z = a1 t i_w,   d L_z / dt = a1 i_w^3
+// -- two reciprocal square roots per evaluation and no sine: rounds 4-5 went through s = sin(theta_air) = t (1 + t^2)^-1/2 and
+// 1 / cos(theta_m) = (1 - a_m^2 s^2)^-1/2, three of them and 18 more instructions per projection (EXPERIMENTS -1.10; the same function,
+// tests/test_port_solver_cpu.py holds both forms against each other).
+// dt: HALLEY's step  -2 f L' / (2 L'^2 - f L''),  f = L - rho  (cubic convergence).  The denominator is kept >= L'^2 (far below the
+// root f L'' > 0 could eat it: the step then is at most twice Newton's).
 // Lzt, Ltt: d L_z / dt, d L_t / dt (to carry L_z, L_t along the step to first order).
 template <typename S, int NQ> struct PortEvalN { S Lt[NQ], Lz[NQ], dt[NQ], Ltt[NQ], Lzt[NQ]; };
 template <int NS, typename S, int NQ>
 __device__ __forceinline__ void port_eval_n(S a0, S a1, S d_air, S G, const S (&W)[NQ], const S (&rho)[NQ], const S (&t)[NQ],
-                                            PortEvalN<S, NQ>& o)          // (S = double; the round's fp32 first step is gone)
+                                            PortEvalN<S, NQ>& o)
 {
-    const S a02 = a0 * a0, a12 = a1 * a1;
-    S x[NQ], r[NQ], s_[NQ], s2[NQ], icg[NQ], icw[NQ];
+    const S qg = S(1) - a0 * a0, qw = S(1) - a1 * a1;
+    S t2[NQ], x[NQ], ig[NQ], iw[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[q] = S(1) + t[q] * t[q];
-    md_rsq_n<NS, NQ>(x, r);
+    for (int q = 0; q < NQ; ++q) t2[q] = t[q] * t[q];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) s_[q] = t[q] * r[q];
+    for (int q = 0; q < NQ; ++q) x[q] = S(1) + qg * t2[q];
+    md_rsq_n<NS, NQ>(x, ig);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) s2[q] = s_[q] * s_[q];
+    for (int q = 0; q < NQ; ++q) x[q] = S(1) + qw * t2[q];
+    md_rsq_n<NS, NQ>(x, iw);
+    S ig2[NQ], iw2[NQ], g1[NQ], w1[NQ], g3[NQ], w3[NQ], f[NQ], Lt2[NQ], den[NQ], h[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[q] = S(1) - a02 * s2[q];
-    md_rsq_n<NS, NQ>(x, icg);
+    for (int q = 0; q < NQ; ++q) { ig2[q] = ig[q] * ig[q]; iw2[q] = iw[q] * iw[q]; g1[q] = G * ig[q]; w1[q] = W[q] * iw[q]; }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[q] = S(1) - a12 * s2[q];
-    md_rsq_n<NS, NQ>(x, icw);
-    S icg2[NQ], icw2[NQ], g1[NQ], w1[NQ], g3[NQ], w3[NQ], q3[NQ], r2[NQ], r3[NQ], L[NQ], f[NQ], Lt2[NQ], den[NQ], h[NQ];
+    for (int q = 0; q < NQ; ++q) { g3[q] = g1[q] * ig2[q]; w3[q] = w1[q] * iw2[q]; f[q] = (g1[q] + w1[q]) + d_air; o.Lz[q] = a1 * t[q] * iw[q]; }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { icg2[q] = icg[q] * icg[q]; icw2[q] = icw[q] * icw[q]; g1[q] = G * icg[q]; w1[q] = W[q] * icw[q]; r2[q] = r[q] * r[q]; }
+    for (int q = 0; q < NQ; ++q) { o.Lt[q] = (g3[q] + w3[q]) + d_air; h[q] = qg * g3[q] * ig2[q] + qw * w3[q] * iw2[q]; f[q] = t[q] * f[q] - rho[q]; }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { g3[q] = g1[q] * icg2[q]; w3[q] = w1[q] * icw2[q]; r3[q] = r2[q] * r[q]; L[q] = g1[q] + w1[q]; }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { q3[q] = g3[q] + w3[q]; L[q] = d_air * t[q] + s_[q] * L[q]; o.Lz[q] = a1 * s_[q] * icw[q]; }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { o.Lt[q] = d_air + r3[q] * q3[q]; h[q] = a02 * g3[q] * icg2[q] + a12 * w3[q] * icw2[q]; f[q] = L[q] - rho[q]; }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { h[q] = s_[q] * r[q] * h[q] - t[q] * q3[q]; o.Lzt[q] = a1 * r3[q] * icw[q] * icw2[q]; Lt2[q] = o.Lt[q] * o.Lt[q]; }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) o.Ltt[q] = S(3) * r3[q] * r2[q] * h[q];
+    for (int q = 0; q < NQ; ++q) { o.Ltt[q] = S(-3) * t[q] * h[q]; o.Lzt[q] = a1 * iw[q] * iw2[q]; Lt2[q] = o.Lt[q] * o.Lt[q]; }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) den[q] = fmax(S(2) * Lt2[q] - f[q] * o.Ltt[q], Lt2[q]);
     md_rcp_n<NS, NQ>(den, h);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) o.dt[q] = -S(2) * f[q] * o.Lt[q] * h[q];
+}
+
+// ---- the START of the port equation's solution, in packed fp32 (round 6) ---------------------------------------------------------
+// The thin-port solution in closed form, twice (see pixel_fold_marker): a starting value for the Halley step in double that follows, good
+// to 1e-4 by construction -- so fp32 arithmetic (1e-7) costs nothing, and the hardware's fp32 estimates issue in half the time of the
+// double ones (v_rsq_f32 8.5 ticks against v_rsq_f64 16.5, profiles/r04_issue_rates.txt) while two projections share one v_pk_* slot:
+// ~104 double instructions (24 of them v_rsq / v_rcp_f64) per four projections become ~80 fp32 ones (EXPERIMENTS -1.10).
+//   rho, zs: lateral offset and water depth of the NP projections (out of view: 0 and 1);  t: tan(theta_air), the start
+using f32x2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_bc(float a) { return f32x2{ a, a }; }
+__device__ __forceinline__ f32x2 pk_rsq(f32x2 a) { return f32x2{ __builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y) }; }
+__device__ __forceinline__ f32x2 pk_rcp(f32x2 a) { return f32x2{ __builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y) }; }
+__device__ __forceinline__ f32x2 pk_max(f32x2 a, float lo) { return f32x2{ __builtin_fmaxf(a.x, lo), __builtin_fmaxf(a.y, lo) }; }
+template <int NP>
+__device__ __forceinline__ void port_start_f32(const MeasConst& mc, const double (&rho)[NP], const double (&zs)[NP], double (&t)[NP])
+{
+    static_assert(NP % 2 == 0, "projections come in pairs");
+    constexpr int H = NP / 2;
+    const float a1sq = mc.st[1], q1 = mc.st[2], qg = mc.st[3], dair = mc.st[4], Gd0 = mc.st[5], c0 = mc.st[6];
+    f32x2 rh[H], z[H], u[H], w[H], tt[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { rh[h] = f32x2{ (float)rho[2 * h], (float)rho[2 * h + 1] }; z[h] = f32x2{ (float)zs[2 * h], (float)zs[2 * h + 1] }; }
+    // t0 = u / sqrt(a1^2 - (1 - a1^2) u^2),  u = rho / z_e,  z_e = z_w + (d_air + d_glass a0) / a1
+#pragma unroll
+    for (int h = 0; h < H; ++h) w[h] = pk_rcp(z[h] + pk_bc(c0));
+#pragma unroll
+    for (int h = 0; h < H; ++h) { u[h] = rh[h] * w[h]; w[h] = pk_max(pk_fma2(pk_bc(-q1) * u[h], u[h], pk_bc(a1sq)), 1e-6f); }
+#pragma unroll
+    for (int h = 0; h < H; ++h) w[h] = pk_rsq(w[h]);
+#pragma unroll
+    for (int h = 0; h < H; ++h) { tt[h] = u[h] * w[h]; w[h] = pk_fma2(pk_bc(qg) * tt[h], tt[h], pk_bc(1.f)); }
+#pragma unroll
+    for (int h = 0; h < H; ++h) { w[h] = pk_rsq(w[h]); z[h] = pk_rcp(z[h]); }     // tan(theta_glass) / (a0 t0) (see port_eval_n), 1 / z_w
+    // the port's offsets at t0 taken off rho, the thin-port equation once more for the water alone
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        u[h] = pk_fma2(-tt[h], pk_fma2(pk_bc(Gd0), w[h], pk_bc(dair)), rh[h]);
+        u[h] = pk_max(u[h] * z[h], 0.f);
+        w[h] = pk_max(pk_fma2(pk_bc(-q1) * u[h], u[h], pk_bc(a1sq)), 1e-6f);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) w[h] = pk_rsq(w[h]);
+#pragma unroll
+    for (int h = 0; h < H; ++h) { tt[h] = u[h] * w[h]; t[2 * h] = (double)tt[h].x; t[2 * h + 1] = (double)tt[h].y; }
 }
 
 // ---- the sums of the fold (double) --------------------------------------------------------------------------------------
@@ -337,7 +379,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
     // per projection q = (corner k, camera c): lateral offset, depth, visibility, and the start of the port equation's solution
     double lat[NP][3], rho[NP], irho[NP], Wd[NP], vis[NP], t[NP];
     {
-        double X[NP][3], z[NP], r2[NP], zwq[NP], r2s[NP], xs[NP], ir0[NP], ze[NP];
+        double X[NP][3], z[NP], r2[NP], zwq[NP], r2s[NP], xs[NP], ir0[NP], zsq[NP];
         bool ok[NP];
         // X = M_c (ru_k - pil) + t_c: corner 0 and the two edge vectors once per camera, the other corners by addition
 #pragma unroll
@@ -380,16 +422,14 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         // in front of the port and inside its field of view (in water no ray leans further than asin(n_air / n_water); 0.9 of that
         // limit, as the oracle): otherwise the corner contributes no rows to this camera.  A point out of view is replaced by a
         // harmless one on the axis (rho = 0, 1 / rho = 0, one metre of water): everything below stays finite, its rows get weight 0
-        const double c0 = (mc.d_air + mc.d_glass * mc.a0) / mc.a1;
         const double klim = 0.81 * mc.a1 * mc.a1 / (1.0 - mc.a1 * mc.a1);      // (0.9 a1)^2 / (1 - a1^2): wave-uniform
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             ok[q] = (zwq[q] > 0.0) && (r2[q] < klim * zwq[q] * zwq[q]);
             vis[q] = ok[q] ? wgt : 0.0;
             r2s[q] = ok[q] ? r2[q] : 0.0;
-            const double zs = ok[q] ? zwq[q] : 1.0;
-            Wd[q] = zs * mc.a1;
-            ze[q] = zs + c0;
+            zsq[q] = ok[q] ? zwq[q] : 1.0;
+            Wd[q] = zsq[q] * mc.a1;
             xs[q] = r2s[q] > 0.0 ? r2s[q] : 1.0;
         }
         md_rsq_n<NS, NP>(xs, ir0);
@@ -402,30 +442,11 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         // Then the port's offsets AT t0 are taken off rho and the thin-port equation is solved once more for the water alone:
         //     u1 = (rho - d_air t0 - d_glass tan(theta_glass(t0))) / z_w,   t1 = u1 / sqrt(a1^2 - (1 - a1^2) u1^2)
         // -- within 1.2e-4 inside tangent 1.4, 6e-4 up to 2, 3.4e-3 up to 2.5, 1.8e-2 at the rim (tests/test_port_solver_cpu.py
-        // restates this solver in numpy and asserts the figures).  The hardware estimates (2^-23) are good enough for a start.  Measured in one run (65 536 filters x 16 slots, left / stereo): second pass always 79.4 / 120.0 us,
+        // restates this solver in numpy and asserts the figures).  Measured in one run of round 4 (65 536 filters x 16 slots, left / stereo): second pass always 79.4 / 120.0 us,
         // only for the waves that hold a tangent > 1.3 (voted, applied per lane) 78.3 / 124.0 -- the branch costs more than the
         // pass --, never 76.0 / 113.2 (and 1.6e-4 off at the rim).
-        const double q1 = 1.0 - mc.a1 * mc.a1, a12 = mc.a1 * mc.a1, Gd0 = mc.d_glass * mc.a0;
-        double u[NP], w_[NP], r_[NP], s_[NP], izw[NP];
-        md_rcp_n<0, NP>(ze, u);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { u[q] *= rho[q]; w_[q] = fmax(a12 - q1 * u[q] * u[q], 1e-6); }
-        md_rsq_n<0, NP>(w_, w_);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { t[q] = u[q] * w_[q]; r_[q] = 1.0 + t[q] * t[q]; izw[q] = Wd[q]; }
-        md_rsq_n<0, NP>(r_, r_);
-        md_rcp_n<0, NP>(izw, izw);                                      // 1 / (z_w a1)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { s_[q] = t[q] * r_[q]; w_[q] = 1.0 - mc.a0 * mc.a0 * s_[q] * s_[q]; }
-        md_rsq_n<0, NP>(w_, w_);                                        // 1 / cos(theta_glass)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            u[q] = fmax((rho[q] - mc.d_air * t[q] - Gd0 * s_[q] * w_[q]) * izw[q] * mc.a1, 0.0);
-            w_[q] = fmax(a12 - q1 * u[q] * u[q], 1e-6);
-        }
-        md_rsq_n<0, NP>(w_, w_);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) t[q] = u[q] * w_[q];
+        // (round 6) in packed fp32: port_start_f32 -- a start good to 1e-4 does not need double
+        port_start_f32<NP>(mc, rho, zsq, t);
     }
     // ONE Halley step in double from there (cubic): 1.4e-13 left inside tangent 1.4 (every lens; the recordings and test scenes stay
     // below 0.8), 7e-12 up to 2, 9e-10 up to 2.5, 4.4e-8 = 1.4e-8 relative at the very rim -- below the fp32 rounding of the image

@@ -308,11 +308,11 @@ void launch_frame_meas_k(hipStream_t s, T* recs, int B, int F, const unsigned ch
     // (round 6) pixel rows, square port: the left-camera and the stereo frame as kernels of their own (CAM = 1 / 2, as correct_pixels2_kernel)
     if (kind == MEAS_PIXELS) {
         if (nz) {
-            // stereo and the left-camera WINDOW as kernels of their own (CAM = 2 / 1: +2-3 % / +2-5 %); the single left-camera frame keeps
-            // the combined kernel (the left-only one measured 1 % slower there: profiles/r06_meas_cam_ab.txt)
+            // the left-camera and the stereo frame as kernels of their own (CAM = 1 / 2: +2-5 % for the windows and the stereo frame; the single
+            // left-camera frame ran 1 % faster in the combined kernel until the fp32 start (EXPERIMENTS -1.10) pushed that kernel into 28 bytes of
+            // scratch -- level since, profiles/r06_port_tangent_ab.txt, so the combined kernel is no longer built for the square port)
             if (right) FBUS_LAUNCH_FM(MEAS_PIXELS, true, 2);
-            else if (F > 1) FBUS_LAUNCH_FM(MEAS_PIXELS, true, 1);
-            else FBUS_LAUNCH_FM(MEAS_PIXELS, true, 0);
+            else FBUS_LAUNCH_FM(MEAS_PIXELS, true, 1);
         } else FBUS_LAUNCH_FM(MEAS_PIXELS, false, 0);
     }
     else                     { if (nz) FBUS_LAUNCH_FM(MEAS_CORNERS, true, 0); else FBUS_LAUNCH_FM(MEAS_CORNERS, false, 0); }

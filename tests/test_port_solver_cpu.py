@@ -1,5 +1,5 @@
-"""CPU suite: the forward flat-port projection as the round-4 measurement kernels solve it (csrc/ekf_meas.hpp::pixel_fold_marker) --
-closed-form thin-port start, taken twice, then ONE Halley step in double (two for fp64 records) with L_t and L_z carried along the
+"""CPU suite: the forward flat-port projection as the measurement kernels solve it (csrc/ekf_meas.hpp::pixel_fold_marker) --
+closed-form thin-port start, taken twice (in fp32 since round 6: port_start_f32), then ONE Halley step in double (two for fp64 records) with L_t and L_z carried along the
 step to first order -- restated in numpy and compared with a converged Newton solution of the same port equation
     rho = L(t) = d_air t + d_glass tan(theta_glass) + z_w tan(theta_water),  t = tan(theta_air)
 (the inverse of the ray construction of RefractionTriangulation, vision.cpp:505-552) over the whole admitted field of view: water depths
@@ -19,7 +19,19 @@ def _consts():
 
 
 def _port(c, zw, t):
-    """L, L_t, L_tt, L_z, L_zt at tangent t (the kernel's port_eval_n)"""
+    """L, L_t, L_tt, L_z, L_zt at tangent t, as the kernel's port_eval_n computes them (round 6: in the tangent --
+    tan(theta_m) = a_m t / sqrt(1 + (1 - a_m^2) t^2): two reciprocal square roots and no sine)"""
+    qg, qw = 1.0 - c["a0"] ** 2, 1.0 - c["a1"] ** 2
+    ig, iw = 1.0 / np.sqrt(1.0 + qg * t * t), 1.0 / np.sqrt(1.0 + qw * t * t)
+    G, W = c["d_glass"] * c["a0"], zw * c["a1"]
+    L = t * (c["d_air"] + G * ig + W * iw)
+    Lt = c["d_air"] + G * ig ** 3 + W * iw ** 3
+    Ltt = -3 * t * (qg * G * ig ** 5 + qw * W * iw ** 5)
+    return L, Lt, Ltt, c["a1"] * t * iw, c["a1"] * iw ** 3
+
+
+def _port_sine(c, zw, t):
+    """the same five values through s = sin(theta_air) and 1 / cos(theta_m) (rounds 4-5's form; the textbook statement of the port)"""
     r = 1.0 / np.sqrt(1.0 + t * t)
     s = t * r
     icg = 1.0 / np.sqrt(1.0 - c["a0"] ** 2 * s * s)
@@ -34,18 +46,20 @@ def _port(c, zw, t):
     return L, Lt, Ltt, Lz, Lzt
 
 
-def _start(c, zw, rho):
-    """the kernel's start: thin port with an effective depth, then once more for the water alone with the port's offsets at t0"""
+def _start(c, zw, rho, dtype=np.float32):
+    """the kernel's start (port_start_f32: fp32 arithmetic since round 6 -- the start is good to 1e-4 by construction): thin port with an
+    effective depth, then once more for the water alone with the port's offsets at t0"""
+    f = dtype
     a1 = c["a1"]
-    q1, a12 = 1.0 - a1 * a1, a1 * a1
-    ze = zw + (c["d_air"] + c["d_glass"] * c["a0"]) / a1
-    u = rho / ze
-    t0 = u / np.sqrt(np.maximum(a12 - q1 * u * u, 1e-6))
-    r = 1.0 / np.sqrt(1.0 + t0 * t0)
-    s = t0 * r
-    icg = 1.0 / np.sqrt(1.0 - c["a0"] ** 2 * s * s)
-    u1 = np.maximum((rho - c["d_air"] * t0 - c["d_glass"] * c["a0"] * s * icg) / zw, 0.0)
-    return t0, u1 / np.sqrt(np.maximum(a12 - q1 * u1 * u1, 1e-6))
+    q1, a12, qg = f(1.0 - a1 * a1), f(a1 * a1), f(1.0 - c["a0"] ** 2)
+    c0, dair, Gd0 = f((c["d_air"] + c["d_glass"] * c["a0"]) / a1), f(c["d_air"]), f(c["d_glass"] * c["a0"])
+    zw, rho = zw.astype(f), rho.astype(f)
+    u = rho / (zw + c0)
+    t0 = u / np.sqrt(np.maximum(a12 - q1 * u * u, f(1e-6)))
+    wg = f(1) / np.sqrt(f(1) + qg * t0 * t0)                             # tan(theta_glass) = a0 t0 wg
+    u1 = np.maximum((rho - t0 * (dair + Gd0 * wg)) / zw, f(0))
+    t1 = u1 / np.sqrt(np.maximum(a12 - q1 * u1 * u1, f(1e-6)))
+    return t0.astype(np.float64), t1.astype(np.float64)
 
 
 def _halley(c, zw, rho, t):
@@ -96,6 +110,20 @@ def test_closed_form_start_and_one_halley_step():
     # and without the carry they would be first order in the step: the carry is what keeps the Jacobian consistent
     _, Lt_s, _, Lz_s, _ = _port(c, zw, t1)
     assert np.abs(Lt_s / Lt - 1)[inner].max() > 10 * dLt[inner].max()
+
+
+def test_the_tangent_form_is_the_port_equation():
+    """port_eval_n's form against the sine form (the same function written the textbook way): values and derivatives to rounding"""
+    c = _consts()
+    zw, rho, t_true = _grid(c)
+    t = t_true * (1 + 1e-4)
+    for a, b, name in zip(_port(c, zw, t), _port_sine(c, zw, t), ("L", "L_t", "L_tt", "L_z", "L_zt")):
+        err = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+        print(f"[port] tangent form vs sine form, {name}: {err.max():.2e}")
+        assert err.max() < 5e-13, name                                   # (the sine form cancels in 1 - a^2 s^2 towards the rim)
+    # and the fp32 start is the double start to fp32 rounding: nothing the Halley step could notice
+    t1_32, t1_64 = _start(c, zw, rho)[1], _start(c, zw, rho, np.float64)[1]
+    assert np.abs(t1_32 - t1_64).max() < 2e-5 * max(1.0, t_true.max())
 
 
 def test_forward_projection_inverts_the_ray_construction():
