@@ -596,37 +596,48 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
 {
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;
     constexpr int NQ = 8;                                 // ray q = 2 k + c: corner k, camera c
-    double r2[NQ][3], P1[NQ][3];                          // the ray in the water and its exit point on the outer glass face
+    double rL[4][3], rR[4][3], PL[4][3], PR[4][3];        // per corner: the two rays in the water and their exit points on the outer glass face, left frame
     if (NZ && vc.sqrt_minus0 && vc.sqrt_minus1) {
         // The port square to the camera and both refractions towards the normal's side (the reference's configuration; wave-uniform):
-        // everything follows from the image point (x, y) and three reciprocal square roots.  With s0 = 1 / |(x, y, 1)| = cos(theta_air):
-        //   cos(theta_glass) = root0 = sqrt(1 - alpha0^2 (1 - s0^2)),  cos(theta_water) = root1 = sqrt(1 - alpha1^2 (1 - root0^2)),
-        //   r2 = (alpha0 alpha1 s0 x, alpha0 alpha1 s0 y, root1),
-        //   P1 = d_air r0 / s0 + d_glass r1 / root0 = ((d_air + d_glass alpha0 s0 / root0) x, (same) y, d_air + d_glass)
-        // -- the same numbers as the general form below (vision.cpp:505-552) without normalising r0, without the two divisions.
-        double xx[NQ], yy[NQ], n2[NQ], s0[NQ], x1[NQ], y1[NQ], x2[NQ], y2[NQ];
+        // everything follows from the image point (x, y) -- t^2 = x^2 + y^2 is the squared tangent in air -- and TWO reciprocal square roots
+        // (round 6, in the tangent as port_eval_n: tan(theta_m) = a_m t / sqrt(1 + (1 - a_m^2) t^2), a_glass = alpha0, a_water = a = alpha0 alpha1):
+        //   x_g = 1 + (1 - alpha0^2) t^2,  x_w = 1 + (1 - a^2) t^2,
+        //   ray ~ (a x, a y, sqrt(x_w))          -- the unit vector of vision.cpp:524-543 times 1 / cos(theta_air): the mid-point of two rays
+        //                                           does not depend on their lengths
+        //   exit = ((d_air + d_glass alpha0 / sqrt(x_g)) x, (same) y, d_air + d_glass)
+        // and the right camera's pair in the left frame (vision.cpp:555-556) from ONE product u = a R_RL(:, 0:1) (x, y):
+        //   ray_R = u + R_RL(:, 2) sqrt(x_w),   exit_R = ((d_air + d_glass alpha0 / sqrt(x_g)) / a) u + (R_RL(:, 2) (d_air + d_glass) + P_LR)
+        // Rounds 4-5 went through cos(theta_air) = 1 / |(x, y, 1)| and the two cosines root0, root1 of vision.cpp:505-543 (three reciprocal
+        // square roots per ray) and rotated ray and exit point separately: 821 -> 653 instructions per marker in isolation, tools/stage_meas_isa.hip (EXPERIMENTS -1.11).
+        double xx[NQ], yy[NQ], t2[NQ], xg[NQ], xw[NQ], ig[NQ], iw[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const T* p = (q & 1) ? yr : yl;
             xx[q] = (double)p[2 * (q >> 1)]; yy[q] = (double)p[2 * (q >> 1) + 1];
-            n2[q] = xx[q] * xx[q] + yy[q] * yy[q] + 1.0;
+            t2[q] = xx[q] * xx[q] + yy[q] * yy[q];
         }
-        md_rsq_n<NS, NQ>(n2, s0);
+        const double a01 = vc.tri[11], qg = 1.0 - vc.alpha0 * vc.alpha0, qw = 1.0 - a01 * a01;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) x1[q] = 1.0 - vc.alpha0 * vc.alpha0 * (1.0 - s0[q] * s0[q]);
-        md_rsq_n<NS, NQ>(x1, y1);
+        for (int q = 0; q < NQ; ++q) { xg[q] = 1.0 + qg * t2[q]; xw[q] = 1.0 + qw * t2[q]; }
+        md_rsq_n<NS, NQ>(xg, ig);
+        md_rsq_n<NS, NQ>(xw, iw);
+        const double zP = vc.d_air + vc.d_glass, ga = vc.d_glass * vc.alpha0;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { const double root0 = x1[q] * y1[q]; x2[q] = 1.0 - vc.alpha1 * vc.alpha1 * (1.0 - root0 * root0); }
-        md_rsq_n<NS, NQ>(x2, y2);
-        const double zP = vc.d_air + vc.d_glass, a01 = vc.alpha0 * vc.alpha1, ga = vc.d_glass * vc.alpha0;
+        for (int k = 0; k < 4; ++k) {
+            const int qL = 2 * k, qR = 2 * k + 1;
+            const double cpL = vc.d_air + ga * ig[qL], cpR = vc.tri[9] + vc.tri[10] * ig[qR], swR = xw[qR] * iw[qR];
+            rL[k][0] = a01 * xx[qL]; rL[k][1] = a01 * yy[qL]; rL[k][2] = xw[qL] * iw[qL];
+            PL[k][0] = cpL * xx[qL]; PL[k][1] = cpL * yy[qL]; PL[k][2] = zP;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const double c2 = a01 * s0[q], cp = vc.d_air + ga * s0[q] * y1[q];
-            r2[q][0] = c2 * xx[q]; r2[q][1] = c2 * yy[q]; r2[q][2] = x2[q] * y2[q];
-            P1[q][0] = cp * xx[q]; P1[q][1] = cp * yy[q]; P1[q][2] = zP;
+            for (int i = 0; i < 3; ++i) {
+                const double u = vc.tri[2 * i] * xx[qR] + vc.tri[2 * i + 1] * yy[qR];
+                rR[k][i] = u + vc.R_RL[3 * i + 2] * swR;
+                PR[k][i] = cpR * u + vc.tri[6 + i];
+            }
         }
     } else {
         const double* n = vc.nrm;
+        double r2[NQ][3], P1[NQ][3];                      // the ray in the water and its exit point, each in its own camera's frame
         double r0[NQ][3], r1[NQ][3], v0[NQ], v1[NQ], x[NQ], y[NQ], iv0[NQ], iv1[NQ];
     #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -675,19 +686,23 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
                 P1[q][i] = aq * r0[q][i] + gq * r1[q][i];      // exit point on the outer glass face (vision.cpp:546-552)
             }
         }
+        // the right ray in the left frame (vision.cpp:555-556)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int qL = 2 * k, qR = 2 * k + 1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                rL[k][i] = r2[qL][i]; PL[k][i] = P1[qL][i];
+                rR[k][i] = vc.R_RL[3 * i] * r2[qR][0] + vc.R_RL[3 * i + 1] * r2[qR][1] + vc.R_RL[3 * i + 2] * r2[qR][2];
+                PR[k][i] = vc.R_RL[3 * i] * P1[qR][0] + vc.R_RL[3 * i + 1] * P1[qR][1] + vc.R_RL[3 * i + 2] * P1[qR][2] + vc.P_LR[i];
+            }
+        }
     }
-    // the right ray in the left frame (vision.cpp:555-556), mid-point of the two rays by Cramer (vision.cpp:559-595)
-    double d3[4], id3[4], t1[4], t2[4], rL[4][3], rR[4][3], PL[4][3], PR[4][3];
+    // mid-point of the two rays by Cramer (vision.cpp:559-595)
+    double d3[4], id3[4], t1[4], t2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int qL = 2 * k, qR = 2 * k + 1;
         double dP[3], cr[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            rL[k][i] = r2[qL][i]; PL[k][i] = P1[qL][i];
-            rR[k][i] = vc.R_RL[3 * i] * r2[qR][0] + vc.R_RL[3 * i + 1] * r2[qR][1] + vc.R_RL[3 * i + 2] * r2[qR][2];
-            PR[k][i] = vc.R_RL[3 * i] * P1[qR][0] + vc.R_RL[3 * i + 1] * P1[qR][1] + vc.R_RL[3 * i + 2] * P1[qR][2] + vc.P_LR[i];
-        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) dP[i] = PR[k][i] - PL[k][i];
         cross3(rL[k], rR[k], cr);

@@ -569,6 +569,14 @@ VisConst<T> make_vc(const fbus_ekf* h)
     vc.sqrt_minus1 = p.n_glass > p.n_water;     // vision.cpp:532
     vc.d_air = (T)p.d_air; vc.d_glass = (T)p.d_glass;
     for (int i = 0; i < 3; ++i) vc.nrm[i] = (T)p.port_normal[i];
+    {
+        const double a = (p.n_air / p.n_glass) * (p.n_glass / p.n_water);
+        for (int i = 0; i < 3; ++i) {
+            vc.tri[2 * i] = (T)(a * Rrl[3 * i]); vc.tri[2 * i + 1] = (T)(a * Rrl[3 * i + 1]);
+            vc.tri[6 + i] = (T)(Rrl[3 * i + 2] * (p.d_air + p.d_glass) + (double)vc.P_LR[i]);
+        }
+        vc.tri[9] = (T)(p.d_air / a); vc.tri[10] = (T)(p.d_glass * (p.n_air / p.n_glass) / a); vc.tri[11] = (T)a;
+    }
     return vc;
 }
 

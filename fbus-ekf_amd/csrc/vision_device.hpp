@@ -25,6 +25,10 @@ struct VisConst {
     int sqrt_minus0, sqrt_minus1;   // which branch of :513-522 / :532-541 applies
     T d_air, d_glass;
     T nrm[3];
+    // (round 6) constants of the square-port triangulation in the tangent (ekf_meas.hpp::tri_corners_refractive), a = alpha0 alpha1:
+    //   tri[2 i], tri[2 i + 1] = a R_RL(i, 0), a R_RL(i, 1);  tri[6 + i] = R_RL(i, 2) (d_air + d_glass) + P_LR(i);
+    //   tri[9] = d_air / a,  tri[10] = d_glass alpha0 / a,  tri[11] = a
+    T tri[12];
 };
 
 template <typename T> __device__ __forceinline__ T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
