@@ -294,6 +294,82 @@ struct PixAcc {
 #pragma unroll
         for (int i = 0; i < 3; ++i) { sa[i] += a[i] * res; sc[i] += c[i] * res; }
     }
+    // (round 6) the two rows of a projection in the camera frame (pixel_fold_marker<..., CF>): the radial one (three components) and the
+    // tangential one (third component zero: 24 operations instead of 33).  Sums of two products are spelled out as one product and one fma --
+    // which product the compiler fuses otherwise depends on the kernel around it, and the window of frames must equal the sequence of frames
+    // bit for bit (see direct_update_part).
+    static __device__ __forceinline__ double dm2(double a, double b, double c, double d) { return __builtin_fma(a, b, -(c * d)); }   // a b - c d
+    static __device__ __forceinline__ double dp3(double a0, double b0, double a1, double b1, double a2, double b2)
+    {
+        return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+    }
+    __device__ __forceinline__ void add_row_cf(const double* a, double res, const double* r)
+    {
+        const double c[3] = { dm2(a[1], r[2], a[2], r[1]), dm2(a[2], r[0], a[0], r[2]), dm2(a[0], r[1], a[1], r[0]) };
+        Saa[0] += a[0] * a[0]; Saa[1] += a[0] * a[1]; Saa[2] += a[0] * a[2];
+        Saa[3] += a[1] * a[1]; Saa[4] += a[1] * a[2]; Saa[5] += a[2] * a[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Sac[3 * i + j] += a[i] * c[j];
+        Scc[0] += c[0] * c[0]; Scc[1] += c[0] * c[1]; Scc[2] += c[0] * c[2];
+        Scc[3] += c[1] * c[1]; Scc[4] += c[1] * c[2]; Scc[5] += c[2] * c[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { sa[i] += a[i] * res; sc[i] += c[i] * res; }
+    }
+    __device__ __forceinline__ void add_row_xy(double a0, double a1, double res, const double* r)
+    {
+        const double c[3] = { a1 * r[2], -(a0 * r[2]), dm2(a0, r[1], a1, r[0]) };
+        Saa[0] += a0 * a0; Saa[1] += a0 * a1; Saa[3] += a1 * a1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Sac[j] += a0 * c[j]; Sac[3 + j] += a1 * c[j]; }
+        Scc[0] += c[0] * c[0]; Scc[1] += c[0] * c[1]; Scc[2] += c[0] * c[2];
+        Scc[3] += c[1] * c[1]; Scc[4] += c[1] * c[2]; Scc[5] += c[2] * c[2];
+        sa[0] += a0 * res; sa[1] += a1 * res;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sc[i] += c[i] * res;
+    }
+    // (round 6) sums folded in a CAMERA frame (rows j, their theta parts c' = j x Y with Y = M^-T r) -> what finish() expects.  The IMU-frame
+    // rows are a = M' j, c = a x r = adj(M) c'  ((A u) x (A v) = cof(A) (u x v)), so  S_aa = M' S_jj M,  S_ac = M' S_jc' adj(M)',
+    // S_cc = adj(M) S_c'c' adj(M)',  s_a = M' s_j,  s_c = adj(M) s_c'.  The M' ... M parts are not formed: finish() rotates S_aa, S_ac, s_a by
+    // R anyway, and R (M' . M) R' = (R M') . (R M')' -- the caller hands finish() RM = R M' (camera_rotation) instead of R.  Here only the
+    // adj(M) parts: S_ac <- S_jc' adj(M)', S_cc <- adj(M) S_c'c' adj(M)', s_c <- adj(M) s_c'  (~110 operations once per filter).
+    __device__ __forceinline__ void to_imu_frame(const double* A)
+    {
+        {
+            double T1[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) T1[3 * i + k] = dp3(Sac[3 * i], A[3 * k], Sac[3 * i + 1], A[3 * k + 1], Sac[3 * i + 2], A[3 * k + 2]);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Sac[i] = T1[i];
+        }
+        {
+            const double Sf[9] = { Scc[0], Scc[1], Scc[2], Scc[1], Scc[3], Scc[4], Scc[2], Scc[4], Scc[5] };
+            double T1[9];                                                        // S_c'c' adj(M)'
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) T1[3 * i + k] = dp3(Sf[3 * i], A[3 * k], Sf[3 * i + 1], A[3 * k + 1], Sf[3 * i + 2], A[3 * k + 2]);
+            int o = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = i; k < 3; ++k) Scc[o++] = dp3(A[3 * i], T1[k], A[3 * i + 1], T1[3 + k], A[3 * i + 2], T1[6 + k]);
+        }
+        const double sp[3] = { sc[0], sc[1], sc[2] };
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sc[i] = dp3(A[3 * i], sp[0], A[3 * i + 1], sp[1], A[3 * i + 2], sp[2]);
+    }
+    // RM = R M' (see to_imu_frame)
+    static __device__ __forceinline__ void camera_rotation(const double* R, const double* M, double* RM)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) RM[3 * i + k] = dp3(R[3 * i], M[3 * k], R[3 * i + 1], M[3 * k + 1], R[3 * i + 2], M[3 * k + 2]);
+    }
     // -> the 6 x 6 information matrix (upper triangle, lidx order) and vector of the stacked rows
     //    Lam_pp = w R S_aa R',  Lam_pt = -w R S_ac,  Lam_tt = w S_cc,  b_p = -w R s_a,  b_t = w s_c
     __device__ __forceinline__ void finish(const double* R, double w, double* Lam, double* b) const
@@ -348,11 +424,20 @@ __device__ __forceinline__ void filter_pil(const double* R, const double* P_IL, 
 // wgt (round 6): 1 for a marker of the map, 0 for a slot whose id is not in it -- the callers fold EVERY slot (with slot 0's frame for the
 // unknown ones, rows of weight 0) instead of branching around the fold per lane: the divergent branch cost ~70 instructions per marker
 // (exec-mask bookkeeping and zero-initialised merge values for the 27 sums) and saved work only when all 64 filters of a wave skip.
-template <int NCAM, typename T, bool NZ, int NK = 4, int K0 = 0>
+// CF (round 6; left camera, square port): the rows are folded IN THE CAMERA FRAME, rotated into the radial and the tangential direction of the
+// image point (the pixel noise is isotropic: sum a a' and sum a res do not change).  There they are sparse --
+//     j_rad = (e_0 / L_t, e_1 / L_t, -c2),   j_tan = (-k e_1, k e_0, 0)          (c1 + k = 1 / L_t; on the axis e = (1, 0))
+// -- no product with M per row (a = M' j: 32 operations per projection) and a short tangential row; their theta parts are c' = j x Y with
+// Y = M^-T R'(c_w - p) (three more 3 x 3 products per marker), and PixAcc::to_imu_frame turns the sums into the IMU-frame ones once per filter:
+// 906 -> 825 arithmetic instructions per marker in the compiled loop (EXPERIMENTS -1.12).  The same rows for BOTH cameras (the right camera's
+// taken to the left camera's frame, 15 operations per projection) was built and is slower: the stereo fold goes corner by corner over N' =
+// sum j j' (PixAcc::add_corner), where the sparse rows save little, and its two halves would each form the Y_k.
+template <int NCAM, typename T, bool NZ, int NK = 4, int K0 = 0, bool CF = false>
 __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, const double* R, const double* pil,
                                                   const MeasConst& mc, const double* mkc, const T* yl, const T* yr, double size, double wgt = 1.0)
 {
     static_assert(NK >= 1 && K0 >= 0 && K0 + NK <= 4, "corners of one marker");
+    static_assert(!CF || (NZ && NCAM == 1), "the camera-frame fold: left camera, square port");
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;           // Newton steps behind v_rsq_f64 / v_rcp_f64
     constexpr int NP = NK * NCAM;
     double ru[4][3], rAx[3], rAy[3];
@@ -377,7 +462,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
     }
     const double* n = mc.n;
     // per projection q = (corner k, camera c): lateral offset, depth, visibility, and the start of the port equation's solution
-    double lat[NP][3], rho[NP], irho[NP], Wd[NP], vis[NP], t[NP];
+    double lat[NP][3], rho[NP], irho[NP], Wd[NP], vis[NP], t[NP], Yc[CF ? NK : 1][3];
     {
         double X[NP][3], z[NP], r2[NP], zwq[NP], r2s[NP], xs[NP], ir0[NP], zsq[NP];
         bool ok[NP];
@@ -399,6 +484,23 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
                     X[k * NCAM + c][i] = kk == 0 ? X0[i] : (kk == 1 ? X0[i] + MAy[i] : (kk == 2 ? X0[i] + MAy[i] + MAx[i] : X0[i] + MAx[i]));
+            }
+        }
+        if constexpr (CF) {
+            // Y_k = McL^-T ru_k, as X: corner 0 and the two edges, the others by addition
+            double Y0[3], YAx[3], YAy[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Y0[i] = PixAcc::dp3(mc.MiTL[3 * i], ru[0][0], mc.MiTL[3 * i + 1], ru[0][1], mc.MiTL[3 * i + 2], ru[0][2]);
+                YAx[i] = PixAcc::dp3(mc.MiTL[3 * i], rAx[0], mc.MiTL[3 * i + 1], rAx[1], mc.MiTL[3 * i + 2], rAx[2]);
+                YAy[i] = PixAcc::dp3(mc.MiTL[3 * i], rAy[0], mc.MiTL[3 * i + 1], rAy[1], mc.MiTL[3 * i + 2], rAy[2]);
+            }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int kk = K0 + k;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    Yc[k][i] = kk == 0 ? Y0[i] : (kk == 1 ? Y0[i] + YAy[i] : (kk == 2 ? Y0[i] + YAy[i] + YAx[i] : Y0[i] + YAx[i]));
             }
         }
         if constexpr (NZ) {
@@ -475,6 +577,26 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
     double kk[NP], uv[NP][2], a[NP][2][3], res[NP][2];
 #pragma unroll
     for (int q = 0; q < NP; ++q) kk[q] = (irho[q] > 0.0) ? t[q] * irho[q] : iLt[q];          // t / rho; on the axis its limit 1 / L_t
+    if constexpr (CF) {
+        double e[NP][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            uv[q][0] = kk[q] * lat[q][0];
+            uv[q][1] = kk[q] * lat[q][1];
+            e[q][0] = (irho[q] > 0.0) ? lat[q][0] * irho[q] : 1.0;          // on the axis any direction will do
+            e[q][1] = lat[q][1] * irho[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int k = K0 + q;
+            const double r0 = (double)yl[2 * k] - uv[q][0], r1 = (double)yl[2 * k + 1] - uv[q][1];
+            const double jr = iLt[q] * vis[q], kv = kk[q] * vis[q];
+            const double jrad[3] = { jr * e[q][0], jr * e[q][1], -(c2[q] * vis[q]) };
+            acc.add_row_cf(jrad, __builtin_fma(e[q][1], r1, e[q][0] * r0), Yc[q]);                                  // res_rad = e . res
+            acc.add_row_xy(-(kv * e[q][1]), kv * e[q][0], PixAcc::dm2(e[q][0], r1, e[q][1], r0), Yc[q]);            // res_tan = e_perp . res
+        }
+        return;
+    }
     if constexpr (NZ) {
         double e[NP][2], eM[NP][3];
 #pragma unroll
@@ -1369,7 +1491,7 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
             for (int k = 0; k < 8; ++k) yl_[k] = slot >= 0 ? cur.l[k] : T(0);
 #pragma unroll
             for (int k = 0; k < NRR; ++k) yr_[k] = slot >= 0 ? cur.r[k] : T(0);
-            if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
+            if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ, 4, 0, true>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
             else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
             else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
             else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
@@ -1397,6 +1519,14 @@ correct_pixels2_kernel(T* __restrict__ recs, int B, int M, const int* __restrict
         }
     }
     if (!live || nfold == 0.0) { if (b < B) applied[b] = 0; return; }
+    if constexpr (CAM == 1) {                                           // (the left-only kernel folds in the camera frame)
+        acc.to_imu_frame(mc.adjL);
+        double RM[9];
+        PixAcc::camera_rotation(Rd, mc.McL, RM);
+        meas_update_tail<T, N>(rs, lane, acc, RM, 1.0 / r_pix, -1, gpark_mem + lane);
+        applied[b] = 1;
+        return;
+    }
     meas_update_tail<T, N>(rs, lane, acc, Rd, 1.0 / r_pix, -1, gpark_mem + lane);
     applied[b] = 1;
 }
@@ -1770,7 +1900,7 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
                 for (int k = 0; k < 8; ++k) yl_[k] = slot >= 0 ? cur.l[k] : T(0);
 #pragma unroll
                 for (int k = 0; k < NRR; ++k) yr_[k] = slot >= 0 ? cur.r[k] : T(0);
-                if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
+                if constexpr (CAM == 1) pixel_fold_marker<1, T, NZ, 4, 0, true>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
                 else if constexpr (CAM == 2) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
                 else if (stereo) pixel_fold_marker_stereo_halves<T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yr_, size, wgt);
                 else pixel_fold_marker<1, T, NZ>(acc, pd, Rd, pil, mc, mk, yl_, yl_, size, wgt);
@@ -1856,7 +1986,13 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
     }
     if constexpr (KIND == MEAS_CORNERS) acc.expand_const(mc.NI);
     T dx[N];
-    meas_solve_update<T, N, !WINDOW && NZ>(P, acc, Rd, 1.0 / r_meas, dx);      // (packed pairs: the one-frame square-port kernels)
+    if constexpr (KIND == MEAS_PIXELS && CAM == 1) {                            // (the left-only kernel folds in the camera frame)
+        acc.to_imu_frame(mc.adjL);
+        double RM[9];
+        PixAcc::camera_rotation(Rd, mc.McL, RM);
+        meas_solve_update<T, N, !WINDOW && NZ>(P, acc, RM, 1.0 / r_meas, dx);
+    } else
+        meas_solve_update<T, N, !WINDOW && NZ>(P, acc, Rd, 1.0 / r_meas, dx);  // (packed pairs: the one-frame square-port kernels)
     inject<T, N>(nom, dx);
     if (new_prev >= 0) P[L::OFF_PREV - L::OFF_COV] = (T)new_prev;
     if constexpr (!WINDOW) {

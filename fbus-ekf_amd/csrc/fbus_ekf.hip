@@ -612,6 +612,15 @@ MeasConst make_mc(const fbus_ekf* h)
         for (int i = 0; i < 3; ++i)
             for (int j = i; j < 3; ++j) mc.NI[o++] = Mm[i] * Mm[j] + Mm[3 + i] * Mm[3 + j] + Mm[6 + i] * Mm[6 + j];
     }
+    {   // adj(McL) (cofactors transposed) and McL^-T = cof(McL) / det
+        const double* m = mc.McL;
+        const double adj[9] = { (m[4] * m[8] - m[5] * m[7]), (m[2] * m[7] - m[1] * m[8]), (m[1] * m[5] - m[2] * m[4]),
+                                (m[5] * m[6] - m[3] * m[8]), (m[0] * m[8] - m[2] * m[6]), (m[2] * m[3] - m[0] * m[5]),
+                                (m[3] * m[7] - m[4] * m[6]), (m[1] * m[6] - m[0] * m[7]), (m[0] * m[4] - m[1] * m[3]) };
+        const double det = m[0] * adj[0] + m[1] * adj[3] + m[2] * adj[6];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) { mc.adjL[3 * i + j] = adj[3 * i + j]; mc.MiTL[3 * i + j] = adj[3 * j + i] / det; }
+    }
     mc.a0 = p.n_air / p.n_glass;
     mc.a1 = p.n_air / p.n_water;
     mc.d_air = p.d_air; mc.d_glass = p.d_glass;

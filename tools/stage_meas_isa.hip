@@ -7,7 +7,7 @@
 #include "ekf_kernels.hpp"
 #include "ekf_meas.hpp"
 namespace {
-template <int NCAM, int NMK>
+template <int NCAM, int NMK, bool CF = false>
 __global__ void __launch_bounds__(64) fold_kernel(const double* __restrict__ in, const float* __restrict__ y, double* __restrict__ out, MeasConst mc)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
@@ -23,8 +23,9 @@ __global__ void __launch_bounds__(64) fold_kernel(const double* __restrict__ in,
         for (int i = 0; i < 9; ++i) mk[i] = mc.mkc[m * 9 + i];
         float yl[8], yr[8];
         for (int i = 0; i < 8; ++i) { yl[i] = y[(b * NMK + m) * 16 + i]; yr[i] = y[(b * NMK + m) * 16 + 8 + i]; }
-        pixel_fold_marker<NCAM, float, true>(acc, p, R, pil, mc, mk, yl, NCAM == 2 ? yr : yl, 0.15);
+        pixel_fold_marker<NCAM, float, true, 4, 0, CF>(acc, p, R, pil, mc, mk, yl, NCAM == 2 ? yr : yl, 0.15);
     }
+    if constexpr (CF) acc.to_imu_frame(mc.adjL);
     for (int i = 0; i < PixAcc::NVAL; ++i) out[b * 32 + i] = acc.at(i);
 }
 // the corner-position fold (correct_corners): triangulation through the square port + 12 position rows per marker
@@ -61,6 +62,8 @@ const void* fbus_stage_meas_keep(int s)
         case 1: return (const void*)fold_kernel<1, 1>;
         case 2: return (const void*)fold_kernel<1, 2>;
         case 3: return (const void*)fold_kernel<2, 1>;
+        case 5: return (const void*)fold_kernel<1, 0, true>;
+        case 6: return (const void*)fold_kernel<1, 1, true>;
         default: return (const void*)fold_kernel<2, 2>;
     }
 }
