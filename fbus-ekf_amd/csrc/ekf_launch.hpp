@@ -68,6 +68,7 @@ struct MeasConst {
     double NI[6];                   // R_IL' R_IL (symmetric: 00 01 02 11 12 22): the N' of a corner's three position rows
     double n[3];                    // port normal
     double a0, a1, d_air, d_glass;  // n_air / n_glass, n_air / n_water
+    double klim;                    // (round 6) (0.9 a1)^2 / (1 - a1^2): the field-of-view test of the fold (a division per marker when left to the kernel)
     double MiTL[9], adjL[9];        // (round 6) McL^-T and adj(McL) = det(McL) McL^-1: the camera-frame fold of the left-only kernels
                                     // (ekf_meas.hpp::pixel_fold_marker<..., CF = true>, PixAcc::to_imu_frame)
     float st[8];                    // (round 6) constants of the fp32 start of the port equation (ekf_meas.hpp::port_start_f32):

@@ -463,6 +463,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
     const double* n = mc.n;
     // per projection q = (corner k, camera c): lateral offset, depth, visibility, and the start of the port equation's solution
     double lat[NP][3], rho[NP], irho[NP], Wd[NP], vis[NP], t[NP], Yc[CF ? NK : 1][3];
+    bool offax[NP];                                       // the point is off the camera's axis (on it: rho = 0, lat = 0, 1 / rho stands for 1)
     {
         double X[NP][3], z[NP], r2[NP], zwq[NP], r2s[NP], xs[NP], ir0[NP], zsq[NP];
         bool ok[NP];
@@ -523,11 +524,11 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         }
         // in front of the port and inside its field of view (in water no ray leans further than asin(n_air / n_water); 0.9 of that
         // limit, as the oracle): otherwise the corner contributes no rows to this camera.  A point out of view is replaced by a
-        // harmless one on the axis (rho = 0, 1 / rho = 0, one metre of water): everything below stays finite, its rows get weight 0
-        const double klim = 0.81 * mc.a1 * mc.a1 / (1.0 - mc.a1 * mc.a1);      // (0.9 a1)^2 / (1 - a1^2): wave-uniform
+        // harmless one (rho = 0, one metre of water; 1 / rho stands for 1 wherever rho = 0): everything below stays finite, its rows get weight 0
+        const double klim = mc.klim;                                             // (0.9 a1)^2 / (1 - a1^2), from the host
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            ok[q] = (zwq[q] > 0.0) && (r2[q] < klim * zwq[q] * zwq[q]);
+            ok[q] = (zwq[q] > 0.0) & (r2[q] < klim * zwq[q] * zwq[q]);      // (&, not &&: the short circuit compiled to two exec-mask regions per projection)
             vis[q] = ok[q] ? wgt : 0.0;
             r2s[q] = ok[q] ? r2[q] : 0.0;
             zsq[q] = ok[q] ? zwq[q] : 1.0;
@@ -536,7 +537,7 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
         }
         md_rsq_n<NS, NP>(xs, ir0);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) { irho[q] = (r2s[q] > 0.0) ? ir0[q] : 0.0; rho[q] = r2s[q] * irho[q]; }
+        for (int q = 0; q < NP; ++q) { offax[q] = r2s[q] > 0.0; irho[q] = ir0[q]; rho[q] = r2s[q] * irho[q]; }
         // Start: the THIN-port solution in closed form, twice.  With the port's own offsets folded into an effective water depth
         // z_e = z_w + (d_air + d_glass a0) / a1 (exact in the paraxial limit) the equation is rho = z_e tan(theta_water) with
         // sin(theta_water) = a1 sin(theta_air):  t0 = u / sqrt(a1^2 - (1 - a1^2) u^2),  u = rho / z_e  -- within 1.4e-3 of the root for
@@ -576,14 +577,14 @@ __device__ __forceinline__ void pixel_fold_marker(PixAcc& acc, const double* p, 
     }
     double kk[NP], uv[NP][2], a[NP][2][3], res[NP][2];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) kk[q] = (irho[q] > 0.0) ? t[q] * irho[q] : iLt[q];          // t / rho; on the axis its limit 1 / L_t
+    for (int q = 0; q < NP; ++q) kk[q] = offax[q] ? t[q] * irho[q] : iLt[q];                 // t / rho; on the axis its limit 1 / L_t
     if constexpr (CF) {
         double e[NP][2];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             uv[q][0] = kk[q] * lat[q][0];
             uv[q][1] = kk[q] * lat[q][1];
-            e[q][0] = (irho[q] > 0.0) ? lat[q][0] * irho[q] : 1.0;          // on the axis any direction will do
+            e[q][0] = offax[q] ? lat[q][0] * irho[q] : 1.0;                 // on the axis any direction will do
             e[q][1] = lat[q][1] * irho[q];
         }
 #pragma unroll

@@ -624,6 +624,7 @@ MeasConst make_mc(const fbus_ekf* h)
     mc.a0 = p.n_air / p.n_glass;
     mc.a1 = p.n_air / p.n_water;
     mc.d_air = p.d_air; mc.d_glass = p.d_glass;
+    mc.klim = 0.81 * mc.a1 * mc.a1 / (1.0 - mc.a1 * mc.a1);
     mc.st[0] = (float)mc.a1; mc.st[1] = (float)(mc.a1 * mc.a1); mc.st[2] = (float)(1.0 - mc.a1 * mc.a1); mc.st[3] = (float)(1.0 - mc.a0 * mc.a0);
     mc.st[4] = (float)mc.d_air; mc.st[5] = (float)(mc.d_glass * mc.a0); mc.st[6] = (float)((mc.d_air + mc.d_glass * mc.a0) / mc.a1); mc.st[7] = 0.f;
     mc.mkc = h->d_mkc;
