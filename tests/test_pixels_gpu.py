@@ -120,6 +120,74 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo, cov_form, monkeypatc
             assert np.linalg.eigvalsh(Ps / (dg[:, :, None] * dg[:, None, :])).min() > 0
 
 
+def test_a_corner_exactly_on_the_camera_axis():
+    """The fold's on-axis case (rho = 0: t / rho is its limit 1 / L_t, and the camera-frame rows of the left-only kernel take e = (1, 0) there)
+    is measure-zero in every other scene.  Here the extrinsics are the identity (T_SC_left = 1: McL = F R_IL = 1, P_IL = 0), the filter sits at the
+    origin with R = 1 and marker 0's first corner at (0, 0, 1): its lateral offset is exactly zero in the kernels' arithmetic.  fp64 and fp32
+    (one-wave left-only kernel, divided-tail kernel, stereo never: the right camera is somewhere else) against the analytic oracle."""
+    B, M, dialect = 128, 2, 0
+    prm = capi.default_params(dialect)
+    prm.marker_size = SIZE
+    for i in range(16):
+        prm.T_SC_left[i] = 1.0 if i % 5 == 0 else 0.0
+    for i in range(3):
+        prm.marker_pos[0][i] = (0.0, 0.0, 1.0)[i]
+    for i in range(9):
+        prm.marker_rot[0][i] = 1.0 if i % 4 == 0 else 0.0
+    R_IL, P_IL, Q_IL = synth.camera_constants(prm)
+    assert np.array_equal(np.diag([-1.0, -1.0, 1.0]) @ R_IL, np.eye(3)) and not P_IL.any()
+    vp = oc.vision_params()
+    for i in range(9):
+        vp.R_IL[i] = 1.0 if i % 4 == 0 else 0.0
+    for i in range(3):
+        vp.P_LI[i] = 0.0
+    mid0 = int(prm.marker_id[0])
+    nom0, _, P, prev = synth.initial_state(0, B, list(prm.p0_diag), 18, mixed_cov=True)
+    nom = np.array(nom0, float)
+    nom[:, 0:3] = 0.0
+    nom[:, 6:10] = (1.0, 0.0, 0.0, 0.0)
+    nom = r32(nom)
+    rot = r32(synth.q2R(nom[:, 6:10]).reshape(B, 9))
+    assert np.array_equal(rot[0].reshape(3, 3), np.eye(3))
+    cam = np.array([[0, 0, 1.0], [0, SIZE, 1.0], [SIZE, SIZE, 1.0], [SIZE, 0, 1.0]]) @ R_IL.T    # the marker's corners in the left camera frame: R_IL (c - p)
+    uvL, _, ok = oc.project_stereo(vp, cam, stereo=False)
+    assert ok.all() and not uvL[0].any()                                                        # corner 0 projects to the principal point
+    rng = np.random.default_rng(5)
+    ids = np.full((B, M), -1, np.int32); ids[:, 0] = mid0
+    left = np.zeros((B, M, 8))
+    left[:, 0, :] = uvL.reshape(8) + rng.normal(0, 5e-4, (B, 8))
+    left, P = r32(left), r32(P)
+    eng = OracleEngine(B, dialect, 18, cov_form=oc.JOSEPH)
+    for i in range(9):
+        eng.orc.prm.R_IL[i] = float(R_IL.reshape(9)[i])
+    for i in range(3):
+        eng.orc.prm.P_IL[i] = 0.0
+        eng.orc.prm.marker_pos[0][i] = (0.0, 0.0, 1.0)[i]
+    for i in range(4):
+        eng.orc.prm.Q_IL[i] = float(Q_IL[i])
+        eng.orc.prm.marker_quat[0][i] = (1.0, 0.0, 0.0, 0.0)[i]
+    eng.set_state(nom, rot, P, prev)
+    ok = eng.orc.correct_pixels(eng.nominal, eng.rot, eng.P, eng.prev, ids, left, None, SIZE, prm.r_pix, vision=vp, analytic=True)
+    assert ok.all()
+    want = eng.get_state()
+    assert np.abs(want[0][:, 0:3] - nom[:, 0:3]).max() > 1e-5                                  # the update did something
+    for dtype, roles in ((64, 1), (32, 1), (32, 0)):
+        with BatchedFilter(B, prm, dtype=dtype) as flt:
+            flt.set_team(0, roles)
+            flt.set_state(nom, rot, P, prev)
+            flt.correct_pixels(ids, left, None)
+            got = flt.get_state()
+            assert flt.applied().all()
+        e = parity_errors(got, want)
+        print(f"[parity] a corner on the camera axis, correct_pixels left fp{dtype} correct_roles {roles}: literal {e['literal']:.2e} "
+              f"sigma-aware {e['sigma']:.2e} cov block-wise {e['cov_block']:.2e}")
+        assert np.isfinite(got[0]).all() and np.isfinite(got[2]).all()
+        if dtype == 64:
+            assert e["literal"] < F64_TOL and e["sigma"] < F64_TOL and e["cov_block"] < F64_TOL
+        else:
+            assert e["literal"] <= STATE_TOL and e["sigma"] <= STATE_TOL and e["plain"] <= PLAIN_TOL and e["cov_block"] <= COV_BLOCK_TOL
+
+
 def test_the_fifteen_state_filter_takes_the_same_updates():
     """north_star's literal filter has 15 error states (per-corner 2 x 15 Jacobians): N = 18 without the gravity block.  The reprojection-row
     update (left, stereo) and the corner-row update through the N = 15 kernels against the N = 15 oracle, standard gates."""
