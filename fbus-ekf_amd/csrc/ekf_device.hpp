@@ -38,6 +38,9 @@
 #ifndef FBUS_X_PACK_TEAM
 #define FBUS_X_PACK_TEAM 9      // the team kernels (ekf_team.hpp): all four bits cost frames_team_kernel 48 bytes of scratch
 #endif
+#ifndef FBUS_X_PACK_FMEAS_CPP_STEREO
+#define FBUS_X_PACK_FMEAS_CPP_STEREO 0
+#endif
 #ifndef FBUS_X_PACK_FMEAS
 #define FBUS_X_PACK_FMEAS 1     // frame_meas_kernel (512 registers around the fp64 fold): the nominal step only -- bits 1-3 add 12-76 bytes of scratch; bit 0 keeps its nominal arithmetic the one of predict_n (the fused frame and predict_n + update then agree to the single-step gate: tests/test_frame_meas_gpu.py)
 #endif

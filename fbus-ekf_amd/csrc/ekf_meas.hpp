@@ -1854,7 +1854,10 @@ frame_meas_kernel(T* __restrict__ recs, int B, int F, FrameCounts kc, const T* _
     {
         // K ImuUpdates; under the covariance stages of the last one the first marker's image points are requested
         auto first_marker = [&]() __attribute__((always_inline)) { if (M > 0) fetch(0, cur); };
-        predict_steps<T, N, DIALECT, decltype(first_marker), NoStepPark, FBUS_X_PACK_FMEAS>(nom, P, K, accel + (size_t)k0 * B * 3, gyro + (size_t)k0 * B * 3, dt + (size_t)k0 * (dt_stride ? B : 1),
+        // (the C++-dialect stereo frame -- 256 + 256 registers -- spilled 36 bytes with the packed nominal step; its window takes the same mask:
+        // the window of frames equals the sequence of frames bit for bit only while both run the same ImuUpdate instructions)
+        constexpr int PKM = (KIND == MEAS_PIXELS && CAM == 2 && DIALECT == 1) ? FBUS_X_PACK_FMEAS_CPP_STEREO : FBUS_X_PACK_FMEAS;
+        predict_steps<T, N, DIALECT, decltype(first_marker), NoStepPark, PKM>(nom, P, K, accel + (size_t)k0 * B * 3, gyro + (size_t)k0 * B * 3, dt + (size_t)k0 * (dt_stride ? B : 1),
                                      dt_stride, B, b, qd.qd, first_marker);
         k0 += K;
         order_fence();
