@@ -239,9 +239,10 @@ void launch_pixels2_k(hipStream_t s, T* recs, int B, int M, const int* ids, cons
     } while (0)
     if (roles >= 3) { FBUS_LAUNCH_PX(4); return; }
     if (roles == 2) { FBUS_LAUNCH_PX(2); return; }
-    if constexpr (sizeof(T) == 4) {
-        // (round 6) one wave per tile, square port, fp32 records -- the full-chip production case: the left-camera and the stereo update as
-        // kernels of their own (CAM = 1 / 2: neither carries the other's image points and register pressure; EXPERIMENTS -1.7)
+    {
+        // (round 6) one wave per tile, square port -- the full-chip production case: the left-camera and the stereo update as kernels of their
+        // own (CAM = 1 / 2: neither carries the other's image points and register pressure; EXPERIMENTS -1.7; fp64 records too: 16 slots
+        // 92 -> 85-90 us left, 137 -> 125-132 us stereo, 4 slots stereo 69 -> 63 us, profiles/r06_f64_cam_ab.txt)
         if (nz) {
             if (right) hipLaunchKernelGGL((correct_pixels2_kernel<T, N, 1, true, 2>), dim3(tiles), dim3(64), 0, s, recs, B, M, ids, left, right,
                                           size, r_pix, skip, applied, id2slot, mc);

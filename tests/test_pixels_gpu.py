@@ -72,7 +72,7 @@ def test_correct_pixels_matches_the_oracle(dialect, stereo, cov_form, monkeypatc
     # an updater wave per tile; fp32, square port); the one-wave kernel (set_team correct_roles = 1), and -- with FBUS_MEAS_SPLIT=0, read
     # at fbus_ekf_create -- the two- and four-role forms of correct_pixels2_kernel (the markers divided among the waves of a tile, one
     # tail) go through the same gate
-    for dtype, roles, split in ((64, 0, None), (32, 0, None), (32, 1, None), (32, 2, None), (32, 2, "0"), (32, 0, "0")):
+    for dtype, roles, split in ((64, 0, None), (64, 1, None), (32, 0, None), (32, 1, None), (32, 2, None), (32, 2, "0"), (32, 0, "0")):
         if split is not None:
             monkeypatch.setenv("FBUS_MEAS_SPLIT", split)
         else:
