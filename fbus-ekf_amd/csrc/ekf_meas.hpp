@@ -720,13 +720,38 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
     constexpr int NS = sizeof(T) == 8 ? 2 : 1;
     constexpr int NQ = 8;                                 // ray q = 2 k + c: corner k, camera c
     double rL[4][3], rR[4][3], PL[4][3], PR[4][3];        // per corner: the two rays in the water and their exit points on the outer glass face, left frame
+    // mid-point of the two rays by Cramer (vision.cpp:559-595).  Inlined behind each of the two ray constructions: the square-port one hands it
+    // left rays with z component exactly 1 (a literal the compiler sees: four operations per corner less in the cross products)
+    auto midpoints = [&]() __attribute__((always_inline)) {
+        double d3[4], id3[4], t1[4], t2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double dP[3], cr[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dP[i] = PR[k][i] - PL[k][i];
+            cross3(rL[k], rR[k], cr);
+            d3[k] = cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2];       // det(cr, rL, rR) = cr . (rL x rR) = |cr|^2
+            t1[k] = det3cols(cr, dP, rR[k]);
+            t2[k] = -det3cols(cr, rL[k], dP);
+        }
+        md_rcp_n<NS, 4>(d3, id3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t1[k] *= id3[k]; t2[k] *= id3[k];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double Pm = 0.5 * (PL[k][i] + t1[k] * rL[k][i] + PR[k][i] + t2[k] * rR[k][i]);
+                C[k][i] = (i < 2) ? -Pm : Pm;                 // vision.cpp:597-599
+            }
+        }
+    };
     if (NZ && vc.sqrt_minus0 && vc.sqrt_minus1) {
         // The port square to the camera and both refractions towards the normal's side (the reference's configuration; wave-uniform):
         // everything follows from the image point (x, y) -- t^2 = x^2 + y^2 is the squared tangent in air -- and TWO reciprocal square roots
         // (round 6, in the tangent as port_eval_n: tan(theta_m) = a_m t / sqrt(1 + (1 - a_m^2) t^2), a_glass = alpha0, a_water = a = alpha0 alpha1):
         //   x_g = 1 + (1 - alpha0^2) t^2,  x_w = 1 + (1 - a^2) t^2,
         //   ray ~ (a x, a y, sqrt(x_w))          -- the unit vector of vision.cpp:524-543 times 1 / cos(theta_air): the mid-point of two rays
-        //                                           does not depend on their lengths
+        //                                           does not depend on their lengths (the left one is taken at z = 1: times 1 / sqrt(x_w))
         //   exit = ((d_air + d_glass alpha0 / sqrt(x_g)) x, (same) y, d_air + d_glass)
         // and the right camera's pair in the left frame (vision.cpp:555-556) from ONE product u = a R_RL(:, 0:1) (x, y):
         //   ray_R = u + R_RL(:, 2) sqrt(x_w),   exit_R = ((d_air + d_glass alpha0 / sqrt(x_g)) / a) u + (R_RL(:, 2) (d_air + d_glass) + P_LR)
@@ -749,7 +774,8 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
         for (int k = 0; k < 4; ++k) {
             const int qL = 2 * k, qR = 2 * k + 1;
             const double cpL = vc.d_air + ga * ig[qL], cpR = vc.tri[9] + vc.tri[10] * ig[qR], swR = xw[qR] * iw[qR];
-            rL[k][0] = a01 * xx[qL]; rL[k][1] = a01 * yy[qL]; rL[k][2] = xw[qL] * iw[qL];
+            const double aL = a01 * iw[qL];                                  // the left ray scaled to z = 1: 1 / sqrt(x_w) = i_w
+            rL[k][0] = aL * xx[qL]; rL[k][1] = aL * yy[qL]; rL[k][2] = 1.0;
             PL[k][0] = cpL * xx[qL]; PL[k][1] = cpL * yy[qL]; PL[k][2] = zP;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -758,6 +784,7 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
                 PR[k][i] = cpR * u + vc.tri[6 + i];
             }
         }
+        midpoints();
     } else {
         const double* n = vc.nrm;
         double r2[NQ][3], P1[NQ][3];                      // the ray in the water and its exit point, each in its own camera's frame
@@ -820,28 +847,7 @@ __device__ __forceinline__ void tri_corners_refractive(const VisConst<double>& v
                 PR[k][i] = vc.R_RL[3 * i] * P1[qR][0] + vc.R_RL[3 * i + 1] * P1[qR][1] + vc.R_RL[3 * i + 2] * P1[qR][2] + vc.P_LR[i];
             }
         }
-    }
-    // mid-point of the two rays by Cramer (vision.cpp:559-595)
-    double d3[4], id3[4], t1[4], t2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double dP[3], cr[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) dP[i] = PR[k][i] - PL[k][i];
-        cross3(rL[k], rR[k], cr);
-        d3[k] = cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2];       // det(cr, rL, rR) = cr . (rL x rR) = |cr|^2
-        t1[k] = det3cols(cr, dP, rR[k]);
-        t2[k] = -det3cols(cr, rL[k], dP);
-    }
-    md_rcp_n<NS, 4>(d3, id3);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        t1[k] *= id3[k]; t2[k] *= id3[k];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double Pm = 0.5 * (PL[k][i] + t1[k] * rL[k][i] + PR[k][i] + t2[k] * rR[k][i]);
-            C[k][i] = (i < 2) ? -Pm : Pm;                 // vision.cpp:597-599
-        }
+        midpoints();
     }
 }
 
