@@ -1,10 +1,12 @@
 #!/bin/bash
 # (any round; R=$2, default 06) the reprojection-row update at 65 536 filters x 16 marker slots -- launch times (the round-3 kernel it replaced: profiles/r04_pixels_times.txt),
-# kernel trace and SQ counters (own passes: --pmc never together with other trace domains).  TAG=$1 names the output directory.
+# kernel trace and SQ counters (own passes: --pmc never together with other trace domains).  TAG=$1 names the output directory;
+# $3 (optional): extra arguments of tools/run_pixels.py for the profiled passes, e.g. --stereo (the digest then describes that launch).
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}" || exit 1
 TAG=${1:-a}
 R=${2:-06}
+export XARGS="${3:-}"
 export OUT=gpurun_out/r${R}/pix_$TAG
 mkdir -p $OUT
 python3 tools/run_pixels.py --both > $OUT/times.txt 2>&1
@@ -12,9 +14,9 @@ python3 tools/run_pixels.py --both > $OUT/times.txt 2>&1
 python3 tools/run_pixels.py --both --batch 16384 --slots 4 >> $OUT/times.txt 2>&1
 python3 bench.py --only-pixels > $OUT/north_star_rows.json 2> $OUT/north_star_rows.err
 cat $OUT/times.txt
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/run_pixels.py > $OUT/trace.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p1 -- python3 tools/run_pixels.py > $OUT/p1.log 2>&1
-timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p2 -- python3 tools/run_pixels.py > $OUT/p2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/run_pixels.py $XARGS > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/p1 -- python3 tools/run_pixels.py $XARGS > $OUT/p1.log 2>&1
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p2 -- python3 tools/run_pixels.py $XARGS > $OUT/p2.log 2>&1
 timeout 120 python3 - <<'PY' | tee $OUT/summary.txt
 import csv, glob, collections, json, os
 out = os.environ["OUT"]
@@ -45,7 +47,7 @@ if fs: shutil.copy(fs[-1], f"{out}/kernel_stats.csv")
 mhz = (per.get("GRBM_GUI_ACTIVE", 0) / 8 / us) if us else None      # GRBM_GUI_ACTIVE sums the 8 XCDs
 if name is None:
     raise SystemExit("no correct_pixels row in the kernel trace: nothing to summarise")
-d = {"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "batch": 65536, "marker_slots": 16, "camera": "left", "waves": grid, "simds": 1024,
+d = {"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "batch": 65536, "marker_slots": 16, "camera": "stereo" if "--stereo" in os.environ.get("XARGS", "") else "left", "waves": grid, "simds": 1024,
      "avg_launch_us_kernel_trace": us, "launch_us_is": "median of the kernel-trace dispatches", "clock_MHz": mhz,
      "SQ_INSTS_VALU_per_wave": per.get("SQ_INSTS_VALU", 0) / max(grid, 1), "counters_per_launch": per}
 if us and per.get("SQ_INSTS_VALU") and mhz:
